@@ -1,0 +1,218 @@
+/* zkmi — C ABI of the MI355X-native proving backend for the Shielder
+ * proof-generation hot path (BLS12-381, Groth16-shaped workload).
+ *
+ * The reference (/root/reference = Cardinal-Cryptography/zk-apps @ v2) has no
+ * FFI of its own.  Each entry point below is what a Rust
+ * shim behind the reference's only "prover API" would bind — the inherent
+ * methods of mocked_zk::relations::ZkProof
+ *   new              shielder/mocked_zk/src/relations.rs:37-55
+ *   update_account   shielder/mocked_zk/src/relations.rs:79-98   (prove step,
+ *                    called at shielder/contract/drink_tests/utils/shielder.rs:105-114)
+ *   verify_creation  shielder/mocked_zk/src/relations.rs:127-136 (contract/lib.rs:56)
+ *   verify_update    shielder/mocked_zk/src/relations.rs:138-155 (contract/lib.rs:74)
+ * and the arithmetic stages they stand in for.
+ * INTEGRATION.md shows the reference-side `extern "C"` block.
+ *
+ * Conventions
+ *   - every function returns int32_t: 0 = ZKMI_OK, negative = error; no
+ *     exceptions or aborts cross the ABI; zkmi_last_error() gives a string.
+ *   - Fr  : 32-byte little-endian canonical integer < r   (= Scalar{bytes:[u8;32]},
+ *           shielder/mocked_zk/src/scalar.rs:1-30)
+ *   - Fq  : 48-byte little-endian canonical integer < p
+ *   - G1 affine : x || y (96 B);  G2 affine : x.c0 || x.c1 || y.c0 || y.c1 (192 B);
+ *     all-zero bytes = point at infinity
+ *   - proof : 192 B = compressed A (48) || B (96) || C (48), zcash/IETF big-endian
+ *   - caller owns every buffer; the library never frees caller memory; device
+ *     state lives behind opaque handles bound to one HIP device; a ctx is not
+ *     thread-safe (one ctx per host thread / process / GPU).
+ *   - *_dev entry points take pointers into HBM (e.g. torch tensors'
+ *     data_ptr()); all other pointers are host memory.
+ */
+#ifndef ZKMI_H
+#define ZKMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKMI_OK 0
+#define ZKMI_ERR_BAD_ARG (-1)
+#define ZKMI_ERR_NON_CANONICAL (-2)   /* Fr/Fq >= modulus, point not on curve */
+#define ZKMI_ERR_HIP (-3)             /* HIP runtime error (see zkmi_last_error) */
+#define ZKMI_ERR_NO_DEVICE (-4)       /* no gfx950 device / HIP extension unusable */
+#define ZKMI_ERR_VERIFICATION (-5)    /* = ZkpError::VerificationError   (mocked_zk/src/errors.rs:3-7) */
+#define ZKMI_ERR_ACCOUNT_UPDATE (-6)  /* = ZkpError::AccountUpdateError */
+#define ZKMI_ERR_OPERATION_COMBINE (-7) /* = ZkpError::OperationCombineError */
+#define ZKMI_ERR_UNSATISFIED (-8)     /* witness does not satisfy the relation */
+
+typedef struct zkmi_ctx zkmi_ctx;
+typedef struct zkmi_bases_g1 zkmi_bases_g1;
+typedef struct zkmi_bases_g2 zkmi_bases_g2;
+typedef struct zkmi_r1cs zkmi_r1cs;
+typedef struct zkmi_pk zkmi_pk;
+
+/* ---- library / context -------------------------------------------------- */
+const char* zkmi_version(void);
+int32_t zkmi_device_count(int32_t* out_count);
+int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx);
+int32_t zkmi_ctx_destroy(zkmi_ctx* ctx);
+const char* zkmi_last_error(const zkmi_ctx* ctx);
+int32_t zkmi_ctx_sync(zkmi_ctx* ctx);
+
+/* per-phase HIP-event timers on the ctx stream (bench.py's roofline leg) */
+#define ZKMI_PH_MSM_SORT 0
+#define ZKMI_PH_MSM_ACCUM_G1 1
+#define ZKMI_PH_MSM_REDUCE_G1 2
+#define ZKMI_PH_MSM_ACCUM_G2 3
+#define ZKMI_PH_MSM_REDUCE_G2 4
+#define ZKMI_PH_NTT 5
+#define ZKMI_PH_WITNESS 6
+#define ZKMI_PH_MISC 7
+int32_t zkmi_prof_enable(zkmi_ctx* ctx, int32_t on);
+int32_t zkmi_prof_reset(zkmi_ctx* ctx);
+int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64_t* out_launches);
+
+/* ---- row a6: Fr NTT ------------------------------------------------------ */
+/* In-place radix-2 transform of 2^log_n Fr elements, natural order in/out.
+ * inverse: 0 forward, 1 inverse (scaled by N^-1); coset: 0/1 (generator 7).
+ * Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft}_in_place + coset
+ * variants [not in reference tree; SURVEY.md row a6]. */
+int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset);
+/* Same on a device buffer holding Montgomery-form elements (the pipeline's
+ * internal representation). */
+int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data_mont, uint32_t log_n, int32_t inverse, int32_t coset);
+int32_t zkmi_fr_to_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n);
+int32_t zkmi_fr_from_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n);
+
+/* ---- rows a8 / a9: multi-scalar multiplication --------------------------- */
+/* Upload n affine points (wire format) and keep them resident in HBM in
+ * Montgomery form.  check != 0 additionally verifies y^2 = x^3 + b on the host. */
+int32_t zkmi_bases_g1_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g1** out);
+int32_t zkmi_bases_g1_free(zkmi_bases_g1* b);
+int32_t zkmi_bases_g2_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g2** out);
+int32_t zkmi_bases_g2_free(zkmi_bases_g2* b);
+/* Synthetic bases P0 = G, P_{i+1} = P_i + [0xC0FFEE]G generated on the device
+ * (SURVEY.md §8d).  Used by bench.py and the large-size property tests. */
+int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out);
+int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out);
+int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out_affine);
+int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first, uint64_t count, uint8_t* out_affine);
+
+/* sum_i scalars[i] * bases[i]; scalars are n x 32 B canonical LE in host memory.
+ * Replaces ark_ec::VariableBaseMSM::msm_bigint / halo2curves::msm::best_multiexp
+ * [not in reference tree; SURVEY.md rows a8, a9]. */
+int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g1* bases, uint8_t out_affine[96]);
+int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g2* bases, uint8_t out_affine[192]);
+/* scalars already resident in HBM (n x 32 B canonical LE) */
+int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases, uint8_t out_affine[96]);
+int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g2* bases, uint8_t out_affine[192]);
+
+/* Multi-GPU split of one large MSM (BASELINE config 3): each
+ * rank runs the bucket method over its slice of the points and emits one
+ * partial sum per window (nwin x 96 B affine, nwin <= 64); the ranks exchange
+ * these few KiB (RCCL all-gather of raw bytes, done by the host layer) and
+ * every rank combines locally.  *out_window_bits receives c. */
+int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin, uint32_t* out_window_bits);
+int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uint32_t nwin, uint32_t window_bits,
+                            uint8_t out_affine[96]);
+
+/* ---- group / encoding helpers (host) -------------------------------------- */
+int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]);
+int32_t zkmi_g1_decompress(const uint8_t in[48], uint8_t out_affine[96]);
+int32_t zkmi_g2_compress(const uint8_t affine[192], uint8_t out[96]);
+int32_t zkmi_g2_decompress(const uint8_t in[96], uint8_t out_affine[192]);
+int32_t zkmi_g1_mul(const uint8_t affine[96], const uint8_t scalar[32], uint8_t out_affine[96]);
+int32_t zkmi_g2_mul(const uint8_t affine[192], const uint8_t scalar[32], uint8_t out_affine[192]);
+int32_t zkmi_g1_add(const uint8_t a[96], const uint8_t b[96], uint8_t out_affine[96]);
+int32_t zkmi_g2_add(const uint8_t a[192], const uint8_t b[192], uint8_t out_affine[192]);
+int32_t zkmi_g1_generator(uint8_t out_affine[96]);
+int32_t zkmi_g2_generator(uint8_t out_affine[192]);
+/* reduced optimal-ate pairing e(P,Q) as 12 x 48-byte LE Fq coefficients in the
+ * tower basis c0.c0.c0, c0.c0.c1, c0.c1.c0, ... (Fq12 = Fq6[w], Fq6 = Fq2[v]) */
+int32_t zkmi_pairing(const uint8_t g1_affine[96], const uint8_t g2_affine[192], uint8_t out_fq12[576]);
+
+/* ---- rows a1-a5, a7: relation + witness ---------------------------------- */
+/* R1CS in CSR form; column 0 is the constant 1, columns [0, n_pub) are the
+ * instance variables; values are 32-byte canonical LE Fr. */
+int32_t zkmi_r1cs_create(uint32_t n_vars, uint32_t n_pub, uint32_t n_constraints,
+                         const uint32_t* a_rowptr, const uint32_t* a_col, const uint8_t* a_val,
+                         const uint32_t* b_rowptr, const uint32_t* b_col, const uint8_t* b_val,
+                         const uint32_t* c_rowptr, const uint32_t* c_col, const uint8_t* c_val,
+                         zkmi_r1cs** out);
+int32_t zkmi_r1cs_free(zkmi_r1cs* r);
+/* Shielder-shaped synthetic relation with 2^log_n variables and
+ * constraints + instance variables = 2^log_n; witness/public-input order as
+ * UpdateNoteInput::new / update_note_circuit
+ * (shielder/relations/src/relations/update_note.rs:47-88, :121, :127). */
+int32_t zkmi_shielder_r1cs(uint32_t log_n, zkmi_r1cs** out);
+int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z /* 2^log_n x 32 B */);
+int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, uint32_t* n_constraints, uint32_t* log_n);
+/* export matrix m (0=A,1=B,2=C) as CSR; pass NULL buffers to query nnz */
+int32_t zkmi_r1cs_export(const zkmi_r1cs* r, int32_t m, uint32_t* rowptr, uint32_t* col, uint8_t* val, uint64_t* nnz);
+int32_t zkmi_r1cs_is_satisfied(const zkmi_r1cs* r, const uint8_t* z);
+
+/* ---- rows a7, a10: Groth16 ------------------------------------------------ */
+/* Trusted setup with explicit toxic waste tau|alpha|beta|gamma|delta
+ * (5 x 32 B), heavy part (fixed-base multiplications) on the device.  The
+ * proving key stays resident in HBM; vk_out receives
+ *   alpha_g1 (96) | beta_g2 (192) | gamma_g2 (192) | delta_g2 (192) | n_pub x gamma_abc_g1 (96 each). */
+int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t toxic[160], zkmi_pk** out_pk,
+                           uint8_t* vk_out, uint64_t vk_cap);
+/* Load a proving key from host arrays in wire format (drop-in for a key
+ * produced by another Groth16 implementation). */
+int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t alpha_g1[96], const uint8_t beta_g1[96],
+                     const uint8_t beta_g2[192], const uint8_t delta_g1[96], const uint8_t delta_g2[192],
+                     const uint8_t* a_query, const uint8_t* b_g1_query, const uint8_t* b_g2_query,
+                     const uint8_t* h_query, const uint8_t* l_query, zkmi_pk** out_pk);
+int32_t zkmi_pk_free(zkmi_pk* pk);
+/* export one query of a resident key (0=a,1=b_g1,2=b_g2,3=h,4=l) in wire format */
+int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count, uint8_t* out);
+/* witness -> proof.  z = full assignment (n_vars x 32 B, z[0] = 1); r, s =
+ * prover randomness (32 B each, explicit so proofs are reproducible).
+ * Replaces ark_groth16::prover::create_proof_with_assignment [not in tree]. */
+int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r[32], const uint8_t s[32],
+                           uint8_t out_proof[192]);
+/* h-polynomial coefficients only (row a7), N x 32 B canonical LE */
+int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h);
+/* row a11: pairing check on the host CPU.  publics excludes the leading 1. */
+int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]);
+
+/* ---- row a12: the reference's prove/verify surface ------------------------ */
+#define ZKMI_MERKLE_TREE_DEPTH 10 /* shielder/mocked_zk/src/lib.rs:16 */
+#define ZKMI_TOKENS_NUMBER 2      /* shielder/mocked_zk/src/lib.rs:17 */
+typedef struct { uint8_t bytes[32]; } zkmi_scalar;                 /* scalar.rs:1-6 */
+typedef struct { zkmi_scalar balances[ZKMI_TOKENS_NUMBER][2]; } zkmi_account; /* account.rs:10-14, (token, balance) */
+typedef struct { uint32_t kind; /* 0 Deposit, 1 Withdraw */ uint8_t amount[16]; zkmi_scalar token; zkmi_scalar user; } zkmi_op_pub; /* ops.rs:4-25 */
+typedef struct { zkmi_scalar user; } zkmi_op_priv;                 /* ops.rs:28-37 */
+typedef struct {                                                   /* relations.rs:14-26 */
+  zkmi_scalar id, trapdoor_new, trapdoor_old, nullifier_new;
+  zkmi_account acc_old, acc_new;
+  zkmi_op_priv op_priv;
+  zkmi_scalar merkle_proof[ZKMI_MERKLE_TREE_DEPTH];
+  uint32_t merkle_proof_leaf_id;
+} zkmi_zkproof;
+int32_t zkmi_scalar_from_u128(const uint8_t le16[16], zkmi_scalar* out);      /* scalar.rs:14-24 */
+int32_t zkmi_scalar_to_u128(const zkmi_scalar* s, uint8_t out_le16[16]);      /* scalar.rs:26-30 */
+int32_t zkmi_account_new(const zkmi_scalar tokens[ZKMI_TOKENS_NUMBER], zkmi_account* out); /* account.rs:27-34 */
+int32_t zkmi_account_hash(const zkmi_account* a, zkmi_scalar* out);           /* account.rs:16-24 */
+int32_t zkmi_account_update(const zkmi_account* a, const zkmi_op_pub* op_pub, const zkmi_op_priv* op_priv, zkmi_account* out); /* account.rs:36-79 */
+int32_t zkmi_note_hash(const zkmi_scalar* id, const zkmi_scalar* trapdoor, const zkmi_scalar* nullifier,
+                       const zkmi_scalar* account_hash, zkmi_scalar* out);    /* note.rs:25-40 */
+int32_t zkmi_combine_merkle_hash(const zkmi_scalar* first, const zkmi_scalar* second, zkmi_scalar* out); /* lib.rs:24-28 */
+int32_t zkmi_operation_combine(const zkmi_op_pub* op_pub, const zkmi_op_priv* op_priv);   /* ops.rs:47-63 */
+int32_t zkmi_zkproof_new(const zkmi_scalar* id, const zkmi_scalar* trapdoor, const zkmi_scalar* nullifier,
+                         const zkmi_op_priv* op_priv, const zkmi_account* acc, zkmi_zkproof* out); /* relations.rs:37-55 */
+int32_t zkmi_zkproof_update_account(const zkmi_zkproof* self, const zkmi_op_pub* op_pub, const zkmi_op_priv* op_priv,
+                                    const zkmi_scalar* trapdoor, const zkmi_scalar* nullifier,
+                                    const zkmi_scalar merkle_proof[ZKMI_MERKLE_TREE_DEPTH], uint32_t leaf_id,
+                                    zkmi_scalar* out_h_note_new, zkmi_zkproof* out_new);  /* relations.rs:79-98 */
+int32_t zkmi_zkproof_verify_creation(const zkmi_zkproof* self, const zkmi_scalar* h_note_new,
+                                     const zkmi_scalar tokens[ZKMI_TOKENS_NUMBER]);       /* relations.rs:127-136 */
+int32_t zkmi_zkproof_verify_update(const zkmi_zkproof* self, const zkmi_op_pub* op_pub, const zkmi_scalar* h_note_new,
+                                   const zkmi_scalar* merkle_root, const zkmi_scalar* nullifier_old); /* relations.rs:138-155 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMI_H */

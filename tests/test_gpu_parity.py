@@ -1,0 +1,198 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the oracle, on the
+committed golden fixtures and on seeded inputs.  Bit-exact (integer work)."""
+import pytest
+
+from conftest import golden
+from oracle import bls12_381 as ec
+from oracle import groth16 as g16
+from oracle import ntt as ont
+from oracle.bls12_381 import R
+
+pytestmark = pytest.mark.gpu
+
+H = bytes.fromhex
+
+
+def frs(vals):
+    return b"".join(ec.fr_to_bytes(v) for v in vals)
+
+
+def unfrs(b):
+    return [int.from_bytes(b[i : i + 32], "little") for i in range(0, len(b), 32)]
+
+
+# ---------------------------------------------------------------- NTT (row a6)
+@pytest.mark.parametrize("case", golden("ntt_small.json"), ids=lambda c: f"log{c['log_n']}")
+def test_ntt_golden(ctx, case):
+    lg = case["log_n"]
+    x = H(case["input"])
+    assert ctx.ntt(x, lg) == H(case["forward"])
+    assert ctx.ntt(x, lg, inverse=True) == H(case["inverse"])
+    assert ctx.ntt(x, lg, coset=True) == H(case["coset_forward"])
+    assert ctx.ntt(x, lg, inverse=True, coset=True) == H(case["coset_inverse"])
+
+
+@pytest.mark.parametrize("lg", [4, 9, 11, 12, 13, 14])
+def test_ntt_vs_oracle_seeded(ctx, lg):
+    rng = ec.SplitMix64(1000 + lg)
+    a = [rng.fr() for _ in range(1 << lg)]
+    assert unfrs(ctx.ntt(frs(a), lg)) == ont.ntt(a)
+    assert unfrs(ctx.ntt(frs(a), lg, inverse=True, coset=True)) == ont.coset_intt(a)
+
+
+def test_ntt_rejects_non_canonical(ctx, pkg):
+    bad = (R).to_bytes(32, "little") + bytes(32)
+    with pytest.raises(pkg.ZkmiError) as e:
+        ctx.ntt(bad, 1)
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("lg", [16, 20])
+def test_ntt_large_properties(ctx, lg):
+    """Full-size checks through size-independent properties: round trip, coset
+    round trip, linearity, and the transform of a delta / constant."""
+    n = 1 << lg
+    rng = ec.SplitMix64(77 + lg)
+    # cheap pseudo-random canonical input: 31 random bytes per element
+    import random
+
+    rnd = random.Random(lg)
+    a = bytearray(rnd.randbytes(32 * n))
+    for i in range(31, 32 * n, 32):
+        a[i] &= 0x3F
+    a = bytes(a)
+    fwd = ctx.ntt(a, lg)
+    assert ctx.ntt(fwd, lg, inverse=True) == a
+    cf = ctx.ntt(a, lg, coset=True)
+    assert ctx.ntt(cf, lg, inverse=True, coset=True) == a
+    # delta at position 1 -> powers of w
+    d = bytearray(32 * n)
+    d[32] = 1
+    wpow = unfrs(ctx.ntt(bytes(d), lg))
+    w = ont.root_of_unity(lg)
+    for k in (0, 1, 2, 3, n // 2, n - 1, 12345 % n):
+        assert wpow[k] == pow(w, k, R)
+    # sum of outputs == n * a[0]
+    s = sum(unfrs(fwd)) % R
+    assert s == n * int.from_bytes(a[:32], "little") % R
+    # out[0] == sum of inputs
+    assert int.from_bytes(fwd[:32], "little") == sum(unfrs(a)) % R
+
+
+# ---------------------------------------------------------- MSM (rows a8, a9)
+@pytest.mark.parametrize("case", golden("msm_small.json"), ids=lambda c: c["name"])
+def test_msm_golden(ctx, case):
+    sc, bs = H(case["scalars"]), H(case["bases"])
+    if case["group"] == 1:
+        b = ctx.bases_g1(bs)
+        assert ctx.msm_g1(sc, b) == H(case["expected"])
+    else:
+        b = ctx.bases_g2(bs)
+        assert ctx.msm_g2(sc, b) == H(case["expected"])
+    b.free()
+
+
+def test_msm_empty(ctx):
+    b = ctx.bases_g1(ec.g1_to_bytes(ec.G1))
+    assert ctx.msm_g1(b"", b) == bytes(96)
+    b.free()
+
+
+def test_synthetic_bases_match_recipe(ctx):
+    c = golden("constants.json")
+    b = ctx.bases_g1_synthetic(2000)
+    assert [b.read(i, 1).hex() for i in range(4)] == c["synthetic_g1_first4"]
+    assert b.read(1000, 1).hex() == c["synthetic_g1_index_1000"]
+    b.free()
+    b2 = ctx.bases_g2_synthetic(130)
+    assert [b2.read(i, 1).hex() for i in range(4)] == c["synthetic_g2_first4"]
+    p129 = ec.pt_add(ec.Fq2, ec.G2, ec.g2_mul(129 * 0xC0FFEE))
+    assert b2.read(129, 1) == ec.g2_to_bytes(p129)
+    b2.free()
+
+
+@pytest.mark.parametrize("n", [300, 3000, 20000])
+def test_msm_g1_structured_vs_closed_form(ctx, n):
+    """With P_i = G + i*Q the MSM has a closed form:
+    sum s_i P_i = (sum s_i) G + (sum i*s_i) Q — checks every plan size."""
+    rng = ec.SplitMix64(n)
+    s = [rng.fr() for _ in range(n)]
+    b = ctx.bases_g1_synthetic(n)
+    got = ctx.msm_g1(frs(s), b)
+    q = ec.g1_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq, ec.g1_mul(sum(s) % R), ec.g1_mul(sum(i * v for i, v in enumerate(s)) % R, q))
+    assert got == ec.g1_to_bytes(exp)
+    b.free()
+
+
+@pytest.mark.parametrize("n", [300, 5000])
+def test_msm_g2_structured_vs_closed_form(ctx, n):
+    rng = ec.SplitMix64(7 * n)
+    s = [rng.fr() for _ in range(n)]
+    b = ctx.bases_g2_synthetic(n)
+    got = ctx.msm_g2(frs(s), b)
+    q = ec.g2_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq2, ec.g2_mul(sum(s) % R), ec.g2_mul(sum(i * v for i, v in enumerate(s)) % R, q))
+    assert got == ec.g2_to_bytes(exp)
+    b.free()
+
+
+def test_msm_g1_full_size_closed_form(ctx):
+    """BASELINE config 1 size (2^20) through the closed form above."""
+    import random
+
+    n = 1 << 20
+    rnd = random.Random(5)
+    raw = bytearray(rnd.randbytes(32 * n))
+    for i in range(31, 32 * n, 32):
+        raw[i] &= 0x3F
+    s = unfrs(bytes(raw))
+    b = ctx.bases_g1_synthetic(n)
+    got = ctx.msm_g1(bytes(raw), b)
+    q = ec.g1_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq, ec.g1_mul(sum(s) % R), ec.g1_mul(sum(i * v for i, v in enumerate(s)) % R, q))
+    assert got == ec.g1_to_bytes(exp)
+    b.free()
+
+
+# ------------------------------------------------- Groth16 (rows a7, a10, a11)
+def test_groth16_golden_n128(ctx, zk):
+    gd = golden("groth16_n128.json")
+    r1 = zk.shielder_r1cs(gd["log_n"])
+    z = zk.shielder_witness(gd["log_n"], gd["witness_seed"])
+    assert z == H(gd["witness"])
+    pk, vk = ctx.groth16_setup(r1, H(gd["toxic"]))
+    assert vk == H(gd["vk"])
+    for which, name in ((0, "a_query"), (1, "b_g1_query"), (2, "b_g2_query"), (3, "h_query"), (4, "l_query")):
+        exp = H(gd["pk"][name])
+        w = 192 if which == 2 else 96
+        assert pk.export_query(which, 0, len(exp) // w) == exp, name
+    assert ctx.groth16_witness_map(pk, z) == H(gd["h"])
+    proof = ctx.groth16_prove(pk, z, H(gd["r"]), H(gd["s"]))
+    assert proof == H(gd["proof"])
+    publics = z[32 : 32 * r1.n_pub]
+    assert zk.groth16_verify(vk, publics, proof) is True
+    bad = bytearray(publics)
+    bad[0] ^= 1
+    assert zk.groth16_verify(vk, bytes(bad), proof) is False
+    # key loaded from wire arrays gives the same proof (drop-in key format)
+    p = gd["pk"]
+    pk2 = ctx.pk_load(r1, H(p["alpha_g1"]), H(p["beta_g1"]), H(p["beta_g2"]), H(p["delta_g1"]), H(p["delta_g2"]),
+                      H(p["a_query"]), H(p["b_g1_query"]), H(p["b_g2_query"]), H(p["h_query"]), H(p["l_query"]))
+    assert ctx.groth16_prove(pk2, z, H(gd["r"]), H(gd["s"])) == H(gd["proof"])
+    pk.free()
+    pk2.free()
+
+
+@pytest.mark.parametrize("lg", [10, 14])
+def test_groth16_self_verifies(ctx, zk, lg):
+    """BASELINE config 0 size (2^14): proof must pass the pairing verifier."""
+    r1 = zk.shielder_r1cs(lg)
+    z = zk.shielder_witness(lg, 0x5A4B0000 + lg)
+    assert r1.is_satisfied(z)
+    rng = ec.SplitMix64(lg)
+    toxic = frs([rng.fr() for _ in range(5)])
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
+    assert zk.groth16_verify(vk, z[32 : 32 * r1.n_pub], proof) is True
+    pk.free()

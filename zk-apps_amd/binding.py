@@ -1,0 +1,481 @@
+"""ctypes binding of include/zkmi.h (one Python method per C entry point).
+
+Mirrors the reference's caller-side conventions: scalars are
+32-byte little-endian `bytes`, points are affine wire bytes, errors surface as
+`ZkmiError(code)` with the code names of `ZkpError`
+(shielder/mocked_zk/src/errors.rs:3-7) where they apply.
+"""
+import ctypes as C
+import os
+
+ERR = {
+    0: "OK",
+    -1: "BAD_ARG",
+    -2: "NON_CANONICAL",
+    -3: "HIP",
+    -4: "NO_DEVICE",
+    -5: "VerificationError",
+    -6: "AccountUpdateError",
+    -7: "OperationCombineError",
+    -8: "UNSATISFIED",
+}
+PHASES = {
+    "msm_sort": 0,
+    "msm_accum_g1": 1,
+    "msm_reduce_g1": 2,
+    "msm_accum_g2": 3,
+    "msm_reduce_g2": 4,
+    "ntt": 5,
+    "witness": 6,
+    "misc": 7,
+}
+MERKLE_TREE_DEPTH = 10
+TOKENS_NUMBER = 2
+
+
+class ZkmiError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        self.name = ERR.get(code, str(code))
+        super().__init__(f"zkmi error {code} ({self.name}) {detail}".strip())
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzkmi.so")
+
+
+class Scalar(C.Structure):
+    _fields_ = [("bytes", C.c_uint8 * 32)]
+
+
+class Account(C.Structure):
+    _fields_ = [("balances", (Scalar * 2) * TOKENS_NUMBER)]
+
+
+class OpPub(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("amount", C.c_uint8 * 16), ("token", Scalar), ("user", Scalar)]
+
+
+class OpPriv(C.Structure):
+    _fields_ = [("user", Scalar)]
+
+
+class ZkProof(C.Structure):
+    _fields_ = [
+        ("id", Scalar),
+        ("trapdoor_new", Scalar),
+        ("trapdoor_old", Scalar),
+        ("nullifier_new", Scalar),
+        ("acc_old", Account),
+        ("acc_new", Account),
+        ("op_priv", OpPriv),
+        ("merkle_proof", Scalar * MERKLE_TREE_DEPTH),
+        ("merkle_proof_leaf_id", C.c_uint32),
+    ]
+
+
+def scalar(b):
+    s = Scalar()
+    b = bytes(b)
+    assert len(b) == 32
+    C.memmove(s.bytes, b, 32)
+    return s
+
+
+def scalar_u128(v):
+    return scalar(int(v).to_bytes(16, "little") + bytes(16))
+
+
+def _buf(b):
+    return (C.c_uint8 * len(b)).from_buffer_copy(bytes(b)) if len(b) else (C.c_uint8 * 1)()
+
+
+class Zkmi:
+    """Loads libzkmi.so.  Fails loudly if it is missing (no fallback path)."""
+
+    def __init__(self, path=None):
+        path = path or lib_path()
+        if not os.path.exists(path):
+            raise ZkmiError(-4, f"{path} not built; run __graft_entry__.build()")
+        self.lib = C.CDLL(path)
+        self.lib.zkmi_version.restype = C.c_char_p
+        self.lib.zkmi_last_error.restype = C.c_char_p
+        self.lib.zkmi_last_error.argtypes = [C.c_void_p]
+
+    def version(self):
+        return self.lib.zkmi_version().decode()
+
+    def device_count(self):
+        n = C.c_int32(0)
+        self.lib.zkmi_device_count(C.byref(n))
+        return n.value
+
+    def _chk(self, rc, ctx=None):
+        if rc != 0:
+            detail = ""
+            if ctx is not None:
+                detail = (self.lib.zkmi_last_error(ctx) or b"").decode()
+            raise ZkmiError(rc, detail)
+
+    # ---- host-only helpers --------------------------------------------------
+    def g1_generator(self):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_g1_generator(out))
+        return bytes(out)
+
+    def g2_generator(self):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_g2_generator(out))
+        return bytes(out)
+
+    def g1_compress(self, a):
+        out = (C.c_uint8 * 48)()
+        self._chk(self.lib.zkmi_g1_compress(_buf(a), out))
+        return bytes(out)
+
+    def g1_decompress(self, a):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_g1_decompress(_buf(a), out))
+        return bytes(out)
+
+    def g2_compress(self, a):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_g2_compress(_buf(a), out))
+        return bytes(out)
+
+    def g2_decompress(self, a):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_g2_decompress(_buf(a), out))
+        return bytes(out)
+
+    def g1_mul(self, a, k):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_g1_mul(_buf(a), _buf(k), out))
+        return bytes(out)
+
+    def g2_mul(self, a, k):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_g2_mul(_buf(a), _buf(k), out))
+        return bytes(out)
+
+    def g1_add(self, a, b):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_g1_add(_buf(a), _buf(b), out))
+        return bytes(out)
+
+    def g2_add(self, a, b):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_g2_add(_buf(a), _buf(b), out))
+        return bytes(out)
+
+    def pairing(self, p, q):
+        out = (C.c_uint8 * 576)()
+        self._chk(self.lib.zkmi_pairing(_buf(p), _buf(q), out))
+        return bytes(out)
+
+    def msm_g1_combine(self, windows, n_ranks, nwin, window_bits):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_combine(_buf(windows), C.c_uint32(n_ranks), C.c_uint32(nwin), C.c_uint32(window_bits), out))
+        return bytes(out)
+
+    def groth16_verify(self, vk, publics, proof):
+        n_pub = (len(vk) - 672) // 96
+        assert len(publics) == 32 * (n_pub - 1)
+        rc = self.lib.zkmi_groth16_verify(_buf(vk), C.c_uint32(n_pub), _buf(publics), _buf(proof))
+        if rc == 0:
+            return True
+        if rc == -5:
+            return False
+        raise ZkmiError(rc)
+
+    # ---- R1CS ---------------------------------------------------------------
+    def shielder_r1cs(self, log_n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_shielder_r1cs(C.c_uint32(log_n), C.byref(h)))
+        return R1cs(self, h)
+
+    def shielder_witness(self, log_n, seed):
+        out = (C.c_uint8 * (32 << log_n))()
+        self._chk(self.lib.zkmi_shielder_witness(C.c_uint32(log_n), C.c_uint64(seed), out))
+        return bytes(out)
+
+    def r1cs_create(self, n_vars, n_pub, mats):
+        """mats = [(rowptr list, col list, val bytes)] * 3"""
+        args = []
+        keep = []
+        nc = len(mats[0][0]) - 1
+        for rowptr, col, val in mats:
+            rp = (C.c_uint32 * len(rowptr))(*rowptr)
+            cl = (C.c_uint32 * max(1, len(col)))(*col)
+            vl = _buf(val)
+            keep += [rp, cl, vl]
+            args += [rp, cl, vl]
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_r1cs_create(C.c_uint32(n_vars), C.c_uint32(n_pub), C.c_uint32(nc), *args, C.byref(h)))
+        return R1cs(self, h)
+
+    # ---- reference prove/verify surface (mocked_zk mirror) -------------------
+    def account_new(self, tokens):
+        arr = (Scalar * TOKENS_NUMBER)(*[scalar(t) for t in tokens])
+        acc = Account()
+        self._chk(self.lib.zkmi_account_new(arr, C.byref(acc)))
+        return acc
+
+    def account_hash(self, acc):
+        out = Scalar()
+        self._chk(self.lib.zkmi_account_hash(C.byref(acc), C.byref(out)))
+        return bytes(out.bytes)
+
+    def account_update(self, acc, op_pub, op_priv):
+        out = Account()
+        self._chk(self.lib.zkmi_account_update(C.byref(acc), C.byref(op_pub), C.byref(op_priv), C.byref(out)))
+        return out
+
+    def note_hash(self, id_, trapdoor, nullifier, acc_hash):
+        out = Scalar()
+        a = [scalar(x) for x in (id_, trapdoor, nullifier, acc_hash)]
+        self._chk(self.lib.zkmi_note_hash(*[C.byref(x) for x in a], C.byref(out)))
+        return bytes(out.bytes)
+
+    def combine_merkle_hash(self, first, second):
+        out = Scalar()
+        a, b = scalar(first), scalar(second)
+        self._chk(self.lib.zkmi_combine_merkle_hash(C.byref(a), C.byref(b), C.byref(out)))
+        return bytes(out.bytes)
+
+    def op_pub(self, kind, amount, token, user):
+        o = OpPub()
+        o.kind = {"deposit": 0, "withdraw": 1}[kind]
+        C.memmove(o.amount, int(amount).to_bytes(16, "little"), 16)
+        o.token = scalar(token)
+        o.user = scalar(user)
+        return o
+
+    def op_priv(self, user):
+        o = OpPriv()
+        o.user = scalar(user)
+        return o
+
+    def operation_combine(self, op_pub, op_priv):
+        self._chk(self.lib.zkmi_operation_combine(C.byref(op_pub), C.byref(op_priv)))
+
+    def zkproof_new(self, id_, trapdoor, nullifier, op_priv, acc):
+        out = ZkProof()
+        a = [scalar(x) for x in (id_, trapdoor, nullifier)]
+        self._chk(self.lib.zkmi_zkproof_new(*[C.byref(x) for x in a], C.byref(op_priv), C.byref(acc), C.byref(out)))
+        return out
+
+    def zkproof_update_account(self, proof, op_pub, op_priv, trapdoor, nullifier, merkle_proof, leaf_id):
+        out = ZkProof()
+        h = Scalar()
+        mp = (Scalar * MERKLE_TREE_DEPTH)(*[scalar(x) for x in merkle_proof])
+        t, n = scalar(trapdoor), scalar(nullifier)
+        self._chk(
+            self.lib.zkmi_zkproof_update_account(
+                C.byref(proof), C.byref(op_pub), C.byref(op_priv), C.byref(t), C.byref(n), mp, C.c_uint32(leaf_id), C.byref(h), C.byref(out)
+            )
+        )
+        return bytes(h.bytes), out
+
+    def zkproof_verify_creation(self, proof, h_note_new, tokens):
+        arr = (Scalar * TOKENS_NUMBER)(*[scalar(t) for t in tokens])
+        h = scalar(h_note_new)
+        self._chk(self.lib.zkmi_zkproof_verify_creation(C.byref(proof), C.byref(h), arr))
+
+    def zkproof_verify_update(self, proof, op_pub, h_note_new, merkle_root, nullifier_old):
+        a = [scalar(x) for x in (h_note_new, merkle_root, nullifier_old)]
+        self._chk(self.lib.zkmi_zkproof_verify_update(C.byref(proof), C.byref(op_pub), *[C.byref(x) for x in a]))
+
+    def context(self, device=0):
+        return Context(self, device)
+
+
+class R1cs:
+    def __init__(self, z, handle):
+        self.z, self.h = z, handle
+        nv, npub, nc, lg = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        z._chk(z.lib.zkmi_r1cs_shape(handle, C.byref(nv), C.byref(npub), C.byref(nc), C.byref(lg)))
+        self.n_vars, self.n_pub, self.n_constraints, self.log_n = nv.value, npub.value, nc.value, lg.value
+
+    def export(self, m):
+        nnz = C.c_uint64()
+        self.z._chk(self.z.lib.zkmi_r1cs_export(self.h, C.c_int32(m), None, None, None, C.byref(nnz)))
+        rp = (C.c_uint32 * (self.n_constraints + 1))()
+        cl = (C.c_uint32 * max(1, nnz.value))()
+        vl = (C.c_uint8 * max(1, 32 * nnz.value))()
+        self.z._chk(self.z.lib.zkmi_r1cs_export(self.h, C.c_int32(m), rp, cl, vl, None))
+        return list(rp), list(cl)[: nnz.value], bytes(vl)[: 32 * nnz.value]
+
+    def is_satisfied(self, zbytes):
+        rc = self.z.lib.zkmi_r1cs_is_satisfied(self.h, _buf(zbytes))
+        if rc == 0:
+            return True
+        if rc == -8:
+            return False
+        raise ZkmiError(rc)
+
+    def free(self):
+        if self.h:
+            self.z.lib.zkmi_r1cs_free(self.h)
+            self.h = None
+
+
+class Context:
+    """One HIP device + stream + resident workspaces (zkmi_ctx)."""
+
+    def __init__(self, z, device=0):
+        self.z = z
+        self.lib = z.lib
+        self.h = C.c_void_p()
+        z._chk(self.lib.zkmi_ctx_create(C.c_int32(device), C.byref(self.h)))
+
+    def _chk(self, rc):
+        self.z._chk(rc, self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.zkmi_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._chk(self.lib.zkmi_ctx_sync(self.h))
+
+    def prof_enable(self, on=True):
+        self._chk(self.lib.zkmi_prof_enable(self.h, C.c_int32(1 if on else 0)))
+
+    def prof_reset(self):
+        self._chk(self.lib.zkmi_prof_reset(self.h))
+
+    def prof_get(self, phase):
+        ms, cnt = C.c_double(), C.c_uint64()
+        self._chk(self.lib.zkmi_prof_get(self.h, C.c_int32(PHASES[phase]), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    # NTT
+    def ntt(self, data, log_n, inverse=False, coset=False):
+        assert len(data) == 32 << log_n
+        buf = _buf(data)
+        self._chk(self.lib.zkmi_ntt_fr(self.h, buf, C.c_uint32(log_n), C.c_int32(inverse), C.c_int32(coset)))
+        return bytes(buf)
+
+    def ntt_dev(self, dptr, log_n, inverse=False, coset=False):
+        self._chk(self.lib.zkmi_ntt_fr_dev(self.h, C.c_void_p(dptr), C.c_uint32(log_n), C.c_int32(inverse), C.c_int32(coset)))
+
+    def fr_to_mont_dev(self, dptr, n):
+        self._chk(self.lib.zkmi_fr_to_mont_dev(self.h, C.c_void_p(dptr), C.c_uint64(n)))
+
+    def fr_from_mont_dev(self, dptr, n):
+        self._chk(self.lib.zkmi_fr_from_mont_dev(self.h, C.c_void_p(dptr), C.c_uint64(n)))
+
+    # bases
+    def bases_g1(self, affine, check=True):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bases_g1_load(self.h, _buf(affine), C.c_uint64(len(affine) // 96), C.c_int32(check), C.byref(h)))
+        return Bases(self, h, 1, len(affine) // 96)
+
+    def bases_g2(self, affine, check=True):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bases_g2_load(self.h, _buf(affine), C.c_uint64(len(affine) // 192), C.c_int32(check), C.byref(h)))
+        return Bases(self, h, 2, len(affine) // 192)
+
+    def bases_g1_synthetic(self, n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bases_g1_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        return Bases(self, h, 1, n)
+
+    def bases_g2_synthetic(self, n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bases_g2_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        return Bases(self, h, 2, n)
+
+    # MSM
+    def msm_g1(self, scalars, bases):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1(self.h, _buf(scalars), C.c_uint64(len(scalars) // 32), bases.h, out))
+        return bytes(out)
+
+    def msm_g2(self, scalars, bases):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_msm_g2(self.h, _buf(scalars), C.c_uint64(len(scalars) // 32), bases.h, out))
+        return bytes(out)
+
+    def msm_g1_dev(self, dptr, n, bases):
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
+    def msm_g2_dev(self, dptr, n, bases):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_msm_g2_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
+    def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
+        out = (C.c_uint8 * (96 * 64))()
+        nwin, cbits = C.c_uint32(), C.c_uint32()
+        self._chk(
+            self.lib.zkmi_msm_g1_windows_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, C.c_uint64(plan_n), out, C.byref(nwin), C.byref(cbits))
+        )
+        return bytes(out)[: 96 * nwin.value], nwin.value, cbits.value
+
+    # Groth16
+    def groth16_setup(self, r1cs, toxic):
+        assert len(toxic) == 160
+        cap = 672 + 96 * r1cs.n_pub
+        vk = (C.c_uint8 * cap)()
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_groth16_setup(self.h, r1cs.h, _buf(toxic), C.byref(h), vk, C.c_uint64(cap)))
+        return ProvingKey(self, h, r1cs), bytes(vk)
+
+    def pk_load(self, r1cs, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, a_q, b1_q, b2_q, h_q, l_q):
+        h = C.c_void_p()
+        self._chk(
+            self.lib.zkmi_pk_load(
+                self.h, r1cs.h, _buf(alpha_g1), _buf(beta_g1), _buf(beta_g2), _buf(delta_g1), _buf(delta_g2),
+                _buf(a_q), _buf(b1_q), _buf(b2_q), _buf(h_q), _buf(l_q), C.byref(h),
+            )
+        )
+        return ProvingKey(self, h, r1cs)
+
+    def groth16_prove(self, pk, z, r, s):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_groth16_prove(self.h, pk.h, _buf(z), _buf(r), _buf(s), out))
+        return bytes(out)
+
+    def groth16_witness_map(self, pk, z):
+        out = (C.c_uint8 * (32 << pk.r1cs.log_n))()
+        self._chk(self.lib.zkmi_groth16_witness_map(self.h, pk.h, _buf(z), out))
+        return bytes(out)
+
+
+class Bases:
+    def __init__(self, ctx, h, group, n):
+        self.ctx, self.h, self.group, self.n = ctx, h, group, n
+
+    def read(self, first, count):
+        w = 96 if self.group == 1 else 192
+        out = (C.c_uint8 * (w * count))()
+        fn = self.ctx.lib.zkmi_bases_g1_read if self.group == 1 else self.ctx.lib.zkmi_bases_g2_read
+        self.ctx._chk(fn(self.ctx.h, self.h, C.c_uint64(first), C.c_uint64(count), out))
+        return bytes(out)
+
+    def free(self):
+        if self.h:
+            fn = self.ctx.lib.zkmi_bases_g1_free if self.group == 1 else self.ctx.lib.zkmi_bases_g2_free
+            fn(self.h)
+            self.h = None
+
+
+class ProvingKey:
+    def __init__(self, ctx, h, r1cs):
+        self.ctx, self.h, self.r1cs = ctx, h, r1cs
+
+    def export_query(self, which, first, count):
+        w = 192 if which == 2 else 96
+        out = (C.c_uint8 * (w * count))()
+        self.ctx._chk(self.ctx.lib.zkmi_pk_export_query(self.ctx.h, self.h, C.c_int32(which), C.c_uint64(first), C.c_uint64(count), out))
+        return bytes(out)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zkmi_pk_free(self.h)
+            self.h = None

@@ -1,0 +1,405 @@
+// zkmi — C ABI entry points (include/zkmi.h): context, NTT, MSM, group helpers.
+// Every function returns a status code; nothing throws across the boundary.
+#include <string.h>
+#include <new>
+#include <vector>
+#include "ctx.hpp"
+#include "msm_impl.hpp"  // msm_combine_windows (host)
+
+using namespace zkmi;
+
+namespace zkmi {
+hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t st);
+hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t st);
+}
+
+template <class B, class A, bool (*FROM)(const uint8_t*, A*, bool), int W>
+static int32_t bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, B** out) {
+  if (!ctx || !out || (n && !affine) || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  *out = nullptr;
+  // wire -> internal on the host (canonical check), upload Montgomery form
+  std::vector<A> h(n);
+  for (uint64_t i = 0; i < n; i++)
+    if (!FROM(affine + (uint64_t)W * i, &h[i], check != 0))
+      return ctx->fail(ZKMI_ERR_NON_CANONICAL, "base point not canonical / not on curve");
+  B* b = new (std::nothrow) B();
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  b->ctx = ctx;
+  b->n = n;
+  hipError_t e = hipMalloc(&b->d, sizeof(A) * (n ? n : 1));
+  if (e == hipSuccess && n) e = hipMemcpy(b->d, h.data(), sizeof(A) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (b->d) (void)hipFree(b->d);
+    delete b;
+    return ctx->hip_fail(e, "bases upload");
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+
+
+extern "C" {
+
+const char* zkmi_version(void) { return "zkmi 0.1 (gfx950)"; }
+
+int32_t zkmi_device_count(int32_t* out_count) {
+  if (!out_count) return ZKMI_ERR_BAD_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *out_count = (e == hipSuccess) ? n : 0;
+  return (e == hipSuccess && n > 0) ? ZKMI_OK : ZKMI_ERR_NO_DEVICE;
+}
+
+int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
+  if (!out_ctx) return ZKMI_ERR_BAD_ARG;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZKMI_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return ZKMI_ERR_BAD_ARG;
+  if (hipSetDevice(device) != hipSuccess) return ZKMI_ERR_HIP;
+  zkmi_ctx* c = new (std::nothrow) zkmi_ctx();
+  if (!c) return ZKMI_ERR_BAD_ARG;
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    return ZKMI_ERR_HIP;
+  }
+  hipError_t e = ntt_enable_big_lds();
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ZKMI_ERR_HIP;
+  }
+  *out_ctx = c;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
+  if (!ctx) return ZKMI_ERR_BAD_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->domains.clear();
+  ctx->sort.release();
+  ctx->g1.release();
+  ctx->g2.release();
+  if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ZKMI_OK;
+}
+
+const char* zkmi_last_error(const zkmi_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
+  if (!ctx) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof.collect();
+  return ZKMI_OK;
+}
+
+int32_t zkmi_prof_enable(zkmi_ctx* ctx, int32_t on) {
+  if (!ctx) return ZKMI_ERR_BAD_ARG;
+  ctx->prof.enabled = on != 0;
+  return ZKMI_OK;
+}
+int32_t zkmi_prof_reset(zkmi_ctx* ctx) {
+  if (!ctx) return ZKMI_ERR_BAD_ARG;
+  ctx->prof.reset();
+  return ZKMI_OK;
+}
+int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64_t* out_launches) {
+  if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->prof.collect();
+  if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
+  if (out_launches) *out_launches = ctx->prof.count[phase];
+  return ZKMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// NTT
+// ---------------------------------------------------------------------------
+int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data_mont, uint32_t log_n, int32_t inverse, int32_t coset) {
+  if (!ctx || !d_data_mont || log_n > 28) return ZKMI_ERR_BAD_ARG;
+  hipError_t e;
+  NttDomain* dom = ctx->domain((int)log_n, &e);
+  if (!dom) return ctx->hip_fail(e, "ntt domain init");
+  PhaseTimer* t = ctx->timer();
+  if (t) t->begin(PH_NTT, ctx->stream);
+  e = dom->transform(static_cast<Fr*>(d_data_mont), inverse != 0, coset != 0, ctx->stream);
+  if (t) t->end(PH_NTT, ctx->stream);
+  if (e != hipSuccess) return ctx->hip_fail(e, "ntt transform");
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+int32_t zkmi_fr_to_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n) {
+  if (!ctx || !d_data) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, ntt_to_mont(static_cast<Fr*>(d_data), (uint32_t)n, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+int32_t zkmi_fr_from_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n) {
+  if (!ctx || !d_data) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, ntt_from_mont(static_cast<Fr*>(d_data), (uint32_t)n, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  if (!ctx || !data || log_n > 28) return ZKMI_ERR_BAD_ARG;
+  const uint64_t n = 1ull << log_n;
+  for (uint64_t i = 0; i < n; i++)
+    if (!fr_is_canonical(data + 32 * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "ntt input >= r");
+  ZK_HIP(ctx, ctx->staging(n * 32));
+  ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, ntt_to_mont(static_cast<Fr*>(ctx->d_tmp), (uint32_t)n, ctx->stream));
+  int32_t rc = zkmi_ntt_fr_dev(ctx, ctx->d_tmp, log_n, inverse, coset);
+  if (rc != ZKMI_OK) return rc;
+  ZK_HIP(ctx, ntt_from_mont(static_cast<Fr*>(ctx->d_tmp), (uint32_t)n, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(data, ctx->d_tmp, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bases
+// ---------------------------------------------------------------------------
+int32_t zkmi_bases_g1_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g1** out) {
+  return bases_load<zkmi_bases_g1, G1Affine, g1_from_wire, 96>(ctx, affine, n, check, out);
+}
+int32_t zkmi_bases_g2_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g2** out) {
+  return bases_load<zkmi_bases_g2, G2Affine, g2_from_wire, 192>(ctx, affine, n, check, out);
+}
+int32_t zkmi_bases_g1_free(zkmi_bases_g1* b) {
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  if (b->d) (void)hipFree(b->d);
+  delete b;
+  return ZKMI_OK;
+}
+int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  if (b->d) (void)hipFree(b->d);
+  delete b;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
+  if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  zkmi_bases_g1* b = new (std::nothrow) zkmi_bases_g1();
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  b->ctx = ctx;
+  b->n = n;
+  hipError_t e = hipMalloc(&b->d, sizeof(G1Affine) * n);
+  if (e == hipSuccess) e = synthetic_bases_g1(b->d, n, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (b->d) (void)hipFree(b->d);
+    delete b;
+    return ctx->hip_fail(e, "synthetic g1 bases");
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) {
+  if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  zkmi_bases_g2* b = new (std::nothrow) zkmi_bases_g2();
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  b->ctx = ctx;
+  b->n = n;
+  hipError_t e = hipMalloc(&b->d, sizeof(G2Affine) * n);
+  if (e == hipSuccess) e = synthetic_bases_g2(b->d, n, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (b->d) (void)hipFree(b->d);
+    delete b;
+    return ctx->hip_fail(e, "synthetic g2 bases");
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out) {
+  if (!ctx || !b || !out || first + count > b->n) return ZKMI_ERR_BAD_ARG;
+  std::vector<G1Affine> h(count);
+  ZK_HIP(ctx, hipMemcpy(h.data(), b->d + first, sizeof(G1Affine) * count, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++) g1_to_wire(h[i], out + 96 * i);
+  return ZKMI_OK;
+}
+int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first, uint64_t count, uint8_t* out) {
+  if (!ctx || !b || !out || first + count > b->n) return ZKMI_ERR_BAD_ARG;
+  std::vector<G2Affine> h(count);
+  ZK_HIP(ctx, hipMemcpy(h.data(), b->d + first, sizeof(G2Affine) * count, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++) g2_to_wire(h[i], out + 192 * i);
+  return ZKMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// MSM
+// ---------------------------------------------------------------------------
+int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                        uint8_t out_affine[96]) {
+  if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, ctx->sort.reserve(n));
+  ZK_HIP(ctx, ctx->g1.reserve(n));
+  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  G1XYZZ res;
+  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &res, ctx->stream));
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g2* bases,
+                        uint8_t out_affine[192]) {
+  if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, ctx->sort.reserve(n));
+  ZK_HIP(ctx, ctx->g2.reserve(n));
+  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  G2XYZZ res;
+  ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &res, ctx->stream));
+  g2_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+static int32_t upload_scalars(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++)
+    if (!fr_is_canonical(scalars + 32 * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "scalar >= r");
+  ZK_HIP(ctx, ctx->staging(n * 32 + 32));
+  if (n) ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return ZKMI_OK;
+}
+
+int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g1* bases,
+                    uint8_t out_affine[96]) {
+  if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  int32_t rc = upload_scalars(ctx, scalars, n);
+  if (rc != ZKMI_OK) return rc;
+  return zkmi_msm_g1_dev(ctx, ctx->d_tmp, n, bases, out_affine);
+}
+int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g2* bases,
+                    uint8_t out_affine[192]) {
+  if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  int32_t rc = upload_scalars(ctx, scalars, n);
+  if (rc != ZKMI_OK) return rc;
+  return zkmi_msm_g2_dev(ctx, ctx->d_tmp, n, bases, out_affine);
+}
+
+int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin,
+                                uint32_t* out_window_bits) {
+  if (!ctx || !bases || !out_windows_affine || !out_nwin || !out_window_bits || n > bases->n) return ZKMI_ERR_BAD_ARG;
+  if (plan_n < n) plan_n = n;
+  ZK_HIP(ctx, ctx->sort.reserve(plan_n));
+  ZK_HIP(ctx, ctx->g1.reserve(plan_n));
+  // every rank must use the same window width: plan from the global size
+  MsmPlan pl = msm_make_plan(plan_n);
+  ctx->sort.plan_override = pl.c;
+  hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+  ctx->sort.plan_override = 0;
+  if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  std::vector<G1XYZZ> win(ctx->sort.plan.nwin);
+  ZK_HIP(ctx, ctx->g1.finish_host_windows(ctx->sort, win.data(), ctx->stream));
+  for (int w = 0; w < ctx->sort.plan.nwin; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);
+  *out_nwin = (uint32_t)ctx->sort.plan.nwin;
+  *out_window_bits = (uint32_t)ctx->sort.plan.c;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uint32_t nwin, uint32_t window_bits,
+                            uint8_t out_affine[96]) {
+  if (!windows_affine || !out_affine || nwin == 0 || nwin > 64 || window_bits == 0 || window_bits > 24)
+    return ZKMI_ERR_BAD_ARG;
+  std::vector<G1XYZZ> win(nwin, G1XYZZ::infinity());
+  for (uint32_t r = 0; r < n_ranks; r++)
+    for (uint32_t w = 0; w < nwin; w++) {
+      G1Affine p;
+      if (!g1_from_wire(windows_affine + 96ull * (r * nwin + w), &p, true)) return ZKMI_ERR_NON_CANONICAL;
+      win[w].madd(p);
+    }
+  G1XYZZ total = msm_combine_windows<Fq>(win.data(), (int)nwin, (int)window_bits);
+  g1_to_wire(total.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// group helpers (host)
+// ---------------------------------------------------------------------------
+int32_t zkmi_g1_generator(uint8_t out[96]) {
+  if (!out) return ZKMI_ERR_BAD_ARG;
+  g1_to_wire(g1_generator(), out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g2_generator(uint8_t out[192]) {
+  if (!out) return ZKMI_ERR_BAD_ARG;
+  g2_to_wire(g2_generator(), out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]) {
+  G1Affine p;
+  if (!affine || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g1_from_wire(affine, &p, true)) return ZKMI_ERR_NON_CANONICAL;
+  g1_compress(p, out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g1_decompress(const uint8_t in[48], uint8_t out[96]) {
+  G1Affine p;
+  if (!in || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g1_decompress(in, &p)) return ZKMI_ERR_NON_CANONICAL;
+  g1_to_wire(p, out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g2_compress(const uint8_t affine[192], uint8_t out[96]) {
+  G2Affine p;
+  if (!affine || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g2_from_wire(affine, &p, true)) return ZKMI_ERR_NON_CANONICAL;
+  g2_compress(p, out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g2_decompress(const uint8_t in[96], uint8_t out[192]) {
+  G2Affine p;
+  if (!in || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g2_decompress(in, &p)) return ZKMI_ERR_NON_CANONICAL;
+  g2_to_wire(p, out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g1_mul(const uint8_t affine[96], const uint8_t scalar[32], uint8_t out[96]) {
+  G1Affine p;
+  if (!affine || !scalar || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g1_from_wire(affine, &p, true) || !fr_is_canonical(scalar)) return ZKMI_ERR_NON_CANONICAL;
+  uint32_t k[8];
+  memcpy(k, scalar, 32);
+  g1_to_wire(scalar_mul(G1XYZZ::from_affine(p), k, 8).to_affine(), out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g2_mul(const uint8_t affine[192], const uint8_t scalar[32], uint8_t out[192]) {
+  G2Affine p;
+  if (!affine || !scalar || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g2_from_wire(affine, &p, true) || !fr_is_canonical(scalar)) return ZKMI_ERR_NON_CANONICAL;
+  uint32_t k[8];
+  memcpy(k, scalar, 32);
+  g2_to_wire(scalar_mul(G2XYZZ::from_affine(p), k, 8).to_affine(), out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g1_add(const uint8_t a[96], const uint8_t b[96], uint8_t out[96]) {
+  G1Affine p, q;
+  if (!a || !b || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g1_from_wire(a, &p, true) || !g1_from_wire(b, &q, true)) return ZKMI_ERR_NON_CANONICAL;
+  G1XYZZ s = G1XYZZ::from_affine(p);
+  s.madd(q);
+  g1_to_wire(s.to_affine(), out);
+  return ZKMI_OK;
+}
+int32_t zkmi_g2_add(const uint8_t a[192], const uint8_t b[192], uint8_t out[192]) {
+  G2Affine p, q;
+  if (!a || !b || !out) return ZKMI_ERR_BAD_ARG;
+  if (!g2_from_wire(a, &p, true) || !g2_from_wire(b, &q, true)) return ZKMI_ERR_NON_CANONICAL;
+  G2XYZZ s = G2XYZZ::from_affine(p);
+  s.madd(q);
+  g2_to_wire(s.to_affine(), out);
+  return ZKMI_OK;
+}
+
+}  // extern "C"

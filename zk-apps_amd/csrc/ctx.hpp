@@ -1,0 +1,94 @@
+// zkmi — context object behind the C ABI (include/zkmi.h): one HIP device, one
+// stream, resident NTT domains and MSM workspaces.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/zkmi.h"
+#include "curve.hpp"
+#include "msm.hpp"
+#include "ntt.hpp"
+
+struct zkmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  zkmi::PhaseTimer prof;
+  std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;
+  zkmi::MsmSort sort;
+  zkmi::MsmEngine<zkmi::Fq> g1;
+  zkmi::MsmEngine<zkmi::Fq2> g2;
+  void* d_tmp = nullptr;  // staging for host-buffer entry points
+  uint64_t d_tmp_cap = 0;
+
+  zkmi::PhaseTimer* timer() { return prof.enabled ? &prof : nullptr; }
+  int32_t fail(int32_t code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  int32_t hip_fail(hipError_t e, const char* where) {
+    err = std::string(where) + ": " + hipGetErrorString(e);
+    return ZKMI_ERR_HIP;
+  }
+  hipError_t staging(uint64_t bytes) {
+    if (bytes <= d_tmp_cap) return hipSuccess;
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_tmp = nullptr;
+    d_tmp_cap = 0;
+    hipError_t e = hipMalloc(&d_tmp, bytes);
+    if (e == hipSuccess) d_tmp_cap = bytes;
+    return e;
+  }
+  zkmi::NttDomain* domain(int log_n, hipError_t* e) {
+    auto it = domains.find(log_n);
+    if (it != domains.end()) {
+      *e = hipSuccess;
+      return it->second.get();
+    }
+    auto d = std::make_unique<zkmi::NttDomain>();
+    *e = d->init(log_n, stream);
+    if (*e != hipSuccess) return nullptr;
+    auto* p = d.get();
+    domains[log_n] = std::move(d);
+    return p;
+  }
+};
+
+struct zkmi_bases_g1 {
+  zkmi_ctx* ctx;
+  zkmi::G1Affine* d = nullptr;
+  uint64_t n = 0;
+};
+struct zkmi_bases_g2 {
+  zkmi_ctx* ctx;
+  zkmi::G2Affine* d = nullptr;
+  uint64_t n = 0;
+};
+
+#define ZK_HIP(ctx, call)                                   \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); \
+  } while (0)
+
+namespace zkmi {
+// wire <-> internal conversions (host)
+bool fr_from_wire(const uint8_t* b, Fr* out);  // canonical check, -> Montgomery
+void fr_to_wire(const Fr& a, uint8_t* b);      // Montgomery -> canonical bytes
+bool fq_from_wire(const uint8_t* b, Fq* out);
+void fq_to_wire(const Fq& a, uint8_t* b);
+bool g1_from_wire(const uint8_t* b, G1Affine* out, bool check_curve);
+void g1_to_wire(const G1Affine& p, uint8_t* b);
+bool g2_from_wire(const uint8_t* b, G2Affine* out, bool check_curve);
+void g2_to_wire(const G2Affine& p, uint8_t* b);
+bool fr_is_canonical(const uint8_t* b);
+G1Affine g1_generator();
+G2Affine g2_generator();
+bool g1_on_curve(const G1Affine& p);
+bool g2_on_curve(const G2Affine& p);
+void g1_compress(const G1Affine& p, uint8_t out[48]);
+bool g1_decompress(const uint8_t in[48], G1Affine* out);
+void g2_compress(const G2Affine& p, uint8_t out[96]);
+bool g2_decompress(const uint8_t in[96], G2Affine* out);
+}  // namespace zkmi

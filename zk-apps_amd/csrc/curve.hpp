@@ -1,0 +1,152 @@
+// zkmi — short-Weierstrass (a = 0) group arithmetic for BLS12-381 G1 (F = Fq)
+// and G2 (F = Fq2) in extended-Jacobian "XYZZ" coordinates:
+//   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2;   infinity <=> ZZ == 0.
+// Affine infinity is encoded as (0, 0) (not on either curve since b != 0).
+//
+// Reference locus: none in /root/reference; the
+// bucket method only needs a correct group law — the MSM result is a unique
+// group element, compared after affine normalisation.
+// Formulas: EFD "xyzz" madd-2008-s (8M+2S), add-2008-s (12M+2S), dbl-2008-s-1.
+#pragma once
+#include "field.hpp"
+
+namespace zkmi {
+
+template <class F>
+struct Affine {
+  F x, y;
+  ZK_HD static Affine infinity() { return {F::zero(), F::zero()}; }
+  ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  ZK_HD Affine neg() const { return {x, y.neg()}; }
+};
+
+template <class F>
+struct XYZZ {
+  F x, y, zz, zzz;
+  ZK_HD static XYZZ infinity() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
+  ZK_HD bool is_inf() const { return zz.is_zero(); }
+  ZK_HD static XYZZ from_affine(const Affine<F>& p) {
+    if (p.is_inf()) return infinity();
+    return {p.x, p.y, F::one(), F::one()};
+  }
+  ZK_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
+
+  ZK_HD static XYZZ dbl_affine(const Affine<F>& p) {
+    // mdbl-2008-s-1 with ZZ1 = ZZZ1 = 1
+    F u = p.y.dbl();
+    F v = u.sqr();
+    F w = u * v;
+    F s = p.x * v;
+    F x2 = p.x.sqr();
+    F m = x2.dbl() + x2;
+    F x3 = m.sqr() - s.dbl();
+    F y3 = m * (s - x3) - w * p.y;
+    return {x3, y3, v, w};
+  }
+
+  ZK_HD void dbl_inplace() {
+    if (is_inf()) return;
+    F u = y.dbl();
+    F v = u.sqr();
+    F w = u * v;
+    F s = x * v;
+    F x2 = x.sqr();
+    F m = x2.dbl() + x2;
+    F x3 = m.sqr() - s.dbl();
+    F y3 = m * (s - x3) - w * y;
+    x = x3;
+    y = y3;
+    zz = v * zz;
+    zzz = w * zzz;
+  }
+
+  // this += p (affine), complete by case analysis
+  ZK_HD void madd(const Affine<F>& p) {
+    if (p.is_inf()) return;
+    if (is_inf()) {
+      x = p.x;
+      y = p.y;
+      zz = F::one();
+      zzz = F::one();
+      return;
+    }
+    F u2 = p.x * zz;
+    F s2 = p.y * zzz;
+    F pp_ = u2 - x;
+    F r = s2 - y;
+    if (pp_.is_zero()) {
+      if (r.is_zero()) {
+        *this = dbl_affine(p);
+      } else {
+        *this = infinity();
+      }
+      return;
+    }
+    F pp = pp_.sqr();
+    F ppp = pp_ * pp;
+    F q = x * pp;
+    F x3 = r.sqr() - ppp - q.dbl();
+    y = r * (q - x3) - y * ppp;
+    x = x3;
+    zz = zz * pp;
+    zzz = zzz * ppp;
+  }
+
+  // this += o
+  ZK_HD void add(const XYZZ& o) {
+    if (o.is_inf()) return;
+    if (is_inf()) {
+      *this = o;
+      return;
+    }
+    F u1 = x * o.zz;
+    F u2 = o.x * zz;
+    F s1 = y * o.zzz;
+    F s2 = o.y * zzz;
+    F pp_ = u2 - u1;
+    F r = s2 - s1;
+    if (pp_.is_zero()) {
+      if (r.is_zero()) {
+        dbl_inplace();
+      } else {
+        *this = infinity();
+      }
+      return;
+    }
+    F pp = pp_.sqr();
+    F ppp = pp_ * pp;
+    F q = u1 * pp;
+    F x3 = r.sqr() - ppp - q.dbl();
+    y = r * (q - x3) - s1 * ppp;
+    x = x3;
+    zz = zz * o.zz * pp;
+    zzz = zzz * o.zzz * ppp;
+  }
+
+  __host__ __device__ Affine<F> to_affine() const {
+    if (is_inf()) return Affine<F>::infinity();
+    F zi = zzz.inv();            // 1/ZZZ
+    F zz_inv = (zi * zz).sqr();  // (ZZ/ZZZ)^2 = 1/ZZ  (since ZZ^3 = ZZZ^2)
+    return {x * zz_inv, y * zi};
+  }
+};
+
+// k * p for a little-endian 32-bit-limb scalar (host-side O(1) steps only)
+template <class F>
+__host__ __device__ inline XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* k, int nlimbs) {
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int i = nlimbs - 1; i >= 0; i--) {
+    for (int b = 31; b >= 0; b--) {
+      acc.dbl_inplace();
+      if ((k[i] >> b) & 1) acc.add(p);
+    }
+  }
+  return acc;
+}
+
+using G1Affine = Affine<Fq>;
+using G2Affine = Affine<Fq2>;
+using G1XYZZ = XYZZ<Fq>;
+using G2XYZZ = XYZZ<Fq2>;
+
+}  // namespace zkmi

@@ -1,0 +1,512 @@
+// zkmi — Groth16 over BLS12-381: witness -> proof on the device, setup with
+// explicit toxic waste, pairing verifier on the host.
+//
+// Reference locus: none in /root/reference (SURVEY.md §0, §8a rows a7, a10,
+// a11); the call this replaces is the mock prove step
+// ZkProof::update_account (shielder/mocked_zk/src/relations.rs:79-98).  The
+// algorithm restates ark-groth16 0.4 [not in tree] exactly as oracle/groth16.py
+// does: LibsnarkReduction witness map (3 iNTT, 3 coset NTT, pointwise
+// quotient, 1 coset iNTT), A/B/C assembly with explicit (r, s).
+//
+// Device pipeline for one proof (all on the ctx stream, key resident in HBM):
+//   upload z (32 B/var) -> to Montgomery
+//   k_matvec x3            a,b,c = <A_i,z>, <B_i,z>, <C_i,z>  (+ input rows)
+//   NTT x7                 see ntt.hip
+//   k_quotient             h = (a*b - c) / Z(g)
+//   digit-sort(z[1..])     shared by the A, B1, B2 and L MSMs (L query is
+//                          stored padded with n_pub-1 infinities so it lines up)
+//   MSM G1 x3, MSM G2 x1, digit-sort(h), MSM G1 (H)
+//   host: O(1) scalar multiplications, compression to 192 bytes
+#include <string.h>
+#include <new>
+#include <vector>
+#include "ctx.hpp"
+#include "pairing.hpp"
+#include "r1cs.hpp"
+
+namespace zkmi {
+
+template <class T>
+__device__ __forceinline__ T ldv(const T* p) {
+  T r;
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+  uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+  return r;
+}
+template <class T>
+__device__ __forceinline__ void stv(T* p, const T& v) {
+  const uint4* s = reinterpret_cast<const uint4*>(&v);
+  uint4* d = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+}
+
+// out[i] = <M_i, z> for i < nc; rows [nc, nc+n_pub) = z_j if is_a else 0; rest 0
+__global__ void __launch_bounds__(256)
+k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ val,
+         const Fr* __restrict__ z, Fr* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr acc = Fr::zero();
+  if (i < nc) {
+    const uint32_t b = rowptr[i], e = rowptr[i + 1];
+    for (uint32_t k = b; k < e; k++) acc = acc + ldv(val + k) * ldv(z + col[k]);
+  } else if (is_a && i < nc + n_pub) {
+    acc = ldv(z + (i - nc));
+  }
+  stv(out + i, acc);
+}
+
+__global__ void __launch_bounds__(256)
+k_quotient(Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, Fr zinv, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stv(a + i, (ldv(a + i) * ldv(b + i) - ldv(c + i)) * zinv);
+}
+
+// fixed-base multiplication out[i] = s_i * B with 8-bit windows:
+// table[w*256 + d] = d * 2^(8w) * B (affine, Montgomery), w < 32
+template <class F>
+__global__ void __launch_bounds__(64)
+k_fixed_base(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__ table, Affine<F>* __restrict__ out,
+             uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int w = 0; w < 32; w++) {
+    const uint32_t limb = scalars[(size_t)i * 8 + (w >> 2)];
+    const uint32_t d = (limb >> ((w & 3) * 8)) & 0xffu;
+    if (d) {
+      Affine<F> p = ldv(table + w * 256 + d);
+      acc.madd(p);
+    }
+  }
+  stv(out + i, acc.to_affine());
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+struct zkmi_pk {
+  zkmi_ctx* ctx = nullptr;
+  uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
+  uint32_t* d_rowptr[3] = {nullptr, nullptr, nullptr};
+  uint32_t* d_col[3] = {nullptr, nullptr, nullptr};
+  Fr* d_val[3] = {nullptr, nullptr, nullptr};
+  G1Affine *a_query = nullptr, *b_g1_query = nullptr, *h_query = nullptr, *l_query = nullptr;  // l padded to n_vars
+  G2Affine* b_g2_query = nullptr;
+  G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
+  G2Affine beta_g2, delta_g2, b2_0;
+  Fr *d_z = nullptr, *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+  ~zkmi_pk() {
+    for (int m = 0; m < 3; m++) {
+      if (d_rowptr[m]) (void)hipFree(d_rowptr[m]);
+      if (d_col[m]) (void)hipFree(d_col[m]);
+      if (d_val[m]) (void)hipFree(d_val[m]);
+    }
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+};
+
+static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
+  pk->ctx = ctx;
+  pk->n_vars = r->n_vars;
+  pk->n_pub = r->n_pub;
+  pk->nc = r->n_constraints;
+  pk->log_n = r->log_n;
+  const uint64_t N = 1ull << r->log_n;
+  hipError_t e;
+  for (int m = 0; m < 3; m++) {
+    const auto& c = r->m[m];
+    const size_t nnz = c.col.size();
+    if ((e = hipMalloc(&pk->d_rowptr[m], sizeof(uint32_t) * c.rowptr.size())) != hipSuccess) return e;
+    if ((e = hipMalloc(&pk->d_col[m], sizeof(uint32_t) * (nnz ? nnz : 1))) != hipSuccess) return e;
+    if ((e = hipMalloc(&pk->d_val[m], sizeof(Fr) * (nnz ? nnz : 1))) != hipSuccess) return e;
+    if ((e = hipMemcpy(pk->d_rowptr[m], c.rowptr.data(), sizeof(uint32_t) * c.rowptr.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if (nnz) {
+      if ((e = hipMemcpy(pk->d_col[m], c.col.data(), sizeof(uint32_t) * nnz, hipMemcpyHostToDevice)) != hipSuccess) return e;
+      if ((e = hipMemcpy(pk->d_val[m], c.val.data(), sizeof(Fr) * nnz, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
+  }
+  if ((e = hipMalloc(&pk->a_query, sizeof(G1Affine) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->b_g1_query, sizeof(G1Affine) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->b_g2_query, sizeof(G2Affine) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->l_query, sizeof(G1Affine) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->h_query, sizeof(G1Affine) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_z, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_zm, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_a, sizeof(Fr) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_b, sizeof(Fr) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_c, sizeof(Fr) * N)) != hipSuccess) return e;
+  const uint64_t cap = N > r->n_vars ? N : r->n_vars;
+  if ((e = ctx->sort.reserve(cap)) != hipSuccess) return e;
+  if ((e = ctx->g1.reserve(cap)) != hipSuccess) return e;
+  if ((e = ctx->g2.reserve(cap)) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+static Fr fr_from_u64(uint64_t v) {
+  Fr a = Fr::zero();
+  a.l[0] = (uint32_t)v;
+  a.l[1] = (uint32_t)(v >> 32);
+  return a.to_mont();
+}
+
+static void fr_limbs(const Fr& mont, uint32_t k[8]) {
+  Fr c = mont.from_mont();
+  memcpy(k, c.l, 32);
+}
+
+template <class F>
+static hipError_t fixed_base_table(const Affine<F>& base, Affine<F>** d_table) {
+  std::vector<Affine<F>> t(32 * 256);
+  XYZZ<F> wbase = XYZZ<F>::from_affine(base);
+  for (int w = 0; w < 32; w++) {
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    t[w * 256] = Affine<F>::infinity();
+    for (int d = 1; d < 256; d++) {
+      acc.add(wbase);
+      t[w * 256 + d] = acc.to_affine();
+    }
+    for (int k = 0; k < 8; k++) wbase.dbl_inplace();
+  }
+  hipError_t e = hipMalloc(d_table, sizeof(Affine<F>) * t.size());
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*d_table, t.data(), sizeof(Affine<F>) * t.size(), hipMemcpyHostToDevice);
+}
+
+// out[i] = scalars[i] * base for Montgomery-form host scalars
+template <class F>
+static hipError_t fixed_base_batch(zkmi_ctx* ctx, const Affine<F>* d_table, const std::vector<Fr>& scalars_mont,
+                                   Affine<F>* d_out) {
+  const size_t n = scalars_mont.size();
+  if (!n) return hipSuccess;
+  std::vector<Fr> canon(n);
+  for (size_t i = 0; i < n; i++) canon[i] = scalars_mont[i].from_mont();
+  hipError_t e = ctx->staging(n * 32);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(ctx->d_tmp, canon.data(), n * 32, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+                     static_cast<const uint32_t*>(ctx->d_tmp), d_table, d_out, (uint32_t)n);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipStreamSynchronize(ctx->stream);
+}
+
+extern "C" {
+
+int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t toxic[160], zkmi_pk** out_pk,
+                           uint8_t* vk_out, uint64_t vk_cap) {
+  if (!ctx || !r || !toxic || !out_pk || !vk_out) return ZKMI_ERR_BAD_ARG;
+  if (vk_cap < 672 + 96ull * r->n_pub) return ctx->fail(ZKMI_ERR_BAD_ARG, "vk buffer too small");
+  Fr tau, alpha, beta, gamma, delta;
+  Fr* tw[5] = {&tau, &alpha, &beta, &gamma, &delta};
+  for (int i = 0; i < 5; i++)
+    if (!fr_from_wire(toxic + 32 * i, tw[i])) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "toxic waste >= r");
+  if (gamma.is_zero() || delta.is_zero()) return ctx->fail(ZKMI_ERR_BAD_ARG, "gamma/delta must be non-zero");
+  const uint32_t N = 1u << r->log_n, nv = r->n_vars, np = r->n_pub, nc = r->n_constraints;
+  // Lagrange basis at tau:  L_i = (tau^N - 1)/N * w^i / (tau - w^i)
+  Fr tn = tau;
+  for (uint32_t i = 0; i < r->log_n; i++) tn = tn.sqr();
+  const Fr zt = tn - Fr::one();
+  if (zt.is_zero()) return ctx->fail(ZKMI_ERR_BAD_ARG, "tau is in the evaluation domain");
+  const Fr w = fr_root_of_unity((int)r->log_n);
+  std::vector<Fr> L(N), den(N);
+  {
+    Fr wi = Fr::one();
+    for (uint32_t i = 0; i < N; i++) {
+      den[i] = tau - wi;
+      L[i] = wi;
+      wi = wi * w;
+    }
+    // batch inversion
+    std::vector<Fr> pre(N);
+    Fr run = Fr::one();
+    for (uint32_t i = 0; i < N; i++) {
+      pre[i] = run;
+      run = run * den[i];
+    }
+    Fr inv = run.inv();
+    const Fr scale = zt * fr_from_u64(N).inv();
+    for (uint32_t i = N; i-- > 0;) {
+      Fr di = inv * pre[i];
+      inv = inv * den[i];
+      L[i] = L[i] * di * scale;
+    }
+  }
+  std::vector<Fr> a(nv, Fr::zero()), b(nv, Fr::zero()), c(nv, Fr::zero());
+  for (uint32_t j = 0; j < np; j++) a[j] = L[nc + j];
+  std::vector<Fr>* dst[3] = {&a, &b, &c};
+  for (int m = 0; m < 3; m++) {
+    const auto& M = r->m[m];
+    for (uint32_t i = 0; i < nc; i++)
+      for (uint32_t k = M.rowptr[i]; k < M.rowptr[i + 1]; k++)
+        (*dst[m])[M.col[k]] = (*dst[m])[M.col[k]] + L[i] * M.val[k];
+  }
+  const Fr ginv = gamma.inv(), dinv = delta.inv();
+  std::vector<Fr> lq(nv), hq(N);
+  for (uint32_t j = 0; j < nv; j++) lq[j] = (beta * a[j] + alpha * b[j] + c[j]) * (j < np ? ginv : dinv);
+  {
+    Fr t = zt * dinv;
+    for (uint32_t i = 0; i + 1 < N; i++) {
+      hq[i] = t;
+      t = t * tau;
+    }
+    hq[N - 1] = Fr::zero();
+  }
+  zkmi_pk* pk = new (std::nothrow) zkmi_pk();
+  if (!pk) return ZKMI_ERR_BAD_ARG;
+  hipError_t e = pk_alloc(pk, ctx, r);
+  G1Affine* t1 = nullptr;
+  G2Affine* t2 = nullptr;
+  const G1Affine g1 = g1_generator();
+  const G2Affine g2 = g2_generator();
+  if (e == hipSuccess) e = fixed_base_table<Fq>(g1, &t1);
+  if (e == hipSuccess) e = fixed_base_table<Fq2>(g2, &t2);
+  if (e == hipSuccess) e = fixed_base_batch<Fq>(ctx, t1, a, pk->a_query);
+  if (e == hipSuccess) e = fixed_base_batch<Fq>(ctx, t1, b, pk->b_g1_query);
+  if (e == hipSuccess) e = fixed_base_batch<Fq2>(ctx, t2, b, pk->b_g2_query);
+  if (e == hipSuccess) e = fixed_base_batch<Fq>(ctx, t1, lq, pk->l_query);
+  if (e == hipSuccess) e = fixed_base_batch<Fq>(ctx, t1, hq, pk->h_query);
+  std::vector<G1Affine> ic(np);
+  if (e == hipSuccess) e = hipMemcpy(ic.data(), pk->l_query, sizeof(G1Affine) * np, hipMemcpyDeviceToHost);
+  // the public part of the L query belongs to the verifying key; blank it in the proving key
+  if (e == hipSuccess) e = hipMemset(pk->l_query, 0, sizeof(G1Affine) * np);
+  if (e == hipSuccess) e = hipMemcpy(&pk->a0, pk->a_query, sizeof(G1Affine), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&pk->b1_0, pk->b_g1_query, sizeof(G1Affine), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&pk->b2_0, pk->b_g2_query, sizeof(G2Affine), hipMemcpyDeviceToHost);
+  if (t1) (void)hipFree(t1);
+  if (t2) (void)hipFree(t2);
+  if (e != hipSuccess) {
+    delete pk;
+    return ctx->hip_fail(e, "groth16 setup");
+  }
+  uint32_t k[8];
+  auto mul1 = [&](const Fr& s) {
+    fr_limbs(s, k);
+    return scalar_mul(G1XYZZ::from_affine(g1), k, 8).to_affine();
+  };
+  auto mul2 = [&](const Fr& s) {
+    fr_limbs(s, k);
+    return scalar_mul(G2XYZZ::from_affine(g2), k, 8).to_affine();
+  };
+  pk->alpha_g1 = mul1(alpha);
+  pk->beta_g1 = mul1(beta);
+  pk->delta_g1 = mul1(delta);
+  pk->beta_g2 = mul2(beta);
+  pk->delta_g2 = mul2(delta);
+  g1_to_wire(pk->alpha_g1, vk_out);
+  g2_to_wire(pk->beta_g2, vk_out + 96);
+  g2_to_wire(mul2(gamma), vk_out + 288);
+  g2_to_wire(pk->delta_g2, vk_out + 480);
+  for (uint32_t j = 0; j < np; j++) g1_to_wire(ic[j], vk_out + 672 + 96ull * j);
+  *out_pk = pk;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t alpha_g1[96], const uint8_t beta_g1[96],
+                     const uint8_t beta_g2[192], const uint8_t delta_g1[96], const uint8_t delta_g2[192],
+                     const uint8_t* a_query, const uint8_t* b_g1_query, const uint8_t* b_g2_query,
+                     const uint8_t* h_query, const uint8_t* l_query, zkmi_pk** out_pk) {
+  if (!ctx || !r || !alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !a_query || !b_g1_query ||
+      !b_g2_query || !h_query || !l_query || !out_pk)
+    return ZKMI_ERR_BAD_ARG;
+  zkmi_pk* pk = new (std::nothrow) zkmi_pk();
+  if (!pk) return ZKMI_ERR_BAD_ARG;
+  hipError_t e = pk_alloc(pk, ctx, r);
+  if (e != hipSuccess) {
+    delete pk;
+    return ctx->hip_fail(e, "pk alloc");
+  }
+  const uint32_t N = 1u << r->log_n, nv = r->n_vars, np = r->n_pub;
+  bool ok = g1_from_wire(alpha_g1, &pk->alpha_g1, true) && g1_from_wire(beta_g1, &pk->beta_g1, true) &&
+            g1_from_wire(delta_g1, &pk->delta_g1, true) && g2_from_wire(beta_g2, &pk->beta_g2, true) &&
+            g2_from_wire(delta_g2, &pk->delta_g2, true);
+  std::vector<G1Affine> h1(nv > N ? nv : N);
+  std::vector<G2Affine> h2(nv);
+  auto up1 = [&](const uint8_t* src, uint32_t cnt, uint32_t pad_front, G1Affine* dst, uint32_t total) {
+    for (uint32_t i = 0; i < total; i++) h1[i] = G1Affine::infinity();
+    for (uint32_t i = 0; i < cnt && ok; i++) ok = g1_from_wire(src + 96ull * i, &h1[pad_front + i], true);
+    if (ok) e = hipMemcpy(dst, h1.data(), sizeof(G1Affine) * total, hipMemcpyHostToDevice);
+  };
+  if (ok) up1(a_query, nv, 0, pk->a_query, nv);
+  if (ok && e == hipSuccess) pk->a0 = h1[0];
+  if (ok && e == hipSuccess) up1(b_g1_query, nv, 0, pk->b_g1_query, nv);
+  if (ok && e == hipSuccess) pk->b1_0 = h1[0];
+  if (ok && e == hipSuccess) up1(l_query, nv - np, np, pk->l_query, nv);
+  if (ok && e == hipSuccess) up1(h_query, N - 1, 0, pk->h_query, N);
+  for (uint32_t i = 0; i < nv && ok; i++) ok = g2_from_wire(b_g2_query + 192ull * i, &h2[i], true);
+  if (ok && e == hipSuccess) {
+    pk->b2_0 = h2[0];
+    e = hipMemcpy(pk->b_g2_query, h2.data(), sizeof(G2Affine) * nv, hipMemcpyHostToDevice);
+  }
+  if (!ok || e != hipSuccess) {
+    delete pk;
+    return ok ? ctx->hip_fail(e, "pk upload") : ctx->fail(ZKMI_ERR_NON_CANONICAL, "proving key point invalid");
+  }
+  *out_pk = pk;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_pk_free(zkmi_pk* pk) {
+  if (!pk) return ZKMI_ERR_BAD_ARG;
+  delete pk;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count,
+                             uint8_t* out) {
+  if (!ctx || !pk || !out || which < 0 || which > 4) return ZKMI_ERR_BAD_ARG;
+  const uint64_t N = 1ull << pk->log_n;
+  if (which == 2) {
+    if (first + count > pk->n_vars) return ZKMI_ERR_BAD_ARG;
+    std::vector<G2Affine> h(count);
+    ZK_HIP(ctx, hipMemcpy(h.data(), pk->b_g2_query + first, sizeof(G2Affine) * count, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < count; i++) g2_to_wire(h[i], out + 192 * i);
+    return ZKMI_OK;
+  }
+  const G1Affine* src = which == 0 ? pk->a_query : which == 1 ? pk->b_g1_query : which == 3 ? pk->h_query : pk->l_query + pk->n_pub;
+  const uint64_t len = which == 3 ? N - 1 : which == 4 ? pk->n_vars - pk->n_pub : pk->n_vars;
+  if (first + count > len) return ZKMI_ERR_BAD_ARG;
+  std::vector<G1Affine> h(count);
+  ZK_HIP(ctx, hipMemcpy(h.data(), src + first, sizeof(G1Affine) * count, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++) g1_to_wire(h[i], out + 96 * i);
+  return ZKMI_OK;
+}
+
+// z -> h coefficients (Montgomery form, natural order) in pk->d_a
+static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z) {
+  const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
+  hipStream_t st = ctx->stream;
+  for (uint32_t i = 0; i < nv; i++)
+    if (!fr_is_canonical(z + 32ull * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+  PhaseTimer* t = ctx->timer();
+  ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, st));
+  if (t) t->begin(PH_WITNESS, st);
+  ZK_HIP(ctx, hipMemcpyAsync(pk->d_zm, pk->d_z, 32ull * nv, hipMemcpyDeviceToDevice, st));
+  ZK_HIP(ctx, ntt_to_mont(pk->d_zm, nv, st));
+  Fr* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
+  for (int m = 0; m < 3; m++)
+    hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
+                       pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0);
+  if (t) t->end(PH_WITNESS, st);
+  hipError_t e;
+  NttDomain* dom = ctx->domain((int)pk->log_n, &e);
+  if (!dom) return ctx->hip_fail(e, "ntt domain");
+  if (t) t->begin(PH_NTT, st);
+  for (int m = 0; m < 3; m++) {
+    ZK_HIP(ctx, dom->transform(outv[m], true, false, st));
+    ZK_HIP(ctx, dom->transform(outv[m], false, true, st));
+  }
+  // 1 / Z(g) with Z(g) = g^N - 1, g = 7
+  Fr gn = fr_from_u64(7);
+  for (uint32_t i = 0; i < pk->log_n; i++) gn = gn.sqr();
+  const Fr zinv = (gn - Fr::one()).inv();
+  hipLaunchKernelGGL(k_quotient, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv, N);
+  ZK_HIP(ctx, dom->transform(pk->d_a, true, true, st));
+  if (t) t->end(PH_NTT, st);
+  ZK_HIP(ctx, hipGetLastError());
+  return ZKMI_OK;
+}
+
+int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h) {
+  if (!ctx || !pk || !z || !out_h) return ZKMI_ERR_BAD_ARG;
+  int32_t rc = witness_map_dev(ctx, pk, z);
+  if (rc != ZKMI_OK) return rc;
+  const uint32_t N = 1u << pk->log_n;
+  ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(out_h, pk->d_a, 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
+                           const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  if (!ctx || !pk || !z || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
+  if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
+  const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
+  hipStream_t st = ctx->stream;
+  int32_t rc = witness_map_dev(ctx, pk, z);
+  if (rc != ZKMI_OK) return rc;
+  ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, st));  // h as canonical integers for the digit sort
+  PhaseTimer* t = ctx->timer();
+  // MSMs over the assignment z[1..): one digit sort, four bucket passes
+  const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z + 1);
+  ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
+  G1XYZZ acc_a, acc_b1, acc_l, acc_h;
+  G2XYZZ acc_b2;
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_a, st));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b_g1_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_b1, st));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_l, st));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b_g2_query + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &acc_b2, st));
+  // H: h[0..N-1) against h_query
+  ZK_HIP(ctx, ctx->sort.run(reinterpret_cast<const uint32_t*>(pk->d_a), N - 1, st, t));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h_query, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_h, st));
+  // assembly
+  uint32_t rk[8], sk[8], rsk[8];
+  memcpy(rk, r_bytes, 32);
+  memcpy(sk, s_bytes, 32);
+  Fr rm, sm;
+  fr_from_wire(r_bytes, &rm);
+  fr_from_wire(s_bytes, &sm);
+  fr_limbs(rm * sm, rsk);
+  const G1XYZZ d1 = G1XYZZ::from_affine(pk->delta_g1);
+  G1XYZZ g_a = scalar_mul(d1, rk, 8);
+  g_a.madd(pk->a0);
+  g_a.add(acc_a);
+  g_a.madd(pk->alpha_g1);
+  G1XYZZ g1_b = scalar_mul(d1, sk, 8);
+  g1_b.madd(pk->b1_0);
+  g1_b.add(acc_b1);
+  g1_b.madd(pk->beta_g1);
+  G2XYZZ g2_b = scalar_mul(G2XYZZ::from_affine(pk->delta_g2), sk, 8);
+  g2_b.madd(pk->b2_0);
+  g2_b.add(acc_b2);
+  g2_b.madd(pk->beta_g2);
+  G1XYZZ g_c = scalar_mul(g_a, sk, 8);
+  g_c.add(scalar_mul(g1_b, rk, 8));
+  g_c.add(scalar_mul(d1, rsk, 8).neg());
+  g_c.add(acc_l);
+  g_c.add(acc_h);
+  g1_compress(g_a.to_affine(), out_proof);
+  g2_compress(g2_b.to_affine(), out_proof + 48);
+  g1_compress(g_c.to_affine(), out_proof + 144);
+  return ZKMI_OK;
+}
+
+int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]) {
+  if (!vk || !proof || n_pub == 0 || (n_pub > 1 && !publics)) return ZKMI_ERR_BAD_ARG;
+  G1Affine alpha, a, c;
+  G2Affine beta, gamma, delta, b;
+  if (!g1_from_wire(vk, &alpha, true) || !g2_from_wire(vk + 96, &beta, true) ||
+      !g2_from_wire(vk + 288, &gamma, true) || !g2_from_wire(vk + 480, &delta, true))
+    return ZKMI_ERR_NON_CANONICAL;
+  if (!g1_decompress(proof, &a) || !g2_decompress(proof + 48, &b) || !g1_decompress(proof + 144, &c))
+    return ZKMI_ERR_NON_CANONICAL;
+  G1Affine ic0;
+  if (!g1_from_wire(vk + 672, &ic0, true)) return ZKMI_ERR_NON_CANONICAL;
+  G1XYZZ acc = G1XYZZ::from_affine(ic0);
+  for (uint32_t j = 1; j < n_pub; j++) {
+    G1Affine icj;
+    if (!g1_from_wire(vk + 672 + 96ull * j, &icj, true)) return ZKMI_ERR_NON_CANONICAL;
+    if (!fr_is_canonical(publics + 32ull * (j - 1))) return ZKMI_ERR_NON_CANONICAL;
+    uint32_t k[8];
+    memcpy(k, publics + 32ull * (j - 1), 32);
+    acc.add(scalar_mul(G1XYZZ::from_affine(icj), k, 8));
+  }
+  // e(-A,B) e(alpha,beta) e(acc,gamma) e(C,delta) == 1
+  Fq12 f = miller_loop(a.neg(), b) * miller_loop(alpha, beta);
+  f = f * miller_loop(acc.to_affine(), gamma) * miller_loop(c, delta);
+  return final_exponentiation(f) == Fq12::one() ? ZKMI_OK : ZKMI_ERR_VERIFICATION;
+}
+
+}  // extern "C"

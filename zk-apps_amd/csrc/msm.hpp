@@ -1,0 +1,89 @@
+// zkmi — host-side handles for the Pippenger MSM pipeline (see msm_impl.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "curve.hpp"
+
+namespace zkmi {
+
+// hipEvent-based per-phase timers on the launch stream (bench.py reads these
+// through zkmi_prof_get; SURVEY.md §8d "hipEvent around the kernel sequence").
+struct PhaseTimer {
+  enum { MAX_PENDING = 4096 };
+  hipEvent_t ev0[MAX_PENDING], ev1[MAX_PENDING];
+  int phase_of[MAX_PENDING];
+  int n_pending = 0, n_created = 0;
+  bool enabled = false;
+  double total_ms[16] = {0};
+  uint64_t count[16] = {0};
+  ~PhaseTimer();
+  void begin(int phase, hipStream_t st);
+  void end(int phase, hipStream_t st);
+  void collect();  // call after the stream is synchronised
+  void reset();
+};
+
+enum Phase {
+  PH_MSM_SORT = 0,
+  PH_MSM_ACCUM_G1 = 1,
+  PH_MSM_REDUCE_G1 = 2,
+  PH_MSM_ACCUM_G2 = 3,
+  PH_MSM_REDUCE_G2 = 4,
+  PH_NTT = 5,
+  PH_WITNESS = 6,
+  PH_MISC = 7,
+  PH_COUNT = 8
+};
+
+struct MsmPlan {
+  int c = 0;        // window bits (signed digits)
+  int nwin = 0;     // number of windows
+  uint32_t nb = 0;  // buckets per window = 2^(c-1)
+  uint64_t n = 0;
+};
+MsmPlan msm_make_plan(uint64_t n);
+MsmPlan msm_make_plan_c(uint64_t n, int c);
+
+// Bucket scatter: signed-digit decomposition + counting sort of point indices
+// by (window, bucket).  Shared by every MSM over the same scalar vector.
+struct MsmSort {
+  uint32_t* counts = nullptr;  // nwin*nb+1 (exclusive offsets after run)
+  uint32_t* cursor = nullptr;
+  uint32_t* sorted = nullptr;  // nwin*n
+  uint64_t cap_entries = 0, cap_buckets = 0;
+  MsmPlan plan;
+  int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
+  ~MsmSort() { release(); }
+  void release();
+  hipError_t reserve(uint64_t n);
+  hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
+};
+
+template <class F>
+struct MsmEngine {
+  XYZZ<F>* buckets = nullptr;
+  XYZZ<F>* segsum = nullptr;
+  XYZZ<F>* segw = nullptr;
+  XYZZ<F>* partial = nullptr;
+  uint64_t cap_buckets = 0;
+  ~MsmEngine() { release(); }
+  void release();
+  hipError_t reserve(uint64_t n);
+  // device part: bucket accumulation + reduction down to per-window partials
+  hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, PhaseTimer* prof,
+                        int ph_accum, int ph_reduce);
+  // host part: fetch partials (synchronises the stream) and combine
+  hipError_t finish_host(const MsmSort& sort, XYZZ<F>* out, hipStream_t st);
+  // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
+  hipError_t finish_host_windows(const MsmSort& sort, XYZZ<F>* out_windows, hipStream_t st);
+};
+
+template <class F>
+hipError_t bases_to_mont(Affine<F>* d_pts, uint64_t n, hipStream_t st);
+
+extern template struct MsmEngine<Fq>;
+extern template struct MsmEngine<Fq2>;
+extern template hipError_t bases_to_mont<Fq>(Affine<Fq>*, uint64_t, hipStream_t);
+extern template hipError_t bases_to_mont<Fq2>(Affine<Fq2>*, uint64_t, hipStream_t);
+
+}  // namespace zkmi

@@ -1,0 +1,272 @@
+// zkmi — Pippenger bucket-method MSM on gfx950, templated on the base field
+// (F = Fq -> G1, F = Fq2 -> G2).
+//
+// Reference locus: none in /root/reference.  The
+// value computed is sum_i s_i * P_i, the same group element
+// ark_ec::VariableBaseMSM::msm_bigint / halo2curves::msm::best_multiexp
+// return; any correct bucket schedule is bit-exact after affine normalisation.
+//
+// HBM layout
+//   scalars : n x 32 B canonical little-endian integers < r (NOT Montgomery)
+//   bases   : n x Affine<F> in Montgomery form, (0,0) = infinity
+//   counts  : (nwin*nb + 1) x u32   bucket histogram -> exclusive offsets
+//   cursor  : nwin*nb x u32         scatter cursors
+//   sorted  : nwin*n x u32          point index | sign<<31, grouped by bucket
+//   buckets : nwin*nb x XYZZ<F>
+//   segsum / segw : nwin*nb/SEG x XYZZ<F>
+//   partial : nwin*(1+log2(nb/SEG)) x XYZZ<F>   -> host
+//
+// Kernel chain (all on one stream):
+//   1 k_hist      thread/scalar : signed c-bit digits, histogram (u32 atomics)
+//   2 k_scan      exclusive prefix sum of the histogram
+//   3 k_scatter   thread/scalar : cursor = atomicAdd -> sorted[] (bucket scatter)
+//   4 k_accum     thread/bucket : gather affine points, XYZZ mixed adds   <- dominant
+//   5 k_segreduce thread/16 buckets : running-sum  sum (i+1) B_i  and  sum B_i
+//   6 k_treesum   block/(window, job) : plain sums (LDS tree) of segw, and of
+//                 segsum over {t : bit j of t set}
+//   host: window_w = P[w][0] + SEG * sum_j 2^j P[w][1+j];  result = sum_w 2^(c w) window_w
+#pragma once
+#include <vector>
+#include "curve.hpp"
+#include "msm.hpp"
+
+namespace zkmi {
+
+constexpr int MSM_SEG = 16;  // buckets per segment in k_segreduce
+constexpr int MSM_SEG_LOG = 4;
+constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 48 KiB LDS
+
+template <class T>
+__device__ __forceinline__ T load_vec(const T* p) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte multiple");
+  T r;
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+  uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+  return r;
+}
+template <class T>
+__device__ __forceinline__ void store_vec(T* p, const T& v) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte multiple");
+  const uint4* s = reinterpret_cast<const uint4*>(&v);
+  uint4* d = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+}
+
+// signed-digit decomposition of a 256-bit little-endian scalar.
+// digit_w in [-(2^(c-1) - 1), 2^(c-1)]; returns |digit| (0 = skip) and sign.
+struct DigitIter {
+  uint32_t k[8];
+  uint32_t carry;
+  int c;
+  __device__ __forceinline__ void init(const uint32_t* s, int c_) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = s[i];
+    carry = 0;
+    c = c_;
+  }
+  __device__ __forceinline__ uint32_t window_bits(int w) const {
+    const int bit = w * c;
+    const int limb = bit >> 5, sh = bit & 31;
+    if (limb >= 8) return 0;
+    uint64_t v = k[limb];
+    if (limb + 1 < 8) v |= (uint64_t)k[limb + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+  }
+  // returns magnitude in [0, 2^(c-1)], sets neg
+  __device__ __forceinline__ uint32_t next(int w, bool& neg) {
+    uint32_t d = window_bits(w) + carry;
+    const uint32_t halfv = 1u << (c - 1);
+    if (d > halfv) {
+      d = (1u << c) - d;
+      neg = true;
+      carry = 1;
+    } else {
+      neg = false;
+      carry = 0;
+    }
+    return d;
+  }
+};
+
+template <class F>
+__global__ void __launch_bounds__(256)
+k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ offsets,
+        const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total_buckets) return;
+  const uint32_t beg = offsets[b], end = offsets[b + 1];
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (uint32_t j = beg; j < end; j++) {
+    const uint32_t v = sorted[j];
+    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+    if (v >> 31) p.y = p.y.neg();
+    acc.madd(p);
+  }
+  store_vec(buckets + b, acc);
+}
+
+// thread t handles buckets [t*SEG, (t+1)*SEG) of one window (global segment id)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, XYZZ<F>* __restrict__ segw,
+            uint32_t total_segs) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_segs) return;
+  XYZZ<F> run = XYZZ<F>::infinity();
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int i = MSM_SEG - 1; i >= 0; i--) {
+    XYZZ<F> bk = load_vec(buckets + (size_t)t * MSM_SEG + i);
+    run.add(bk);
+    acc.add(run);
+  }
+  store_vec(segsum + t, run);
+  store_vec(segw + t, acc);
+}
+
+// grid = (njobs, nwin).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t]
+template <class F>
+__global__ void __launch_bounds__(MSM_TREE_T)
+k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, uint32_t segs_per_win,
+          XYZZ<F>* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
+  const int job = blockIdx.x;
+  const int w = blockIdx.y;
+  const XYZZ<F>* src = (job == 0 ? segw : segsum) + (size_t)w * segs_per_win;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (uint32_t t = threadIdx.x; t < segs_per_win; t += blockDim.x) {
+    if (job == 0 || ((t >> (job - 1)) & 1u)) {
+      XYZZ<F> v = load_vec(src + t);
+      acc.add(v);
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      acc.add(sh[threadIdx.x + s]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_vec(partial + (size_t)w * gridDim.x + job, acc);
+}
+
+template <class F>
+__global__ void k_bases_to_mont(Affine<F>* __restrict__ pts, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = load_vec(pts + i);
+  p.x = p.x.to_mont();
+  p.y = p.y.to_mont();
+  store_vec(pts + i, p);
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+template <class F>
+void MsmEngine<F>::release() {
+  if (buckets) (void)hipFree(buckets);
+  if (segsum) (void)hipFree(segsum);
+  if (segw) (void)hipFree(segw);
+  if (partial) (void)hipFree(partial);
+  buckets = segsum = segw = partial = nullptr;
+  cap_buckets = 0;
+}
+
+uint64_t msm_max_buckets(uint64_t n);
+
+template <class F>
+hipError_t MsmEngine<F>::reserve(uint64_t n) {
+  const uint64_t need = msm_max_buckets(n);
+  if (need <= cap_buckets) return hipSuccess;
+  release();
+  hipError_t e;
+  if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need)) != hipSuccess) return e;
+  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&partial, sizeof(XYZZ<F>) * 64 * 32)) != hipSuccess) return e;
+  cap_buckets = need;
+  return hipSuccess;
+}
+
+static inline int msm_seg_bits(const MsmPlan& pl) {
+  const uint32_t segs_per_win = pl.nb / MSM_SEG;
+  int seg_bits = 0;
+  while ((1u << seg_bits) < segs_per_win) seg_bits++;
+  return seg_bits;
+}
+
+template <class F>
+hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
+                                    PhaseTimer* prof, int ph_accum, int ph_reduce) {
+  const MsmPlan& pl = sort.plan;
+  const uint32_t tot_b = pl.nwin * pl.nb;
+  const int T = 256;
+  if (prof) prof->begin(ph_accum, st);
+  hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.counts, sort.sorted,
+                     buckets, tot_b);
+  if (prof) prof->end(ph_accum, st);
+  if (prof) prof->begin(ph_reduce, st);
+  const uint32_t segs_per_win = pl.nb / MSM_SEG;
+  const uint32_t tot_segs = pl.nwin * segs_per_win;
+  hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st, buckets, segsum, segw, tot_segs);
+  const int njobs = 1 + msm_seg_bits(pl);
+  hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, segsum,
+                     segw, segs_per_win, partial);
+  if (prof) prof->end(ph_reduce, st);
+  return hipGetLastError();
+}
+
+template <class F>
+hipError_t MsmEngine<F>::finish_host_windows(const MsmSort& sort, XYZZ<F>* out_windows, hipStream_t st) {
+  const MsmPlan& pl = sort.plan;
+  const int seg_bits = msm_seg_bits(pl);
+  const int njobs = 1 + seg_bits;
+  std::vector<XYZZ<F>> h((size_t)pl.nwin * njobs);
+  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(XYZZ<F>) * h.size(), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  for (int w = 0; w < pl.nwin; w++) {
+    XYZZ<F> u = XYZZ<F>::infinity();
+    for (int j = seg_bits - 1; j >= 0; j--) {
+      u.dbl_inplace();
+      u.add(h[(size_t)w * njobs + 1 + j]);
+    }
+    for (int i = 0; i < MSM_SEG_LOG; i++) u.dbl_inplace();
+    u.add(h[(size_t)w * njobs]);
+    out_windows[w] = u;
+  }
+  return hipSuccess;
+}
+
+template <class F>
+XYZZ<F> msm_combine_windows(const XYZZ<F>* windows, int nwin, int c) {
+  XYZZ<F> total = XYZZ<F>::infinity();
+  for (int w = nwin - 1; w >= 0; w--) {
+    for (int i = 0; i < c; i++) total.dbl_inplace();
+    total.add(windows[w]);
+  }
+  return total;
+}
+
+template <class F>
+hipError_t MsmEngine<F>::finish_host(const MsmSort& sort, XYZZ<F>* out, hipStream_t st) {
+  std::vector<XYZZ<F>> win(sort.plan.nwin);
+  hipError_t e = finish_host_windows(sort, win.data(), st);
+  if (e != hipSuccess) return e;
+  *out = msm_combine_windows(win.data(), sort.plan.nwin, sort.plan.c);
+  return hipSuccess;
+}
+
+template <class F>
+hipError_t bases_to_mont(Affine<F>* d_pts, uint64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_bases_to_mont<F>, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, (uint32_t)n);
+  return hipGetLastError();
+}
+
+}  // namespace zkmi
