@@ -173,6 +173,10 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
  * Replaces ark_groth16::prover::create_proof_with_assignment [not in tree]. */
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r[32], const uint8_t s[32],
                            uint8_t out_proof[192]);
+/* same with the witness already resident in HBM (n_vars x 32 B canonical LE;
+ * elements are trusted to be < r) — the entry point bench.py times. */
+int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z, const uint8_t r[32], const uint8_t s[32],
+                               uint8_t out_proof[192]);
 /* h-polynomial coefficients only (row a7), N x 32 B canonical LE */
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h);
 /* row a11: pairing check on the host CPU.  publics excludes the leading 1. */

@@ -1,0 +1,221 @@
+"""CPU suite, part 2: the product's host logic through the C ABI (no compute
+kernels are launched; the library must load and export every declared symbol
+without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, golden
+from oracle import bls12_381 as ec
+from oracle import groth16 as g16
+
+H = bytes.fromhex
+
+
+def test_library_exports_every_declared_symbol(zk):
+    hdr = open(os.path.join(ROOT, "include", "zkmi.h")).read()
+    names = set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 50
+    for n in sorted(names):
+        assert hasattr(zk.lib, n), f"{n} declared in include/zkmi.h but not exported"
+
+
+def test_ctx_create_without_gpu_fails_loudly(zk, pkg):
+    if zk.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.context(0)
+    assert e.value.code == -4  # ZKMI_ERR_NO_DEVICE: no silent CPU fallback
+
+
+def test_wire_and_compression(zk):
+    c = golden("constants.json")
+    assert zk.g1_generator().hex() == c["g1"] and zk.g2_generator().hex() == c["g2"]
+    assert zk.g1_compress(H(c["g1"])).hex() == c["g1_compressed"]
+    assert zk.g2_compress(H(c["g2"])).hex() == c["g2_compressed"]
+    assert zk.g1_decompress(H(c["g1_compressed"])).hex() == c["g1"]
+    assert zk.g2_decompress(H(c["g2_compressed"])).hex() == c["g2"]
+    assert zk.g1_mul(H(c["g1"]), (0xC0FFEE).to_bytes(32, "little")).hex() == c["g1_times_c0ffee"]
+    assert zk.g2_mul(H(c["g2"]), (0xC0FFEE).to_bytes(32, "little")).hex() == c["g2_times_c0ffee"]
+    assert zk.g1_mul(H(c["g1"]), ec.fr_to_bytes(ec.R - 1)).hex() == c["g1_times_r_minus_1"]
+    # P + (-P) = infinity, infinity encodings
+    assert zk.g1_add(H(c["g1"]), H(c["g1_times_r_minus_1"])) == bytes(96)
+    assert zk.g1_compress(bytes(96)) == bytes([0xC0]) + bytes(47)
+    assert zk.g1_decompress(bytes([0xC0]) + bytes(47)) == bytes(96)
+    assert zk.g2_compress(bytes(192)) == bytes([0xC0]) + bytes(95)
+
+
+def test_rejects_bad_points_and_scalars(zk, pkg):
+    g = bytearray(zk.g1_generator())
+    g[0] ^= 1
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.g1_compress(bytes(g))
+    assert e.value.code == -2
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.g1_mul(zk.g1_generator(), ec.R.to_bytes(32, "little"))
+    assert e.value.code == -2
+
+
+def test_pairing_matches_oracle(zk):
+    pg = golden("pairing.json")
+    p = ec.g1_to_bytes(ec.g1_mul(pg["a"]))
+    q = ec.g2_to_bytes(ec.g2_mul(pg["b"]))
+    gt = zk.pairing(p, q)
+    co = [int.from_bytes(gt[48 * i : 48 * i + 48], "little") for i in range(12)]
+    poly = [0] * 12  # tower basis -> Fq[w]/(w^12 - 2w^6 + 2): u = w^6 - 1, v = w^2
+    idx = 0
+    for i in range(2):
+        for j in range(3):
+            for u in range(2):
+                c = co[idx]
+                idx += 1
+                e = 2 * j + i
+                if u == 0:
+                    poly[e] = (poly[e] + c) % ec.P
+                else:
+                    poly[e + 6] = (poly[e + 6] + c) % ec.P
+                    poly[e] = (poly[e] - c) % ec.P
+    assert [hex(v) for v in poly] == pg["e_aG1_bG2"]
+
+
+def test_shielder_relation_matches_oracle(zk):
+    lg = 7
+    r = zk.shielder_r1cs(lg)
+    ro = g16.shielder_r1cs(lg)
+    assert (r.n_vars, r.n_pub, r.n_constraints, r.log_n) == (ro.n_vars, ro.n_pub, ro.n_constraints, ro.log_n)
+    for m, M in enumerate((ro.A, ro.B, ro.C)):
+        rp, cl, vl = r.export(m)
+        rows = [
+            [(cl[k], int.from_bytes(vl[32 * k : 32 * k + 32], "little")) for k in range(rp[i], rp[i + 1])]
+            for i in range(r.n_constraints)
+        ]
+        assert rows == [[(j, c % ec.R) for j, c in row] for row in M]
+    w = zk.shielder_witness(lg, 42)
+    assert w == b"".join(ec.fr_to_bytes(v) for v in g16.shielder_witness(lg, 42))
+    assert r.is_satisfied(w)
+    bad = bytearray(w)
+    bad[32 * 50] ^= 1
+    assert not r.is_satisfied(bytes(bad))
+    # round trip through the generic CSR constructor
+    r2 = zk.r1cs_create(r.n_vars, r.n_pub, [r.export(m) for m in range(3)])
+    assert r2.is_satisfied(w) and r2.log_n == r.log_n
+    r.free()
+    r2.free()
+
+
+def test_shielder_relation_shape_at_config0_size(zk):
+    r = zk.shielder_r1cs(14)
+    assert r.n_vars == 1 << 14 and r.n_constraints + r.n_pub == 1 << 14 and r.log_n == 14
+    assert r.is_satisfied(zk.shielder_witness(14, 1))
+    r.free()
+
+
+def test_host_verifier_on_golden_proof(zk):
+    gd = golden("groth16_n128.json")
+    wit = H(gd["witness"])
+    publics = wit[32 : 32 * 7]
+    assert zk.groth16_verify(H(gd["vk"]), publics, H(gd["proof"])) is True
+    bad = bytearray(publics)
+    bad[5] ^= 0x10
+    assert zk.groth16_verify(H(gd["vk"]), bytes(bad), H(gd["proof"])) is False
+    # proof with A and C swapped is rejected
+    pr = H(gd["proof"])
+    assert zk.groth16_verify(H(gd["vk"]), publics, pr[144:] + pr[48:144] + pr[:48]) is False
+
+
+def test_msm_window_combine_host(zk):
+    """zkmi_msm_g1_combine (the local step after the all-gather of SURVEY §8e)."""
+    c, nwin = 13, 255 // 13 + 1
+    rng = ec.SplitMix64(5)
+    ks = [[rng.fr() for _ in range(nwin)] for _ in range(2)]
+    wins = b"".join(ec.g1_to_bytes(ec.g1_mul(k)) for r in ks for k in r)
+    exp = sum((ks[0][w] + ks[1][w]) << (c * w) for w in range(nwin)) % ec.R
+    assert zk.msm_g1_combine(wins, 2, nwin, c) == ec.g1_to_bytes(ec.g1_mul(exp))
+
+
+# ------------------------------------------------ mocked_zk mirror (row a12)
+def _tokens():
+    return [bytes([228] * 32), bytes(32)]  # MOCKED_TOKEN, shielder/mocked_zk/src/lib.rs:18
+
+
+def _empty_note_proof(zk, id_, nullifier, trapdoor):
+    acc = zk.account_new(_tokens())
+    h = zk.note_hash(id_, trapdoor, nullifier, zk.account_hash(acc))
+    user = (1).to_bytes(16, "little") + bytes(16)  # mocked_user()
+    return h, zk.zkproof_new(id_, trapdoor, nullifier, zk.op_priv(user), acc)
+
+
+def test_mock_boundary_golden_vectors(zk):
+    m = golden("mock_boundary.json")
+    acc = zk.account_new(_tokens())
+    assert zk.account_hash(acc).hex() == m["account_hash_empty"]
+    z32 = bytes(32)
+    assert zk.note_hash(z32, z32, z32, zk.account_hash(acc)).hex() == m["empty_note_hash"]
+    s1 = (1).to_bytes(16, "little") + bytes(16)
+    s2 = (2).to_bytes(16, "little") + bytes(16)
+    cur = zk.combine_merkle_hash(s1, s2)
+    for _ in range(9):
+        cur = zk.combine_merkle_hash(cur, z32)
+    assert cur.hex() == m["merkle_root_two_leaves"]
+
+
+def test_create_note(zk):
+    """shielder/mocked_zk/src/tests.rs:27-35"""
+    z32 = bytes(32)
+    h, proof = _empty_note_proof(zk, z32, z32, z32)
+    zk.zkproof_verify_creation(proof, h, _tokens())
+
+
+def test_create_note_fails(zk, pkg):
+    """shielder/mocked_zk/src/tests.rs:37-51"""
+    z32 = bytes(32)
+    _, proof = _empty_note_proof(zk, z32, z32, z32)
+    h_other, _ = _empty_note_proof(zk, (1).to_bytes(16, "little") + bytes(16), z32, z32)
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.zkproof_verify_creation(proof, h_other, _tokens())
+    assert e.value.name == "VerificationError"
+
+
+def test_deposit_withdraw_flow(zk, pkg):
+    """Prove-side sequence of drink_tests/utils/shielder.rs:78-134 against the
+    verify side of contract/lib.rs:63-78, with the Merkle path semantics of
+    contract/merkle.rs:89-102 (missing sibling = zero scalar)."""
+    z32 = bytes(32)
+    user = (1).to_bytes(16, "little") + bytes(16)
+    token = _tokens()[0]
+    ident = (7).to_bytes(16, "little") + bytes(16)
+    h0, p0 = _empty_note_proof(zk, ident, (11).to_bytes(32, "little"), (12).to_bytes(32, "little"))
+    path = [z32] * 10  # single-leaf tree: zero siblings, leaf id 0
+    root = h0
+    for s in path:
+        root = zk.combine_merkle_hash(root, s)
+    dep = zk.op_pub("deposit", 10, token, user)
+    h1, p1 = zk.zkproof_update_account(p0, dep, zk.op_priv(user), (13).to_bytes(32, "little"), (14).to_bytes(32, "little"), path, 0)
+    zk.zkproof_verify_update(p1, dep, h1, root, (11).to_bytes(32, "little"))
+    with pytest.raises(pkg.ZkmiError) as e:  # wrong old nullifier
+        zk.zkproof_verify_update(p1, dep, h1, root, (99).to_bytes(32, "little"))
+    assert e.value.name == "VerificationError"
+    other = zk.op_pub("deposit", 10, token, (2).to_bytes(16, "little") + bytes(16))
+    with pytest.raises(pkg.ZkmiError) as e:  # ops.rs:47-63
+        zk.zkproof_verify_update(p1, other, h1, root, (11).to_bytes(32, "little"))
+    assert e.value.name == "OperationCombineError"
+    wd = zk.op_pub("withdraw", 11, token, user)
+    with pytest.raises(pkg.ZkmiError) as e:  # account.rs:57-62 checked_sub
+        zk.zkproof_update_account(p1, wd, zk.op_priv(user), z32, z32, path, 0)
+    assert e.value.name == "AccountUpdateError"
+    unk = zk.op_pub("deposit", 1, bytes([9] * 32), user)
+    with pytest.raises(pkg.ZkmiError) as e:  # unknown token
+        zk.zkproof_update_account(p1, unk, zk.op_priv(user), z32, z32, path, 0)
+    assert e.value.name == "AccountUpdateError"
+    wd9 = zk.op_pub("withdraw", 9, token, user)
+    h2, p2 = zk.zkproof_update_account(p1, wd9, zk.op_priv(user), z32, z32, path, 0)
+    assert bytes(p2.acc_new.balances[0][1].bytes)[:16] == (1).to_bytes(16, "little")
+
+
+def test_account_hash_quirk_only_second_balance(zk):
+    """account.rs:16-24 hashes only balances[1].1 — token-0 deposits do not change it."""
+    user = (1).to_bytes(16, "little") + bytes(16)
+    acc = zk.account_new(_tokens())
+    acc2 = zk.account_update(acc, zk.op_pub("deposit", 5, _tokens()[0], user), zk.op_priv(user))
+    assert zk.account_hash(acc) == zk.account_hash(acc2)

@@ -1,0 +1,124 @@
+"""CPU suite, part 1: the oracle against the golden vectors and its own
+definitions (no GPU, no product code)."""
+import hashlib
+
+from conftest import golden
+from oracle import bls12_381 as ec
+from oracle import cpp as ocpp
+from oracle import groth16 as g16
+from oracle import ntt as ont
+from oracle.bls12_381 import P, R
+
+H = bytes.fromhex
+
+
+def test_curve_constants_known_answers():
+    c = golden("constants.json")
+    x = -0xD201000000010000
+    assert int(c["r"], 16) == x**4 - x**2 + 1 == R
+    assert int(c["p"], 16) == (x - 1) ** 2 * R // 3 + x == P
+    assert ec.on_curve(ec.Fq, ec.B_G1, ec.G1) and ec.on_curve(ec.Fq2, ec.B_G2, ec.G2)
+    assert ec.pt_mul(ec.Fq, ec.G1, R) is None and ec.pt_mul(ec.Fq2, ec.G2, R) is None
+    # public KAT: zcash-format compressed generators
+    assert c["g1_compressed"] == (
+        "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+        "6c55e83ff97a1aeffb3af00adb22c6bb"
+    )
+    assert c["g2_compressed"].startswith("93e02b6052719f607dacd3a088274f65")
+    assert ec.g1_compress(ec.G1).hex() == c["g1_compressed"]
+    assert ec.g2_compress(ec.G2).hex() == c["g2_compressed"]
+    w = int(c["fr_root_2_32"], 16)
+    assert w == 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
+    assert pow(w, 1 << 32, R) == 1 and pow(w, 1 << 31, R) == R - 1
+
+
+def test_reference_pinned_mock_boundary_vectors():
+    """Values the reference's own tests pin."""
+    m = golden("mock_boundary.json")
+    assert (123456).to_bytes(16, "little")[:3].hex() == m["scalar_from_123456_prefix"]
+    assert int.from_bytes(H(m["scalar_to_u128_bytes"]) + bytes(12), "little") == m["scalar_to_u128_value"]
+    assert hashlib.sha256(bytes(32)).hexdigest() == m["account_hash_empty"]
+    assert m["account_hash_empty"] == "66687aadf862bd776c8fc18b8e9f8e20089714856ee233b3902a591d0d5f2925"
+    assert m["empty_note_hash"] == "09ed9cfa36a525a93385ccdb9c324cd5e7c6396f2bc1f00860a3a7ad97e827c6"
+    assert m["merkle_root_two_leaves"] == "1025a722a6336773a341a72fdb484a51b003b588638729623e8ff89fbbfffd59"
+
+
+def test_py_ntt_matches_definition():
+    rng = ec.SplitMix64(9)
+    for lg in (1, 3, 6):
+        a = [rng.fr() for _ in range(1 << lg)]
+        assert ont.ntt(a) == ont.dft_naive(a)
+        assert ont.ntt(a, inverse=True) == ont.dft_naive(a, inverse=True)
+        assert ont.coset_intt(ont.coset_ntt(a)) == a
+    # convolution theorem
+    a = [rng.fr() for _ in range(8)] + [0] * 8
+    b = [rng.fr() for _ in range(8)] + [0] * 8
+    c = ont.ntt([x * y % R for x, y in zip(ont.ntt(a), ont.ntt(b))], inverse=True)
+    exp = [0] * 16
+    for i in range(8):
+        for j in range(8):
+            exp[i + j] = (exp[i + j] + a[i] * b[j]) % R
+    assert c == exp
+
+
+def test_cpp_oracle_ntt_golden():
+    for c in golden("ntt_small.json"):
+        x, lg = H(c["input"]), c["log_n"]
+        assert ocpp.ntt(x, lg) == H(c["forward"])
+        assert ocpp.ntt(x, lg, True) == H(c["inverse"])
+        assert ocpp.ntt(x, lg, False, True) == H(c["coset_forward"])
+        assert ocpp.ntt(x, lg, True, True) == H(c["coset_inverse"])
+
+
+def test_cpp_oracle_msm_golden():
+    for c in golden("msm_small.json"):
+        f = ocpp.msm_g1 if c["group"] == 1 else ocpp.msm_g2
+        assert f(H(c["scalars"]), H(c["bases"])) == H(c["expected"]), c["name"]
+
+
+def test_cpp_oracle_thread_count_invariance():
+    c = [x for x in golden("msm_small.json") if x["name"] == "g1_uniform_64"][0]
+    assert ocpp.msm_g1(H(c["scalars"]), H(c["bases"]), 1) == ocpp.msm_g1(H(c["scalars"]), H(c["bases"]), 3)
+    n = golden("ntt_small.json")[-1]
+    assert ocpp.ntt(H(n["input"]), n["log_n"], nthreads=1) == ocpp.ntt(H(n["input"]), n["log_n"], nthreads=5)
+
+
+def test_py_pairing_bilinear_and_golden():
+    pg = golden("pairing.json")
+    e = ec.pairing(ec.G1, ec.G2)
+    assert [hex(v) for v in e] == pg["e_g1_g2"]
+    assert e != ec.f12_one() and ec.f12_pow(e, R) == ec.f12_one()
+
+
+def test_py_groth16_golden_proof_verifies():
+    gd = golden("groth16_n128.json")
+    r1 = g16.shielder_r1cs(gd["log_n"])
+    z = g16.shielder_witness(gd["log_n"], gd["witness_seed"])
+    assert b"".join(map(ec.fr_to_bytes, z)) == H(gd["witness"])
+    assert r1.is_satisfied(z)
+    vk = H(gd["vk"])
+    vkd = {
+        "alpha_g1": ec.g1_from_bytes(vk[:96]),
+        "beta_g2": ec.g2_from_bytes(vk[96:288]),
+        "gamma_g2": ec.g2_from_bytes(vk[288:480]),
+        "delta_g2": ec.g2_from_bytes(vk[480:672]),
+        "gamma_abc_g1": [ec.g1_from_bytes(vk[672 + 96 * i : 768 + 96 * i]) for i in range(r1.n_pub)],
+    }
+    proof = g16.proof_from_bytes(H(gd["proof"]))
+    assert g16.verify(vkd, z[1 : r1.n_pub], proof)
+    bad = list(z[1 : r1.n_pub])
+    bad[3] = (bad[3] + 1) % R
+    assert not g16.verify(vkd, bad, proof)
+
+
+def test_cpp_oracle_prover_golden(zk):
+    """C++ restatement reproduces the Python oracle's proof bytes (uses the
+    product only to export the relation's CSR matrices)."""
+    gd = golden("groth16_n128.json")
+    r1 = zk.shielder_r1cs(gd["log_n"])
+    mats = [r1.export(m) for m in range(3)]
+    pk = {k: H(v) for k, v in gd["pk"].items()}
+    wit = H(gd["witness"])
+    assert ocpp.witness_map(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, wit) == H(gd["h"])
+    pf = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, pk, wit, H(gd["r"]), H(gd["s"]))
+    assert pf == H(gd["proof"])

@@ -441,6 +441,11 @@ class Context:
         self._chk(self.lib.zkmi_groth16_prove(self.h, pk.h, _buf(z), _buf(r), _buf(s), out))
         return bytes(out)
 
+    def groth16_prove_dev(self, pk, d_z_ptr, r, s):
+        out = (C.c_uint8 * 192)()
+        self._chk(self.lib.zkmi_groth16_prove_dev(self.h, pk.h, C.c_void_p(d_z_ptr), _buf(r), _buf(s), out))
+        return bytes(out)
+
     def groth16_witness_map(self, pk, z):
         out = (C.c_uint8 * (32 << pk.r1cs.log_n))()
         self._chk(self.lib.zkmi_groth16_witness_map(self.h, pk.h, _buf(z), out))

@@ -379,13 +379,17 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
 }
 
 // z -> h coefficients (Montgomery form, natural order) in pk->d_a
-static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z) {
+static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z_in) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   hipStream_t st = ctx->stream;
-  for (uint32_t i = 0; i < nv; i++)
-    if (!fr_is_canonical(z + 32ull * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
   PhaseTimer* t = ctx->timer();
-  ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, st));
+  if (z) {
+    for (uint32_t i = 0; i < nv; i++)
+      if (!fr_is_canonical(z + 32ull * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, st));
+  } else {
+    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, d_z_in, 32ull * nv, hipMemcpyDeviceToDevice, st));
+  }
   if (t) t->begin(PH_WITNESS, st);
   ZK_HIP(ctx, hipMemcpyAsync(pk->d_zm, pk->d_z, 32ull * nv, hipMemcpyDeviceToDevice, st));
   ZK_HIP(ctx, ntt_to_mont(pk->d_zm, nv, st));
@@ -415,7 +419,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
 
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h) {
   if (!ctx || !pk || !z || !out_h) return ZKMI_ERR_BAD_ARG;
-  int32_t rc = witness_map_dev(ctx, pk, z);
+  int32_t rc = witness_map_dev(ctx, pk, z, nullptr);
   if (rc != ZKMI_OK) return rc;
   const uint32_t N = 1u << pk->log_n;
   ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, ctx->stream));
@@ -424,13 +428,13 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   return ZKMI_OK;
 }
 
-int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
-                           const uint8_t s_bytes[32], uint8_t out_proof[192]) {
-  if (!ctx || !pk || !z || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
+static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, const uint8_t r_bytes[32],
+                          const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
   if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   hipStream_t st = ctx->stream;
-  int32_t rc = witness_map_dev(ctx, pk, z);
+  int32_t rc = witness_map_dev(ctx, pk, z, d_z);
   if (rc != ZKMI_OK) return rc;
   ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, st));  // h as canonical integers for the digit sort
   PhaseTimer* t = ctx->timer();
@@ -481,6 +485,18 @@ int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, c
   g2_compress(g2_b.to_affine(), out_proof + 48);
   g1_compress(g_c.to_affine(), out_proof + 144);
   return ZKMI_OK;
+}
+
+int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
+                           const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  if (!z) return ZKMI_ERR_BAD_ARG;
+  return prove_impl(ctx, pk, z, nullptr, r_bytes, s_bytes, out_proof);
+}
+
+int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z, const uint8_t r_bytes[32],
+                               const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  if (!d_z) return ZKMI_ERR_BAD_ARG;
+  return prove_impl(ctx, pk, nullptr, d_z, r_bytes, s_bytes, out_proof);
 }
 
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]) {
