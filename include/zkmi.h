@@ -117,6 +117,10 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
 int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uint32_t nwin, uint32_t window_bits,
                             uint8_t out_affine[96]);
 
+/* Host-executed self-test of the device limb representation (field28.hpp)
+ * against the 32-bit-limb host arithmetic; *out_mismatches must be 0. */
+int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
+
 /* ---- group / encoding helpers (host) -------------------------------------- */
 int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]);
 int32_t zkmi_g1_decompress(const uint8_t in[48], uint8_t out_affine[96]);

@@ -219,3 +219,13 @@ def test_account_hash_quirk_only_second_balance(zk):
     acc = zk.account_new(_tokens())
     acc2 = zk.account_update(acc, zk.op_pub("deposit", 5, _tokens()[0], user), zk.op_priv(user))
     assert zk.account_hash(acc) == zk.account_hash(acc2)
+
+
+def test_device_limb_representation_selftest(zk):
+    """field28.hpp (the MSM kernels' 28-bit-limb Fq) executed on the host
+    against the 32-bit-limb arithmetic: mixed-add-shaped chains, zero tests."""
+    import ctypes as C
+
+    bad = C.c_uint32(1)
+    assert zk.lib.zkmi_selftest_fq28(C.c_uint64(7), C.c_uint32(5000), C.byref(bad)) == 0
+    assert bad.value == 0

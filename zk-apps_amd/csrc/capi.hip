@@ -2,6 +2,7 @@
 // Every function returns a status code; nothing throws across the boundary.
 #include <string.h>
 #include <new>
+#include <type_traits>
 #include <vector>
 #include "ctx.hpp"
 #include "msm_impl.hpp"  // msm_combine_windows (host)
@@ -11,6 +12,21 @@ using namespace zkmi;
 namespace zkmi {
 hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t st);
 hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t st);
+}
+
+template <class B>
+static hipError_t bases_finish(B* b, hipStream_t st) {
+  using F28 = typename std::remove_pointer<decltype(b->d28)>::type;
+  hipError_t e = hipMalloc(&b->d28, sizeof(F28) * (b->n ? b->n : 1));
+  if (e != hipSuccess) return e;
+  if ((e = bases_convert(b->d, b->d28, b->n, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
+}
+template <class B>
+static void bases_destroy(B* b) {
+  if (b->d) (void)hipFree(b->d);
+  if (b->d28) (void)hipFree(b->d28);
+  delete b;
 }
 
 template <class B, class A, bool (*FROM)(const uint8_t*, A*, bool), int W>
@@ -28,9 +44,9 @@ static int32_t bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int3
   b->n = n;
   hipError_t e = hipMalloc(&b->d, sizeof(A) * (n ? n : 1));
   if (e == hipSuccess && n) e = hipMemcpy(b->d, h.data(), sizeof(A) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = bases_finish(b, ctx->stream);
   if (e != hipSuccess) {
-    if (b->d) (void)hipFree(b->d);
-    delete b;
+    bases_destroy(b);
     return ctx->hip_fail(e, "bases upload");
   }
   *out = b;
@@ -173,14 +189,12 @@ int32_t zkmi_bases_g2_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int
 }
 int32_t zkmi_bases_g1_free(zkmi_bases_g1* b) {
   if (!b) return ZKMI_ERR_BAD_ARG;
-  if (b->d) (void)hipFree(b->d);
-  delete b;
+  bases_destroy(b);
   return ZKMI_OK;
 }
 int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
   if (!b) return ZKMI_ERR_BAD_ARG;
-  if (b->d) (void)hipFree(b->d);
-  delete b;
+  bases_destroy(b);
   return ZKMI_OK;
 }
 
@@ -192,10 +206,10 @@ int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) 
   b->n = n;
   hipError_t e = hipMalloc(&b->d, sizeof(G1Affine) * n);
   if (e == hipSuccess) e = synthetic_bases_g1(b->d, n, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = bases_finish(b, ctx->stream);
   if (e != hipSuccess) {
-    if (b->d) (void)hipFree(b->d);
-    delete b;
+    bases_destroy(b);
+    b = nullptr;
     return ctx->hip_fail(e, "synthetic g1 bases");
   }
   *out = b;
@@ -209,10 +223,10 @@ int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) 
   b->n = n;
   hipError_t e = hipMalloc(&b->d, sizeof(G2Affine) * n);
   if (e == hipSuccess) e = synthetic_bases_g2(b->d, n, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = bases_finish(b, ctx->stream);
   if (e != hipSuccess) {
-    if (b->d) (void)hipFree(b->d);
-    delete b;
+    bases_destroy(b);
+    b = nullptr;
     return ctx->hip_fail(e, "synthetic g2 bases");
   }
   *out = b;
@@ -243,7 +257,7 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g1.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   G1XYZZ res;
   ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &res, ctx->stream));
   g1_to_wire(res.to_affine(), out_affine);
@@ -256,7 +270,7 @@ int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g2.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
   G2XYZZ res;
   ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &res, ctx->stream));
   g2_to_wire(res.to_affine(), out_affine);
@@ -299,7 +313,7 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
   hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
   ctx->sort.plan_override = 0;
   if (e != hipSuccess) return ctx->hip_fail(e, "sort");
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   std::vector<G1XYZZ> win(ctx->sort.plan.nwin);
   ZK_HIP(ctx, ctx->g1.finish_host_windows(ctx->sort, win.data(), ctx->stream));
   for (int w = 0; w < ctx->sort.plan.nwin; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);

@@ -17,8 +17,8 @@ struct zkmi_ctx {
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;
   zkmi::MsmSort sort;
-  zkmi::MsmEngine<zkmi::Fq> g1;
-  zkmi::MsmEngine<zkmi::Fq2> g2;
+  zkmi::MsmEngine<zkmi::Fq28> g1;
+  zkmi::MsmEngine<zkmi::Fq2_28> g2;
   void* d_tmp = nullptr;  // staging for host-buffer entry points
   uint64_t d_tmp_cap = 0;
 
@@ -55,14 +55,18 @@ struct zkmi_ctx {
   }
 };
 
+// d  : host representation (Montgomery R = 2^384), kept for read-back/export
+// d28: device MSM representation (28-bit limbs, R = 2^392), what the kernels gather
 struct zkmi_bases_g1 {
   zkmi_ctx* ctx;
   zkmi::G1Affine* d = nullptr;
+  zkmi::Affine<zkmi::Fq28>* d28 = nullptr;
   uint64_t n = 0;
 };
 struct zkmi_bases_g2 {
   zkmi_ctx* ctx;
   zkmi::G2Affine* d = nullptr;
+  zkmi::Affine<zkmi::Fq2_28>* d28 = nullptr;
   uint64_t n = 0;
 };
 

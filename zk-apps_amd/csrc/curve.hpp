@@ -31,6 +31,13 @@ struct XYZZ {
   }
   ZK_HD XYZZ neg() const { return {x, y.neg(), zz, zzz}; }
 
+  // rare-path wrappers kept out of line so the hot add path stays compact
+  __host__ __device__ __attribute__((noinline)) static XYZZ dbl_affine_slow(Affine<F> p) { return dbl_affine(p); }
+  __host__ __device__ __attribute__((noinline)) static XYZZ dbl_slow(XYZZ p) {
+    p.dbl_inplace();
+    return p;
+  }
+
   ZK_HD static XYZZ dbl_affine(const Affine<F>& p) {
     // mdbl-2008-s-1 with ZZ1 = ZZZ1 = 1
     F u = p.y.dbl();
@@ -74,15 +81,17 @@ struct XYZZ {
     F s2 = p.y * zzz;
     F pp_ = u2 - x;
     F r = s2 - y;
-    if (pp_.is_zero()) {
-      if (r.is_zero()) {
-        *this = dbl_affine(p);
+    // zero tests are made on products (P = 0 <=> P^2 = 0): exact for every
+    // field representation, including the lazily reduced device limbs
+    F pp = pp_.sqr();
+    if (pp.is_zero()) {
+      if (r.sqr().is_zero()) {
+        *this = dbl_affine_slow(p);
       } else {
         *this = infinity();
       }
       return;
     }
-    F pp = pp_.sqr();
     F ppp = pp_ * pp;
     F q = x * pp;
     F x3 = r.sqr() - ppp - q.dbl();
@@ -105,15 +114,15 @@ struct XYZZ {
     F s2 = o.y * zzz;
     F pp_ = u2 - u1;
     F r = s2 - s1;
-    if (pp_.is_zero()) {
-      if (r.is_zero()) {
-        dbl_inplace();
+    F pp = pp_.sqr();
+    if (pp.is_zero()) {
+      if (r.sqr().is_zero()) {
+        *this = dbl_slow(*this);
       } else {
         *this = infinity();
       }
       return;
     }
-    F pp = pp_.sqr();
     F ppp = pp_ * pp;
     F q = u1 * pp;
     F x3 = r.sqr() - ppp - q.dbl();

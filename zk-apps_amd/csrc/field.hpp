@@ -288,44 +288,46 @@ struct Fp {
 using Fr = Fp<FrParams>;
 using Fq = Fp<FqParams>;
 
-// Fq2 = Fq[u]/(u^2+1)
-struct Fq2 {
-  Fq c0, c1;
-  ZK_HD static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
-  ZK_HD static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+// Fq2 = Fq[u]/(u^2+1), generic over the base-field representation
+template <class B>
+struct Fq2T {
+  B c0, c1;
+  ZK_HD static Fq2T zero() { return {B::zero(), B::zero()}; }
+  ZK_HD static Fq2T one() { return {B::one(), B::zero()}; }
   ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-  ZK_HD bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; }
-  ZK_HD bool operator!=(const Fq2& o) const { return !(*this == o); }
-  ZK_HD friend Fq2 operator+(const Fq2& a, const Fq2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
-  ZK_HD friend Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
-  ZK_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
-  ZK_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
-  ZK_HD friend Fq2 operator*(const Fq2& a, const Fq2& b) {
-    Fq t0 = a.c0 * b.c0;
-    Fq t1 = a.c1 * b.c1;
-    Fq t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
+  ZK_HD bool operator==(const Fq2T& o) const { return c0 == o.c0 && c1 == o.c1; }
+  ZK_HD bool operator!=(const Fq2T& o) const { return !(*this == o); }
+  ZK_HD friend Fq2T operator+(const Fq2T& a, const Fq2T& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  ZK_HD friend Fq2T operator-(const Fq2T& a, const Fq2T& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+  ZK_HD Fq2T neg() const { return {c0.neg(), c1.neg()}; }
+  ZK_HD Fq2T dbl() const { return {c0.dbl(), c1.dbl()}; }
+  ZK_HD friend Fq2T operator*(const Fq2T& a, const Fq2T& b) {
+    B t0 = a.c0 * b.c0;
+    B t1 = a.c1 * b.c1;
+    B t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
     return {t0 - t1, t2 - t0 - t1};
   }
-  ZK_HD Fq2 sqr() const {
-    Fq s = c0 + c1;
-    Fq d = c0 - c1;
-    Fq m = c0 * c1;
+  ZK_HD Fq2T sqr() const {
+    B s = c0 + c1;
+    B d = c0 - c1;
+    B m = c0 * c1;
     return {s * d, m.dbl()};
   }
-  ZK_HD Fq2 mul_fq(const Fq& k) const { return {c0 * k, c1 * k}; }
-  ZK_HD Fq2 conj() const { return {c0, c1.neg()}; }
+  ZK_HD Fq2T mul_fq(const B& k) const { return {c0 * k, c1 * k}; }
+  ZK_HD Fq2T conj() const { return {c0, c1.neg()}; }
   // multiply by xi = 1 + u
-  ZK_HD Fq2 mul_xi() const { return {c0 - c1, c0 + c1}; }
-  __host__ __device__ Fq2 inv() const {
-    Fq d = (c0.sqr() + c1.sqr()).inv();
+  ZK_HD Fq2T mul_xi() const { return {c0 - c1, c0 + c1}; }
+  __host__ __device__ Fq2T inv() const {
+    B d = (c0.sqr() + c1.sqr()).inv();
     return {c0 * d, (c1 * d).neg()};
   }
-  ZK_HD Fq2 to_mont() const { return {c0.to_mont(), c1.to_mont()}; }
-  ZK_HD Fq2 from_mont() const { return {c0.from_mont(), c1.from_mont()}; }
+  ZK_HD Fq2T to_mont() const { return {c0.to_mont(), c1.to_mont()}; }
+  ZK_HD Fq2T from_mont() const { return {c0.from_mont(), c1.from_mont()}; }
   __host__ bool lex_larger() const {
     if (!c1.is_zero()) return c1.lex_larger();
     return c0.lex_larger();
   }
 };
+using Fq2 = Fq2T<Fq>;
 
 }  // namespace zkmi

@@ -1,0 +1,260 @@
+// zkmi — device-side Fq for the MSM kernels: 14 signed 28-bit limbs in 32-bit
+// words ("unsaturated limbs"), Montgomery radix R = 2^392.
+//
+// Why this representation on gfx950 (measured with scripts/ubench.hip, see
+// DESIGN.md): v_mad_i64_i32 / v_mad_u64_u32 issue at the same rate as a
+// carry-propagating v_addc_co_u32, so with saturated 32-bit limbs every partial
+// product costs two issue slots (multiply-add + carry) and hipcc additionally
+// spends a v_mov per product assembling 64-bit addends (1329 instructions per
+// 384-bit product).  With 28-bit limbs a 64-bit column accumulator absorbs all
+// 28 partial products of a Montgomery multiplication with no carry handling at
+// all: 196 + 196 multiply-adds and one carry sweep at the end (~500
+// instructions), and field add/sub are 14 independent v_add/v_sub plus a
+// 3-instruction-per-limb carry sweep.
+//
+// Invariants ("normalised"): limbs 0..12 in [0, 2^28); limb 13 signed and
+// small; the represented integer v = sum l[i] 2^(28 i) satisfies |v| < 16 p.
+// Values are NOT reduced to [0, p): a residue has several representations.
+//   * mul/sqr accept any normalised operands (also one lazy add/sub of two
+//     normalised values) and return v in (-p/2, 3p/2).
+//   * is_zero() is exact for |v| <= 4p, which covers products, Fq2 products and
+//     canonical inputs — the only places it is called (see curve.hpp).
+//   * to_canonical() returns the unique representative in [0, p).
+#pragma once
+#include "field.hpp"
+
+namespace zkmi {
+
+struct Fq28Params {
+  static constexpr int NL = 14;   // limbs
+  static constexpr int N32 = 12;  // 32-bit words of the canonical form
+  static constexpr uint32_t INV = 0xffcfffdu;  // -p^-1 mod 2^28
+  static constexpr int32_t MOD[14] = {0xfffaaab, 0xfefffff, 0x3ffffb9, 0xfffeb15, 0x6241eab, 0xa0f6b0f, 0xf6730d2,
+                                      0xf38512b, 0x4774b84, 0x4bacd76, 0xba7b643, 0xe69a4b1, 0x1ea397f, 0x001a011};
+  static constexpr int32_t ONE[14] = {0x347fcb8, 0xd800000, 0x002b119, 0x0cde6d2, 0xc7212e0, 0x83a2090, 0x037669f,
+                                      0xda0f73e, 0x9b09b42, 0x1297bb0, 0x515d98f, 0x012ca7c, 0x659fcfa, 0x000577a};
+  static constexpr int32_t R2[14] = {0x10370ed, 0x6d1c345, 0xe243d62, 0xec45c53, 0x3b1d65a, 0x093317d, 0xb4f36a0,
+                                     0x5d74088, 0xc10ea72, 0x865d118, 0x7320a75, 0xfd5cd50, 0xcc8a759, 0x000c8d4};
+};
+
+template <class P>
+struct Fp28 {
+  static constexpr int NL = P::NL;
+  static constexpr int32_t MASK = (1 << 28) - 1;
+  int32_t l[NL];
+
+  ZK_HD static Fp28 zero() {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = 0;
+    return r;
+  }
+  ZK_HD static Fp28 one() {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = P::ONE[i];
+    return r;
+  }
+  // signed carry sweep: limbs 0..NL-2 -> [0, 2^28), the top limb absorbs the rest
+  ZK_HD void carry() {
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+      const int32_t c = l[i] >> 28;
+      l[i] &= MASK;
+      l[i + 1] += c;
+    }
+  }
+  ZK_HD friend Fp28 operator+(const Fp28& a, const Fp28& b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    r.carry();
+    return r;
+  }
+  ZK_HD friend Fp28 operator-(const Fp28& a, const Fp28& b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] - b.l[i];
+    r.carry();
+    return r;
+  }
+  // lazy forms: no carry sweep; result may only feed mul/sqr or one carry()
+  ZK_HD Fp28 add_lazy(const Fp28& b) const {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = l[i] + b.l[i];
+    return r;
+  }
+  ZK_HD Fp28 sub_lazy(const Fp28& b) const {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = l[i] - b.l[i];
+    return r;
+  }
+  ZK_HD Fp28 neg() const {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = -l[i];
+    r.carry();
+    return r;
+  }
+  ZK_HD Fp28 dbl() const {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = l[i] * 2;
+    r.carry();
+    return r;
+  }
+
+  // Montgomery reduction of the 2*NL column accumulators, result from columns NL..
+  ZK_HD static Fp28 reduce(int64_t* T) {
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      const int32_t m = (int32_t)(((uint32_t)T[k] * P::INV) & (uint32_t)MASK);
+#pragma unroll
+      for (int j = 0; j < NL; j++) T[k + j] += (int64_t)m * P::MOD[j];
+      T[k + 1] += T[k] >> 28;  // exact: low 28 bits of T[k] are now zero
+    }
+    Fp28 r;
+    int64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+      const int64_t v = T[NL + k] + c;
+      r.l[k] = (int32_t)v & MASK;
+      c = v >> 28;
+    }
+    r.l[NL - 1] = (int32_t)(T[2 * NL - 1] + c);
+    return r;
+  }
+
+  ZK_HD friend Fp28 operator*(const Fp28& a, const Fp28& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CALL_MUL28)
+    return mul_call(a, b);
+#else
+    return mul_inline(a, b);
+#endif
+  }
+  ZK_HD Fp28 sqr() const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CALL_MUL28)
+    return sqr_call(*this);
+#else
+    return sqr_inline();
+#endif
+  }
+  // out-of-line device copies (one shared routine per TU; keeps G2 kernels
+  // inside the instruction cache)
+  __device__ __attribute__((noinline)) static Fp28 mul_call(Fp28 a, Fp28 b) { return mul_inline(a, b); }
+  __device__ __attribute__((noinline)) static Fp28 sqr_call(Fp28 a) { return a.sqr_inline(); }
+  ZK_HD static Fp28 mul_inline(const Fp28& a, const Fp28& b) {
+    int64_t T[2 * NL];
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+      for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
+    return reduce(T);
+  }
+  ZK_HD Fp28 sqr_inline() const {
+    int64_t T[2 * NL];
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      T[2 * i] += (int64_t)l[i] * l[i];
+      const int32_t d = l[i] * 2;
+#pragma unroll
+      for (int j = i + 1; j < NL; j++) T[i + j] += (int64_t)d * l[j];
+    }
+    return reduce(T);
+  }
+
+  // exact for |v| <= 4p (see header): v == k p for some |k| <= 4
+  ZK_HD bool is_zero() const {
+    // top limbs of the normalised representations of k*p, k = -4..4
+    const int32_t t = l[NL - 1];
+    bool cand = false;
+#pragma unroll
+    for (int k = -4; k <= 4; k++) cand |= (t == kp_limb(k, NL - 1));
+    if (!cand) return false;
+    bool hit = false;
+#pragma unroll
+    for (int k = -4; k <= 4; k++) {
+      int32_t diff = 0;
+#pragma unroll
+      for (int i = 0; i < NL; i++) diff |= l[i] ^ kp_limb(k, i);
+      hit |= (diff == 0);
+    }
+    return hit;
+  }
+  // limb i of the normalised representation of k*p (compile-time foldable)
+  ZK_HD static constexpr int32_t kp_limb(int k, int i) {
+    int64_t c = 0;
+    int32_t out = 0;
+    for (int j = 0; j <= i; j++) {
+      const int64_t v = (int64_t)k * P::MOD[j] + c;
+      if (j < NL - 1) {
+        out = (int32_t)(v & MASK);
+        c = v >> 28;
+      } else {
+        out = (int32_t)v;
+      }
+    }
+    return out;
+  }
+
+  // canonical little-endian 32-bit words (plain integer < p) -> Montgomery limbs
+  ZK_HD static Fp28 from_canonical(const uint32_t* w) {
+    Fp28 a;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int bit = 28 * i;
+      const int wi = bit >> 5, sh = bit & 31;
+      uint64_t v = (wi < P::N32) ? w[wi] : 0u;
+      if (wi + 1 < P::N32) v |= (uint64_t)w[wi + 1] << 32;
+      a.l[i] = (int32_t)((v >> sh) & (uint32_t)MASK);
+    }
+    Fp28 r2;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r2.l[i] = P::R2[i];
+    return a * r2;
+  }
+  // Montgomery limbs -> canonical words in [0, p)
+  ZK_HD void to_canonical(uint32_t* w) const {
+    Fp28 o = zero();
+    o.l[0] = 1;
+    Fp28 c = (*this) * o;  // in [0, p]
+    bool is_p = true;
+#pragma unroll
+    for (int i = 0; i < NL; i++) is_p &= (c.l[i] == P::MOD[i]);
+#pragma unroll
+    for (int i = 0; i < P::N32; i++) w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint64_t v = is_p ? 0u : (uint64_t)(uint32_t)c.l[i];
+      const int bit = 28 * i;
+      const int wi = bit >> 5, sh = bit & 31;
+      const uint64_t s = v << sh;
+      if (wi < P::N32) w[wi] |= (uint32_t)s;
+      if (wi + 1 < P::N32) w[wi + 1] |= (uint32_t)(s >> 32);
+    }
+  }
+};
+
+using Fq28 = Fp28<Fq28Params>;
+using Fq2_28 = Fq2T<Fq28>;
+
+// conversions between the host/old representation (12x32, R = 2^384) and Fq28
+ZK_HD Fq28 fq28_from_fq(const Fq& a) {
+  Fq c = a.from_mont();
+  return Fq28::from_canonical(c.l);
+}
+ZK_HD Fq fq_from_fq28(const Fq28& a) {
+  Fq c;
+  a.to_canonical(c.l);
+  return c.to_mont();
+}
+ZK_HD Fq2_28 fq28_from_fq(const Fq2& a) { return {fq28_from_fq(a.c0), fq28_from_fq(a.c1)}; }
+ZK_HD Fq2 fq_from_fq28(const Fq2_28& a) { return {fq_from_fq28(a.c0), fq_from_fq28(a.c1)}; }
+
+}  // namespace zkmi

@@ -98,6 +98,9 @@ struct zkmi_pk {
   Fr* d_val[3] = {nullptr, nullptr, nullptr};
   G1Affine *a_query = nullptr, *b_g1_query = nullptr, *h_query = nullptr, *l_query = nullptr;  // l padded to n_vars
   G2Affine* b_g2_query = nullptr;
+  // the same queries in the device MSM representation (28-bit limbs)
+  Affine<Fq28>*a28 = nullptr, *b1_28 = nullptr, *h28 = nullptr, *l28 = nullptr;
+  Affine<Fq2_28>* b2_28 = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
   Fr *d_z = nullptr, *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
@@ -107,7 +110,7 @@ struct zkmi_pk {
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
-    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c};
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, a28, b1_28, h28, l28, b2_28};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
   }
@@ -138,6 +141,11 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->b_g2_query, sizeof(G2Affine) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->l_query, sizeof(G1Affine) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h_query, sizeof(G1Affine) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->a28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->b1_28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->b2_28, sizeof(Affine<Fq2_28>) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->l28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_z, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_zm, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_a, sizeof(Fr) * N)) != hipSuccess) return e;
@@ -148,6 +156,19 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = ctx->g1.reserve(cap)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap)) != hipSuccess) return e;
   return hipSuccess;
+}
+
+// queries are final in the host representation -> build the device MSM copies
+static hipError_t pk_convert_queries(zkmi_pk* pk) {
+  hipStream_t st = pk->ctx->stream;
+  const uint64_t N = 1ull << pk->log_n;
+  hipError_t e;
+  if ((e = bases_convert<Fq28>(pk->a_query, pk->a28, pk->n_vars, st)) != hipSuccess) return e;
+  if ((e = bases_convert<Fq28>(pk->b_g1_query, pk->b1_28, pk->n_vars, st)) != hipSuccess) return e;
+  if ((e = bases_convert<Fq2_28>(pk->b_g2_query, pk->b2_28, pk->n_vars, st)) != hipSuccess) return e;
+  if ((e = bases_convert<Fq28>(pk->l_query, pk->l28, pk->n_vars, st)) != hipSuccess) return e;
+  if ((e = bases_convert<Fq28>(pk->h_query, pk->h28, N, st)) != hipSuccess) return e;
+  return hipStreamSynchronize(st);
 }
 
 static Fr fr_from_u64(uint64_t v) {
@@ -279,6 +300,7 @@ int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t toxi
   if (e == hipSuccess) e = hipMemcpy(&pk->a0, pk->a_query, sizeof(G1Affine), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(&pk->b1_0, pk->b_g1_query, sizeof(G1Affine), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(&pk->b2_0, pk->b_g2_query, sizeof(G2Affine), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = pk_convert_queries(pk);
   if (t1) (void)hipFree(t1);
   if (t2) (void)hipFree(t2);
   if (e != hipSuccess) {
@@ -344,6 +366,7 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t alpha_g1[9
     pk->b2_0 = h2[0];
     e = hipMemcpy(pk->b_g2_query, h2.data(), sizeof(G2Affine) * nv, hipMemcpyHostToDevice);
   }
+  if (ok && e == hipSuccess) e = pk_convert_queries(pk);
   if (!ok || e != hipSuccess) {
     delete pk;
     return ok ? ctx->hip_fail(e, "pk upload") : ctx->fail(ZKMI_ERR_NON_CANONICAL, "proving key point invalid");
@@ -443,17 +466,17 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
   G1XYZZ acc_a, acc_b1, acc_l, acc_h;
   G2XYZZ acc_b2;
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_a, st));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b_g1_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_b1, st));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l_query + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_l, st));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b_g2_query + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
   ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &acc_b2, st));
   // H: h[0..N-1) against h_query
   ZK_HIP(ctx, ctx->sort.run(reinterpret_cast<const uint32_t*>(pk->d_a), N - 1, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h_query, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_h, st));
   // assembly
   uint32_t rk[8], sk[8], rsk[8];

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "curve.hpp"
+#include "field28.hpp"
 
 namespace zkmi {
 
@@ -59,12 +60,18 @@ struct MsmSort {
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
 };
 
+// device field F (lazily reduced 28-bit limbs) <-> host field (32-bit limbs)
+template <class F> struct HostFieldOf;
+template <> struct HostFieldOf<Fq28> { using type = Fq; };
+template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
+
 template <class F>
 struct MsmEngine {
+  using HF = typename HostFieldOf<F>::type;
   XYZZ<F>* buckets = nullptr;
   XYZZ<F>* segsum = nullptr;
   XYZZ<F>* segw = nullptr;
-  XYZZ<F>* partial = nullptr;
+  XYZZ<HF>* partial = nullptr;  // per-(window, job) sums, converted to the host representation
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }
   void release();
@@ -73,17 +80,21 @@ struct MsmEngine {
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, PhaseTimer* prof,
                         int ph_accum, int ph_reduce);
   // host part: fetch partials (synchronises the stream) and combine
-  hipError_t finish_host(const MsmSort& sort, XYZZ<F>* out, hipStream_t st);
+  hipError_t finish_host(const MsmSort& sort, XYZZ<HF>* out, hipStream_t st);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
-  hipError_t finish_host_windows(const MsmSort& sort, XYZZ<F>* out_windows, hipStream_t st);
+  hipError_t finish_host_windows(const MsmSort& sort, XYZZ<HF>* out_windows, hipStream_t st);
 };
 
+// host-format affine points (Montgomery, R = 2^384) -> device format (R = 2^392 limbs)
 template <class F>
-hipError_t bases_to_mont(Affine<F>* d_pts, uint64_t n, hipStream_t st);
+hipError_t bases_convert(const Affine<typename HostFieldOf<F>::type>* d_in, Affine<F>* d_out, uint64_t n, hipStream_t st);
 
-extern template struct MsmEngine<Fq>;
-extern template struct MsmEngine<Fq2>;
-extern template hipError_t bases_to_mont<Fq>(Affine<Fq>*, uint64_t, hipStream_t);
-extern template hipError_t bases_to_mont<Fq2>(Affine<Fq2>*, uint64_t, hipStream_t);
+template <class HF>
+XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c);
+
+extern template struct MsmEngine<Fq28>;
+extern template struct MsmEngine<Fq2_28>;
+extern template hipError_t bases_convert<Fq28>(const Affine<Fq>*, Affine<Fq28>*, uint64_t, hipStream_t);
+extern template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
 
 }  // namespace zkmi

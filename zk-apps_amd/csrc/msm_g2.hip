@@ -1,8 +1,10 @@
-// zkmi — G2 (F = Fq2) instantiation of the Pippenger MSM kernels (msm_impl.hpp).
-#define ZK_CALL_MUL 1
+// zkmi — G2 (F = Fq2 over Fq28 limbs) instantiation of the Pippenger MSM kernels (msm_impl.hpp).
+#ifndef ZK_G2_INLINE_MUL
+#define ZK_CALL_MUL28 1
+#endif
 #include "msm_impl.hpp"
 namespace zkmi {
-template struct MsmEngine<Fq2>;
-template hipError_t bases_to_mont<Fq2>(Affine<Fq2>*, uint64_t, hipStream_t);
+template struct MsmEngine<Fq2_28>;
+template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
 template XYZZ<Fq2> msm_combine_windows<Fq2>(const XYZZ<Fq2>*, int, int);
 }  // namespace zkmi

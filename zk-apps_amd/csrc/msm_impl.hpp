@@ -130,7 +130,7 @@ k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, X
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, uint32_t segs_per_win,
-          XYZZ<F>* __restrict__ partial) {
+          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const int job = blockIdx.x;
@@ -152,17 +152,22 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) store_vec(partial + (size_t)w * gridDim.x + job, acc);
+  if (threadIdx.x == 0) {
+    XYZZ<typename HostFieldOf<F>::type> o = {fq_from_fq28(acc.x), fq_from_fq28(acc.y), fq_from_fq28(acc.zz),
+                                             fq_from_fq28(acc.zzz)};
+    store_vec(partial + (size_t)w * gridDim.x + job, o);
+  }
 }
 
 template <class F>
-__global__ void k_bases_to_mont(Affine<F>* __restrict__ pts, uint32_t n) {
+__global__ void __launch_bounds__(256)
+k_bases_convert(const Affine<typename HostFieldOf<F>::type>* __restrict__ in, Affine<F>* __restrict__ out,
+                uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Affine<F> p = load_vec(pts + i);
-  p.x = p.x.to_mont();
-  p.y = p.y.to_mont();
-  store_vec(pts + i, p);
+  Affine<typename HostFieldOf<F>::type> p = load_vec(in + i);
+  Affine<F> q = {fq28_from_fq(p.x), fq28_from_fq(p.y)};  // (0,0) stays exactly (0,0)
+  store_vec(out + i, q);
 }
 
 // ---------------------------------------------------------------------------
@@ -174,7 +179,8 @@ void MsmEngine<F>::release() {
   if (segsum) (void)hipFree(segsum);
   if (segw) (void)hipFree(segw);
   if (partial) (void)hipFree(partial);
-  buckets = segsum = segw = partial = nullptr;
+  buckets = segsum = segw = nullptr;
+  partial = nullptr;
   cap_buckets = 0;
 }
 
@@ -189,7 +195,7 @@ hipError_t MsmEngine<F>::reserve(uint64_t n) {
   if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need)) != hipSuccess) return e;
   if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
-  if ((e = hipMalloc(&partial, sizeof(XYZZ<F>) * 64 * 32)) != hipSuccess) return e;
+  if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * 64 * 32)) != hipSuccess) return e;
   cap_buckets = need;
   return hipSuccess;
 }
@@ -223,16 +229,16 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
 }
 
 template <class F>
-hipError_t MsmEngine<F>::finish_host_windows(const MsmSort& sort, XYZZ<F>* out_windows, hipStream_t st) {
+hipError_t MsmEngine<F>::finish_host_windows(const MsmSort& sort, XYZZ<HF>* out_windows, hipStream_t st) {
   const MsmPlan& pl = sort.plan;
   const int seg_bits = msm_seg_bits(pl);
   const int njobs = 1 + seg_bits;
-  std::vector<XYZZ<F>> h((size_t)pl.nwin * njobs);
-  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(XYZZ<F>) * h.size(), hipMemcpyDeviceToHost, st);
+  std::vector<XYZZ<HF>> h((size_t)pl.nwin * njobs);
+  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(XYZZ<HF>) * h.size(), hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
   for (int w = 0; w < pl.nwin; w++) {
-    XYZZ<F> u = XYZZ<F>::infinity();
+    XYZZ<HF> u = XYZZ<HF>::infinity();
     for (int j = seg_bits - 1; j >= 0; j--) {
       u.dbl_inplace();
       u.add(h[(size_t)w * njobs + 1 + j]);
@@ -244,9 +250,9 @@ hipError_t MsmEngine<F>::finish_host_windows(const MsmSort& sort, XYZZ<F>* out_w
   return hipSuccess;
 }
 
-template <class F>
-XYZZ<F> msm_combine_windows(const XYZZ<F>* windows, int nwin, int c) {
-  XYZZ<F> total = XYZZ<F>::infinity();
+template <class HF>
+XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c) {
+  XYZZ<HF> total = XYZZ<HF>::infinity();
   for (int w = nwin - 1; w >= 0; w--) {
     for (int i = 0; i < c; i++) total.dbl_inplace();
     total.add(windows[w]);
@@ -255,8 +261,8 @@ XYZZ<F> msm_combine_windows(const XYZZ<F>* windows, int nwin, int c) {
 }
 
 template <class F>
-hipError_t MsmEngine<F>::finish_host(const MsmSort& sort, XYZZ<F>* out, hipStream_t st) {
-  std::vector<XYZZ<F>> win(sort.plan.nwin);
+hipError_t MsmEngine<F>::finish_host(const MsmSort& sort, XYZZ<HF>* out, hipStream_t st) {
+  std::vector<XYZZ<HF>> win(sort.plan.nwin);
   hipError_t e = finish_host_windows(sort, win.data(), st);
   if (e != hipSuccess) return e;
   *out = msm_combine_windows(win.data(), sort.plan.nwin, sort.plan.c);
@@ -264,8 +270,10 @@ hipError_t MsmEngine<F>::finish_host(const MsmSort& sort, XYZZ<F>* out, hipStrea
 }
 
 template <class F>
-hipError_t bases_to_mont(Affine<F>* d_pts, uint64_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_bases_to_mont<F>, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, (uint32_t)n);
+hipError_t bases_convert(const Affine<typename HostFieldOf<F>::type>* d_in, Affine<F>* d_out, uint64_t n,
+                         hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_bases_convert<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, d_out, (uint32_t)n);
   return hipGetLastError();
 }
 

@@ -1,0 +1,73 @@
+// zkmi — host-executed self-test of the device field representation
+// (field28.hpp is __host__ __device__): random chains of mul/sqr/add/sub/neg/dbl
+// in Fq28 limbs against the 32-bit-limb Fq, plus the zero test on k*p forms.
+#include "ctx.hpp"
+#include "field28.hpp"
+
+using namespace zkmi;
+
+namespace {
+struct Rng {
+  uint64_t s;
+  uint64_t next() {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  Fq fq() {
+    Fq a;
+    for (int i = 0; i < 12; i += 2) {
+      uint64_t v = next();
+      a.l[i] = (uint32_t)v;
+      a.l[i + 1] = (uint32_t)(v >> 32);
+    }
+    a.l[11] &= 0x0fffffffu;  // < 2^380 < p
+    return a;                // arbitrary residue, read as Montgomery form
+  }
+};
+}  // namespace
+
+extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
+  if (!out_mismatches) return ZKMI_ERR_BAD_ARG;
+  Rng rng{seed};
+  uint32_t bad = 0;
+  for (uint32_t it = 0; it < iters; it++) {
+    Fq a = rng.fq(), b = rng.fq(), c = rng.fq();
+    if (it % 7 == 0) b = a;
+    if (it % 11 == 0) c = Fq::zero();
+    if (it % 13 == 0) a = Fq::one();
+    Fq28 A = fq28_from_fq(a), B = fq28_from_fq(b), C = fq28_from_fq(c);
+    if (fq_from_fq28(A) != a) bad++;
+    // a chain shaped like the XYZZ mixed addition
+    Fq u2 = a * b, s2 = c * a.sqr();
+    Fq pp_ = u2 - c, r = s2 - b;
+    Fq pp = pp_.sqr(), ppp = pp_ * pp, q = c * pp;
+    Fq x3 = r.sqr() - ppp - q.dbl();
+    Fq y3 = r * (q - x3) - b * ppp;
+    Fq z3 = (a + b + c).neg().dbl() * x3;
+    Fq28 U2 = A * B, S2 = C * A.sqr();
+    Fq28 PP_ = U2 - C, R_ = S2 - B;
+    Fq28 PP = PP_.sqr(), PPP = PP_ * PP, Q = C * PP;
+    Fq28 X3 = R_.sqr() - PPP - Q.dbl();
+    Fq28 Y3 = R_ * (Q - X3) - B * PPP;
+    Fq28 Z3 = (A + B + C).neg().dbl() * X3;
+    if (fq_from_fq28(X3) != x3) bad++;
+    if (fq_from_fq28(Y3) != y3) bad++;
+    if (fq_from_fq28(Z3) != z3) bad++;
+    if (PP.is_zero() != pp.is_zero()) bad++;
+    // zero tests on products and Fq2-style combinations
+    Fq28 t0 = A * B, t1 = B * A;
+    if (!(t0 - t1).is_zero()) bad++;
+    if (!((A - A) * B).is_zero()) bad++;
+    if ((A * B).is_zero() != (a * b).is_zero()) bad++;
+    Fq28 zero_like = (t0 + t0) - t1 - t1;  // |v| < 4p
+    if (!zero_like.is_zero()) bad++;
+    if (!Fq28::zero().is_zero() || Fq28::one().is_zero()) bad++;
+    // lazy forms feeding a product
+    if (fq_from_fq28(A.add_lazy(B) * C.sub_lazy(A)) != (a + b) * (c - a)) bad++;
+  }
+  *out_mismatches = bad;
+  return ZKMI_OK;
+}
