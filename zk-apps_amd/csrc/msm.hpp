@@ -48,10 +48,11 @@ MsmPlan msm_make_plan_c(uint64_t n, int c);
 // Bucket scatter: signed-digit decomposition + counting sort of point indices
 // by (window, bucket).  Shared by every MSM over the same scalar vector.
 struct MsmSort {
-  uint32_t* counts = nullptr;  // nwin*nb+1 (exclusive offsets after run)
-  uint32_t* cursor = nullptr;
-  uint32_t* sorted = nullptr;  // nwin*n
-  uint64_t cap_entries = 0, cap_buckets = 0;
+  uint32_t* count = nullptr;      // nwin*nb   points per bucket
+  uint32_t* begin = nullptr;      // nwin*nb   first slot of the bucket in sorted[] (window w owns [w*n, (w+1)*n))
+  uint32_t* blockhist = nullptr;  // nwin*nch*nb  per-(window, chunk) tile histogram -> tile base slots
+  uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31
+  uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
   int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
   ~MsmSort() { release(); }

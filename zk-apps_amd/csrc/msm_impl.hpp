@@ -7,19 +7,20 @@
 // return; any correct bucket schedule is bit-exact after affine normalisation.
 //
 // HBM layout
-//   scalars : n x 32 B canonical little-endian integers < r (NOT Montgomery)
-//   bases   : n x Affine<F> in Montgomery form, (0,0) = infinity
-//   counts  : (nwin*nb + 1) x u32   bucket histogram -> exclusive offsets
-//   cursor  : nwin*nb x u32         scatter cursors
-//   sorted  : nwin*n x u32          point index | sign<<31, grouped by bucket
-//   buckets : nwin*nb x XYZZ<F>
+//   scalars   : n x 32 B canonical little-endian integers < r (NOT Montgomery)
+//   bases     : n x Affine<F>, F = 14 x 28-bit limbs (field28.hpp), (0,0) = infinity
+//   blockhist : nwin*nch*nb x u32  per-(window, chunk) tile histograms -> tile base slots
+//   count/begin : nwin*nb x u32    points per bucket / first slot in sorted[]
+//   sorted    : nwin*n x u32       point index | sign<<31, grouped by bucket
+//   buckets   : nwin*nb x XYZZ<F>
 //   segsum / segw : nwin*nb/SEG x XYZZ<F>
-//   partial : nwin*(1+log2(nb/SEG)) x XYZZ<F>   -> host
+//   partial   : nwin*(1+log2(nb/SEG)) x XYZZ<host field>   -> host
 //
 // Kernel chain (all on one stream):
-//   1 k_hist      thread/scalar : signed c-bit digits, histogram (u32 atomics)
-//   2 k_scan      exclusive prefix sum of the histogram
-//   3 k_scatter   thread/scalar : cursor = atomicAdd -> sorted[] (bucket scatter)
+//   1 k_bucket_pass<false>  (window, chunk) tile: carry-free signed digits, LDS histogram
+//                           (2^15 u32 counters = 128 KiB of the CU's 160 KiB LDS)
+//   2 k_bucket_totals / k_window_scan / k_bucket_bases   prefix sums -> slots
+//   3 k_bucket_pass<true>   same tiles: LDS cursors (ds_add_rtn) -> sorted[]   (bucket scatter)
 //   4 k_accum     thread/bucket : gather affine points, XYZZ mixed adds   <- dominant
 //   5 k_segreduce thread/16 buckets : running-sum  sum (i+1) B_i  and  sum B_i
 //   6 k_treesum   block/(window, job) : plain sums (LDS tree) of segw, and of
@@ -55,49 +56,14 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
-// signed-digit decomposition of a 256-bit little-endian scalar.
-// digit_w in [-(2^(c-1) - 1), 2^(c-1)]; returns |digit| (0 = skip) and sign.
-struct DigitIter {
-  uint32_t k[8];
-  uint32_t carry;
-  int c;
-  __device__ __forceinline__ void init(const uint32_t* s, int c_) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) k[i] = s[i];
-    carry = 0;
-    c = c_;
-  }
-  __device__ __forceinline__ uint32_t window_bits(int w) const {
-    const int bit = w * c;
-    const int limb = bit >> 5, sh = bit & 31;
-    if (limb >= 8) return 0;
-    uint64_t v = k[limb];
-    if (limb + 1 < 8) v |= (uint64_t)k[limb + 1] << 32;
-    return (uint32_t)(v >> sh) & ((1u << c) - 1u);
-  }
-  // returns magnitude in [0, 2^(c-1)], sets neg
-  __device__ __forceinline__ uint32_t next(int w, bool& neg) {
-    uint32_t d = window_bits(w) + carry;
-    const uint32_t halfv = 1u << (c - 1);
-    if (d > halfv) {
-      d = (1u << c) - d;
-      neg = true;
-      carry = 1;
-    } else {
-      neg = false;
-      carry = 0;
-    }
-    return d;
-  }
-};
-
 template <class F>
 __global__ void __launch_bounds__(256)
-k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ offsets,
-        const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets) {
+k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
+        const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
+        uint32_t total_buckets) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= total_buckets) return;
-  const uint32_t beg = offsets[b], end = offsets[b + 1];
+  const uint32_t beg = begin[b], end = beg + count[b];
   XYZZ<F> acc = XYZZ<F>::infinity();
   for (uint32_t j = beg; j < end; j++) {
     const uint32_t v = sorted[j];
@@ -214,8 +180,8 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
   if (prof) prof->begin(ph_accum, st);
-  hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.counts, sort.sorted,
-                     buckets, tot_b);
+  hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+                     sort.sorted, buckets, tot_b);
   if (prof) prof->end(ph_accum, st);
   if (prof) prof->begin(ph_reduce, st);
   const uint32_t segs_per_win = pl.nb / MSM_SEG;

@@ -7,79 +7,129 @@ namespace zkmi {
 
 namespace {
 
-__device__ __forceinline__ void load_scalar(const uint32_t* __restrict__ scalars, uint32_t i, uint32_t* k) {
+// Signed-digit recoding without a carry chain: with
+//   M = sum_w (2^(c-1) - 1) 2^(c w)
+// the unsigned base-2^c digits e_w of k' = k + M give d_w = e_w - (2^(c-1) - 1)
+// in [-(2^(c-1) - 1), 2^(c-1)], so any (scalar, window) digit is independent.
+struct RecodeConst {
+  uint32_t m[9];
+};
+
+__device__ __forceinline__ void load_biased(const uint32_t* __restrict__ scalars, uint32_t i, const RecodeConst& rc,
+                                            uint32_t* k) {
   const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 a = q[0], b = q[1];
-  k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w;
-  k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  const uint4 a = q[0], b = q[1];
+  const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint64_t v = (uint64_t)s[j] + rc.m[j] + carry;
+    k[j] = (uint32_t)v;
+    carry = v >> 32;
+  }
+  k[8] = rc.m[8] + (uint32_t)carry;
 }
 
-}  // namespace
+// returns bucket index + 1 (0 = skip) and the sign
+__device__ __forceinline__ uint32_t digit_of(const uint32_t* k, int w, int c, bool& neg) {
+  const int bit = w * c;
+  const int limb = bit >> 5, sh = bit & 31;
+  uint64_t v = k[limb];
+  if (limb + 1 < 9) v |= (uint64_t)k[limb + 1] << 32;
+  const int32_t e = (int32_t)((uint32_t)(v >> sh) & ((1u << c) - 1u));
+  const int32_t d = e - (int32_t)((1u << (c - 1)) - 1u);
+  neg = d < 0;
+  return (uint32_t)(neg ? -d : d);
+}
 
-__global__ void __launch_bounds__(256)
-k_hist(const uint32_t* __restrict__ scalars, uint32_t n, int c, int nwin, uint32_t nb,
-       uint32_t* __restrict__ counts) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k[8];
-  load_scalar(scalars, i, k);
-  DigitIter it;
-  it.init(k, c);
-  for (int w = 0; w < nwin; w++) {
+// Pass 1 (SCATTER = false): LDS histogram of one (window, chunk) tile -> blockhist.
+// Pass 3 (SCATTER = true):  blockhist holds the tile's first output slot per
+// bucket; LDS cursors hand out slots (ds_add_rtn), point ids go to sorted[].
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024)
+k_bucket_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, uint32_t nb, uint32_t chunk, RecodeConst rc,
+              uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  uint32_t* gh = blockhist + ((size_t)w * nch + ch) * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
+  __syncthreads();
+  const uint32_t beg = ch * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    uint32_t k[9];
+    load_biased(scalars, i, rc, k);
     bool neg;
-    uint32_t d = it.next(w, neg);
-    if (d) atomicAdd(&counts[(uint32_t)w * nb + (d - 1)], 1u);
+    const uint32_t d = digit_of(k, (int)w, c, neg);
+    if (d) {
+      if (SCATTER) {
+        const uint32_t pos = atomicAdd(&hist[d - 1], 1u);
+        sorted[pos] = i | (neg ? 0x80000000u : 0u);
+      } else {
+        atomicAdd(&hist[d - 1], 1u);
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) gh[b] = hist[b];
   }
 }
 
-// single-workgroup exclusive scan of counts[0..total) (in place); counts[total]
-// receives the grand total; cursor = copy of the offsets.
+// Pass 2a: per (window, bucket) exclusive prefix over the chunks (in place) and the bucket total.
+__global__ void __launch_bounds__(256)
+k_bucket_totals(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ count, uint32_t nb, uint32_t nch,
+                uint32_t total_buckets) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_buckets) return;
+  const uint32_t w = g / nb, b = g - w * nb;
+  uint32_t run = 0;
+  for (uint32_t ch = 0; ch < nch; ch++) {
+    uint32_t* p = blockhist + ((size_t)w * nch + ch) * nb + b;
+    const uint32_t v = *p;
+    *p = run;
+    run += v;
+  }
+  count[g] = run;
+}
+
+// Pass 2b: one workgroup per window: begin[w][b] = w*n + exclusive prefix of count[w][*].
 __global__ void __launch_bounds__(1024)
-k_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, uint32_t total) {
+k_window_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t nb, uint32_t n) {
   __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t per = (total + 1023u) / 1024u;
-  const uint32_t beg = tid * per;
-  const uint32_t end = (beg + per < total) ? beg + per : total;
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  const uint32_t per = (nb + 1023u) / 1024u;
+  const uint32_t b0 = tid * per;
+  const uint32_t b1 = (b0 + per < nb) ? b0 + per : nb;
   uint32_t s = 0;
-  for (uint32_t i = beg; i < end; i++) s += counts[i];
+  for (uint32_t b = b0; b < b1; b++) s += count[w * nb + b];
   part[tid] = s;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = (tid == 0) ? 0u : part[tid - 1];
-  for (uint32_t i = beg; i < end; i++) {
-    uint32_t v = counts[i];
-    counts[i] = run;
-    cursor[i] = run;
-    run += v;
+  uint32_t run = w * n + ((tid == 0) ? 0u : part[tid - 1]);
+  for (uint32_t b = b0; b < b1; b++) {
+    begin[w * nb + b] = run;
+    run += count[w * nb + b];
   }
-  if (tid == 1023) counts[total] = part[1023];
 }
 
+// Pass 2c: tile bases = bucket begin + prefix over chunks.
 __global__ void __launch_bounds__(256)
-k_scatter(const uint32_t* __restrict__ scalars, uint32_t n, int c, int nwin, uint32_t nb,
-          uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k[8];
-  load_scalar(scalars, i, k);
-  DigitIter it;
-  it.init(k, c);
-  for (int w = 0; w < nwin; w++) {
-    bool neg;
-    uint32_t d = it.next(w, neg);
-    if (d) {
-      uint32_t pos = atomicAdd(&cursor[(uint32_t)w * nb + (d - 1)], 1u);
-      sorted[pos] = i | (neg ? 0x80000000u : 0u);
-    }
-  }
+k_bucket_bases(uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ begin, uint32_t nb, uint32_t nch,
+               uint32_t total) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t b = g % nb;
+  const uint32_t w = g / (nb * nch);
+  blockhist[g] += begin[w * nb + b];
 }
+
+}  // namespace
 
 // ---------------------------------------------------------------------------
 static int pick_window(uint64_t n) {
@@ -89,8 +139,7 @@ static int pick_window(uint64_t n) {
   if (n <= (1u << 11)) return 8;
   if (n <= (1u << 14)) return 10;
   if (n <= (1u << 17)) return 13;
-  if (n <= (1u << 22)) return 16;
-  return 17;
+  return 16;  // 2^15 buckets = 128 KiB of LDS counters per (window, chunk) tile
 }
 
 MsmPlan msm_make_plan_c(uint64_t n, int c) {
@@ -103,7 +152,7 @@ MsmPlan msm_make_plan_c(uint64_t n, int c) {
 }
 MsmPlan msm_make_plan(uint64_t n) { return msm_make_plan_c(n, pick_window(n)); }
 
-static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, 1u << 22, ~0ull};
+static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
 uint64_t msm_max_buckets(uint64_t n) {
   uint64_t best = 0;
@@ -129,43 +178,96 @@ static uint64_t msm_max_entries(uint64_t n) {
   return best;
 }
 
+static uint32_t pick_chunks(const MsmPlan& p) {
+  uint32_t nch = (256 + p.nwin - 1) / p.nwin;  // ~1 tile per CU
+  const uint64_t max_by_n = (p.n + 1023) / 1024;
+  if (nch > max_by_n) nch = (uint32_t)(max_by_n ? max_by_n : 1);
+  return nch ? nch : 1;
+}
+
+static uint64_t msm_max_hist(uint64_t n) {
+  uint64_t best = 0;
+  for (uint64_t step : PLAN_STEPS) {
+    uint64_t m = step < n ? step : n;
+    MsmPlan p = msm_make_plan(m);
+    uint64_t v = (uint64_t)p.nwin * p.nb * pick_chunks(p);
+    if (v > best) best = v;
+    if (step >= n) break;
+  }
+  // a forced window width (multi-GPU split) can pair the largest bucket count with any n
+  MsmPlan q = msm_make_plan_c(n, 16);
+  uint64_t v = (uint64_t)q.nwin * q.nb * pick_chunks(q);
+  return v > best ? v : best;
+}
+
 void MsmSort::release() {
-  if (counts) (void)hipFree(counts);
-  if (cursor) (void)hipFree(cursor);
+  if (count) (void)hipFree(count);
+  if (begin) (void)hipFree(begin);
+  if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  counts = cursor = sorted = nullptr;
-  cap_entries = cap_buckets = 0;
+  count = begin = blockhist = sorted = nullptr;
+  cap_entries = cap_buckets = cap_hist = 0;
 }
 
 hipError_t MsmSort::reserve(uint64_t n) {
-  const uint64_t ne = msm_max_entries(n), nbk = msm_max_buckets(n);
-  if (ne <= cap_entries && nbk <= cap_buckets) return hipSuccess;
+  uint64_t ne = msm_max_entries(n), nbk = msm_max_buckets(n), nh = msm_max_hist(n);
+  const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);
+  if (nbk < forced) nbk = forced;  // allow plan_override = 16 for any n
+  if (16 * n > ne) ne = 16 * n;
+  if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
   release();
   hipError_t e;
-  if ((e = hipMalloc(&counts, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;
-  if ((e = hipMalloc(&cursor, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&count, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * nh)) != hipSuccess) return e;
   if ((e = hipMalloc(&sorted, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
   cap_entries = ne;
   cap_buckets = nbk;
+  cap_hist = nh;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   return hipSuccess;
 }
 
 hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
   plan = plan_override ? msm_make_plan_c(n, plan_override) : msm_make_plan(n);
-  const uint32_t tot_b = plan.nwin * plan.nb;
-  hipError_t e;
-  if ((e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (tot_b + 1), st)) != hipSuccess) return e;
-  const int T = 256;
+  const uint32_t nb = plan.nb, nwin = (uint32_t)plan.nwin;
+  const uint32_t tot_b = nwin * nb;
+  const uint32_t nch = pick_chunks(plan);
+  const uint32_t chunk = (uint32_t)((n + nch - 1) / nch);
+  // M = sum_w (2^(c-1) - 1) 2^(c w), 9 limbs
+  RecodeConst rc;
+  for (int j = 0; j < 9; j++) rc.m[j] = 0;
+  for (uint32_t w = 0; w < nwin; w++) {
+    const uint64_t v = (1ull << (plan.c - 1)) - 1;
+    const int bit = (int)w * plan.c, limb = bit >> 5, sh = bit & 31;
+    if (limb < 9) {
+      const uint64_t lo = v << sh;  // c <= 16, sh <= 31: fits 64 bits
+      uint64_t carry = lo;
+      for (int j = limb; j < 9 && carry; j++) {
+        const uint64_t sum = (uint64_t)rc.m[j] + (uint32_t)carry;
+        rc.m[j] = (uint32_t)sum;
+        carry = (carry >> 32) + (sum >> 32);
+      }
+    }
+  }
   if (prof) prof->begin(PH_MSM_SORT, st);
-  if (n) {
-    hipLaunchKernelGGL(k_hist, dim3((n + T - 1) / T), dim3(T), 0, st, d_scalars, (uint32_t)n, plan.c, plan.nwin,
-                       plan.nb, counts);
-  }
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, counts, cursor, tot_b);
-  if (n) {
-    hipLaunchKernelGGL(k_scatter, dim3((n + T - 1) / T), dim3(T), 0, st, d_scalars, (uint32_t)n, plan.c, plan.nwin,
-                       plan.nb, cursor, sorted);
-  }
+  const size_t lds = sizeof(uint32_t) * nb;
+  const dim3 grid(nch, nwin);
+  hipLaunchKernelGGL(k_bucket_pass<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
+                     blockhist, sorted);
+  hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
+  hipLaunchKernelGGL(k_window_scan, dim3(nwin), dim3(1024), 0, st, count, begin, nb, (uint32_t)n);
+  const uint32_t tot_h = tot_b * nch;
+  hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
+  hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
+                     blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
