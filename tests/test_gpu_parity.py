@@ -125,6 +125,37 @@ def test_msm_g1_structured_vs_closed_form(ctx, n):
     b.free()
 
 
+@pytest.mark.parametrize("n", [5000, 70000])
+def test_msm_g1_witness_like_heavy_buckets(ctx, n):
+    """Witness-like scalars: 40 % zero, 20 % one, 10 % < 2^16,
+    one value repeated in 10 %, rest uniform — drives single buckets far above
+    the mean load (the workgroup-per-heavy-bucket path)."""
+    rng = ec.SplitMix64(31 * n)
+    rep = rng.fr()
+    s = []
+    for _ in range(n):
+        t = rng.next() % 10
+        s.append(0 if t < 4 else 1 if t < 6 else (rng.next() & 0xFFFF) if t < 7 else rep if t < 8 else rng.fr())
+    b = ctx.bases_g1_synthetic(n)
+    got = ctx.msm_g1(frs(s), b)
+    q = ec.g1_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq, ec.g1_mul(sum(s) % R), ec.g1_mul(sum(i * v for i, v in enumerate(s)) % R, q))
+    assert got == ec.g1_to_bytes(exp)
+    b.free()
+
+
+def test_msm_g1_all_scalars_equal(ctx):
+    """Every point lands in the same bucket of every window."""
+    n = 4096
+    k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF
+    b = ctx.bases_g1_synthetic(n)
+    got = ctx.msm_g1(ec.fr_to_bytes(k) * n, b)
+    q = ec.g1_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq, ec.g1_mul(n * k % R), ec.g1_mul(k * (n * (n - 1) // 2) % R, q))
+    assert got == ec.g1_to_bytes(exp)
+    b.free()
+
+
 @pytest.mark.parametrize("n", [300, 5000])
 def test_msm_g2_structured_vs_closed_form(ctx, n):
     rng = ec.SplitMix64(7 * n)

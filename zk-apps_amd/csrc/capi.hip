@@ -259,7 +259,7 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   G1XYZZ res;
-  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &res, ctx->stream));
+  ZK_HIP(ctx, ctx->g1.finish_host(&res));
   g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }
@@ -272,7 +272,7 @@ int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
   ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
   G2XYZZ res;
-  ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &res, ctx->stream));
+  ZK_HIP(ctx, ctx->g2.finish_host(&res));
   g2_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }
@@ -315,7 +315,7 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
   if (e != hipSuccess) return ctx->hip_fail(e, "sort");
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   std::vector<G1XYZZ> win(ctx->sort.plan.nwin);
-  ZK_HIP(ctx, ctx->g1.finish_host_windows(ctx->sort, win.data(), ctx->stream));
+  ZK_HIP(ctx, ctx->g1.finish_host_windows(win.data()));
   for (int w = 0; w < ctx->sort.plan.nwin; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);
   *out_nwin = (uint32_t)ctx->sort.plan.nwin;
   *out_window_bits = (uint32_t)ctx->sort.plan.c;

@@ -288,6 +288,20 @@ struct Fp {
 using Fr = Fp<FrParams>;
 using Fq = Fp<FqParams>;
 
+// Fq2 product/square components; the device limb representation overloads these
+// (field28.hpp) to sum partial products in the column accumulators and pay one
+// Montgomery reduction per component instead of one per base-field product.
+template <class B>
+ZK_HD B fq2_mul_c0(const B& a0, const B& a1, const B& b0, const B& b1) { return a0 * b0 - a1 * b1; }
+template <class B>
+ZK_HD B fq2_mul_c1(const B& a0, const B& a1, const B& b0, const B& b1) {
+  return (a0 + a1) * (b0 + b1) - a0 * b0 - a1 * b1;
+}
+template <class B>
+ZK_HD B fq2_sqr_c0(const B& a0, const B& a1) { return (a0 + a1) * (a0 - a1); }
+template <class B>
+ZK_HD B fq2_sqr_c1(const B& a0, const B& a1) { return (a0 * a1).dbl(); }
+
 // Fq2 = Fq[u]/(u^2+1), generic over the base-field representation
 template <class B>
 struct Fq2T {
@@ -302,17 +316,9 @@ struct Fq2T {
   ZK_HD Fq2T neg() const { return {c0.neg(), c1.neg()}; }
   ZK_HD Fq2T dbl() const { return {c0.dbl(), c1.dbl()}; }
   ZK_HD friend Fq2T operator*(const Fq2T& a, const Fq2T& b) {
-    B t0 = a.c0 * b.c0;
-    B t1 = a.c1 * b.c1;
-    B t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
-    return {t0 - t1, t2 - t0 - t1};
+    return {fq2_mul_c0(a.c0, a.c1, b.c0, b.c1), fq2_mul_c1(a.c0, a.c1, b.c0, b.c1)};
   }
-  ZK_HD Fq2T sqr() const {
-    B s = c0 + c1;
-    B d = c0 - c1;
-    B m = c0 * c1;
-    return {s * d, m.dbl()};
-  }
+  ZK_HD Fq2T sqr() const { return {fq2_sqr_c0(c0, c1), fq2_sqr_c1(c0, c1)}; }
   ZK_HD Fq2T mul_fq(const B& k) const { return {c0 * k, c1 * k}; }
   ZK_HD Fq2T conj() const { return {c0, c1.neg()}; }
   // multiply by xi = 1 + u

@@ -242,6 +242,46 @@ struct Fp28 {
 };
 
 using Fq28 = Fp28<Fq28Params>;
+
+// ---- Fq2 components with lazy reduction (overloads of field.hpp's generic forms) ----
+// a0 b0 + s a1 b1 summed in the 64-bit columns: 28 products of < 2^56 plus the
+// reduction's 14 stay below 2^62; one reduction for the pair.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CALL_MUL28)
+#define ZK_FQ2_28 __device__ __attribute__((noinline))
+#else
+#define ZK_FQ2_28 ZK_HD
+#endif
+ZK_FQ2_28 Fq28 fq2_mul_c0(const Fq28& a0, const Fq28& a1, const Fq28& b0, const Fq28& b1) {
+  constexpr int NL = Fq28::NL;
+  int64_t T[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int32_t n1 = -a1.l[i];
+#pragma unroll
+    for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a0.l[i] * b0.l[j] + (int64_t)n1 * b1.l[j];
+  }
+  return Fq28::reduce(T);
+}
+ZK_FQ2_28 Fq28 fq2_mul_c1(const Fq28& a0, const Fq28& a1, const Fq28& b0, const Fq28& b1) {
+  constexpr int NL = Fq28::NL;
+  int64_t T[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++)
+#pragma unroll
+    for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a0.l[i] * b1.l[j] + (int64_t)a1.l[i] * b0.l[j];
+  return Fq28::reduce(T);
+}
+ZK_FQ2_28 Fq28 fq2_sqr_c0(const Fq28& a0, const Fq28& a1) {
+  return Fq28::mul_inline(a0.add_lazy(a1), a0.sub_lazy(a1));  // operands < 2^29 per limb
+}
+ZK_FQ2_28 Fq28 fq2_sqr_c1(const Fq28& a0, const Fq28& a1) {
+  return Fq28::mul_inline(a0.add_lazy(a0), a1);
+}
+
 using Fq2_28 = Fq2T<Fq28>;
 
 // conversions between the host/old representation (12x32, R = 2^384) and Fq28

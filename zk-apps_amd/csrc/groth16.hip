@@ -466,18 +466,21 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
   G1XYZZ acc_a, acc_b1, acc_l, acc_h;
   G2XYZZ acc_b2;
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
-  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_a, st));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
-  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_b1, st));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
-  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_l, st));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
-  ZK_HIP(ctx, ctx->g2.finish_host(ctx->sort, &acc_b2, st));
-  // H: h[0..N-1) against h_query
+  // every MSM's device work is queued back to back; each leaves its per-window
+  // partials in a pinned host slot + an event, and the CPU combines them while
+  // the GPU is already busy with the next MSM
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 0));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, 0));
+  // H: h[0..N-1) against h_query (re-uses the sort buffers: stream order keeps it behind the four above)
   ZK_HIP(ctx, ctx->sort.run(reinterpret_cast<const uint32_t*>(pk->d_a), N - 1, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
-  ZK_HIP(ctx, ctx->g1.finish_host(ctx->sort, &acc_h, st));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 3));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_a, 0));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1, 1));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_l, 2));
+  ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2, 0));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_h, 3));
   // assembly
   uint32_t rk[8], sk[8], rsk[8];
   memcpy(rk, r_bytes, 32);

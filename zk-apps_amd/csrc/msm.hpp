@@ -51,6 +51,8 @@ struct MsmSort {
   uint32_t* count = nullptr;      // nwin*nb   points per bucket
   uint32_t* begin = nullptr;      // nwin*nb   first slot of the bucket in sorted[] (window w owns [w*n, (w+1)*n))
   uint32_t* blockhist = nullptr;  // nwin*nch*nb  per-(window, chunk) tile histogram -> tile base slots
+  uint32_t* perm = nullptr;       // nwin*nb   bucket ids ordered by descending load (per window)
+  uint32_t* heavy = nullptr;      // [0] = number of heavy buckets, [1..] their ids
   uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
@@ -69,21 +71,28 @@ template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
 template <class F>
 struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
+  enum { SLOTS = 4, SLOT_PTS = 64 * 32 };
   XYZZ<F>* buckets = nullptr;
   XYZZ<F>* segsum = nullptr;
   XYZZ<F>* segw = nullptr;
-  XYZZ<HF>* partial = nullptr;  // per-(window, job) sums, converted to the host representation
+  // per-(window, job) sums converted to the host representation; several MSMs can be
+  // in flight on the stream, each with its own slot, pinned host copy and event
+  XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS
+  XYZZ<HF>* h_partial = nullptr;  // pinned host, SLOTS x SLOT_PTS
+  hipEvent_t done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }
   void release();
   hipError_t reserve(uint64_t n);
-  // device part: bucket accumulation + reduction down to per-window partials
+  // device part: bucket accumulation + reduction down to per-window partials,
+  // async copy of the partials to the host and an event; does not block
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, PhaseTimer* prof,
-                        int ph_accum, int ph_reduce);
-  // host part: fetch partials (synchronises the stream) and combine
-  hipError_t finish_host(const MsmSort& sort, XYZZ<HF>* out, hipStream_t st);
+                        int ph_accum, int ph_reduce, int slot = 0);
+  // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
+  hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
-  hipError_t finish_host_windows(const MsmSort& sort, XYZZ<HF>* out_windows, hipStream_t st);
+  hipError_t finish_host_windows(XYZZ<HF>* out_windows, int slot = 0);
 };
 
 // host-format affine points (Montgomery, R = 2^384) -> device format (R = 2^392 limbs)

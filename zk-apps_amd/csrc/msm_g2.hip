@@ -1,7 +1,6 @@
 // zkmi — G2 (F = Fq2 over Fq28 limbs) instantiation of the Pippenger MSM kernels (msm_impl.hpp).
-#ifndef ZK_G2_INLINE_MUL
-#define ZK_CALL_MUL28 1
-#endif
+// Fully inlined field products: measured 12.5 ms vs 21 ms (out-of-line calls spill the
+// operands to scratch) for the 2^20 accumulate; define ZK_CALL_MUL28 to get the call form.
 #include "msm_impl.hpp"
 namespace zkmi {
 template struct MsmEngine<Fq2_28>;

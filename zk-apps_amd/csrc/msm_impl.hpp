@@ -35,7 +35,8 @@ namespace zkmi {
 
 constexpr int MSM_SEG = 16;  // buckets per segment in k_segreduce
 constexpr int MSM_SEG_LOG = 4;
-constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 48 KiB LDS
+constexpr int MSM_TREE_T = 128;
+constexpr uint32_t MSM_HEAVY = 256;  // buckets above this load are reduced by a whole workgroup  // k_treesum block: 128 x XYZZ<Fq2> = 48 KiB LDS
 
 template <class T>
 __device__ __forceinline__ T load_vec(const T* p) {
@@ -59,11 +60,14 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
 template <class F>
 __global__ void __launch_bounds__(256)
 k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
-        const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
-        uint32_t total_buckets) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= total_buckets) return;
-  const uint32_t beg = begin[b], end = beg + count[b];
+        const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
+        const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_buckets) return;
+  const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
+  const uint32_t cnt = count[b];
+  if (cnt > MSM_HEAVY) return;  // k_accum_heavy owns it
+  const uint32_t beg = begin[b], end = beg + cnt;
   XYZZ<F> acc = XYZZ<F>::infinity();
   for (uint32_t j = beg; j < end; j++) {
     const uint32_t v = sorted[j];
@@ -72,6 +76,39 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
     acc.madd(p);
   }
   store_vec(buckets + b, acc);
+}
+
+// one workgroup per heavy bucket: strided partial sums, then an LDS tree
+template <class F>
+__global__ void __launch_bounds__(MSM_TREE_T)
+k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
+              const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
+              const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
+  const uint32_t n_heavy = heavy[0];
+  for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    const uint32_t b = heavy[1 + h];
+    const uint32_t beg = begin[b], end = beg + count[b];
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
+      const uint32_t v = sorted[j];
+      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        acc.add(sh[threadIdx.x + s]);
+        sh[threadIdx.x] = acc;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) store_vec(buckets + b, acc);
+    __syncthreads();
+  }
 }
 
 // thread t handles buckets [t*SEG, (t+1)*SEG) of one window (global segment id)
@@ -145,8 +182,14 @@ void MsmEngine<F>::release() {
   if (segsum) (void)hipFree(segsum);
   if (segw) (void)hipFree(segw);
   if (partial) (void)hipFree(partial);
+  if (h_partial) (void)hipHostFree(h_partial);
+  for (int i = 0; i < SLOTS; i++)
+    if (done[i]) {
+      (void)hipEventDestroy(done[i]);
+      done[i] = nullptr;
+    }
   buckets = segsum = segw = nullptr;
-  partial = nullptr;
+  partial = h_partial = nullptr;
   cap_buckets = 0;
 }
 
@@ -154,14 +197,19 @@ uint64_t msm_max_buckets(uint64_t n);
 
 template <class F>
 hipError_t MsmEngine<F>::reserve(uint64_t n) {
-  const uint64_t need = msm_max_buckets(n);
+  uint64_t need = msm_max_buckets(n);
+  const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);  // plan_override = 16 for any n
+  if (need < forced) need = forced;
   if (need <= cap_buckets) return hipSuccess;
   release();
   hipError_t e;
   if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need)) != hipSuccess) return e;
   if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
-  if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * 64 * 32)) != hipSuccess) return e;
+  if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
+  for (int i = 0; i < SLOTS; i++)
+    if ((e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming)) != hipSuccess) return e;
   cap_buckets = need;
   return hipSuccess;
 }
@@ -175,34 +223,41 @@ static inline int msm_seg_bits(const MsmPlan& pl) {
 
 template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
-                                    PhaseTimer* prof, int ph_accum, int ph_reduce) {
+                                    PhaseTimer* prof, int ph_accum, int ph_reduce, int slot) {
   const MsmPlan& pl = sort.plan;
+  slot_plan[slot] = pl;
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
   if (prof) prof->begin(ph_accum, st);
   hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                     sort.sorted, buckets, tot_b);
+                     sort.perm, sort.sorted, buckets, tot_b);
+  hipLaunchKernelGGL(k_accum_heavy<F>, dim3(512), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
+                     sort.begin, sort.count, sort.heavy, sort.sorted, buckets);
   if (prof) prof->end(ph_accum, st);
   if (prof) prof->begin(ph_reduce, st);
   const uint32_t segs_per_win = pl.nb / MSM_SEG;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
   hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st, buckets, segsum, segw, tot_segs);
   const int njobs = 1 + msm_seg_bits(pl);
+  XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
   hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, segsum,
-                     segw, segs_per_win, partial);
+                     segw, segs_per_win, dp);
   if (prof) prof->end(ph_reduce, st);
+  hipError_t e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
+                                hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  if ((e = hipEventRecord(done[slot], st)) != hipSuccess) return e;
   return hipGetLastError();
 }
 
 template <class F>
-hipError_t MsmEngine<F>::finish_host_windows(const MsmSort& sort, XYZZ<HF>* out_windows, hipStream_t st) {
-  const MsmPlan& pl = sort.plan;
+hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
+  const MsmPlan& pl = slot_plan[slot];
   const int seg_bits = msm_seg_bits(pl);
   const int njobs = 1 + seg_bits;
-  std::vector<XYZZ<HF>> h((size_t)pl.nwin * njobs);
-  hipError_t e = hipMemcpyAsync(h.data(), partial, sizeof(XYZZ<HF>) * h.size(), hipMemcpyDeviceToHost, st);
+  hipError_t e = hipEventSynchronize(done[slot]);
   if (e != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
   for (int w = 0; w < pl.nwin; w++) {
     XYZZ<HF> u = XYZZ<HF>::infinity();
     for (int j = seg_bits - 1; j >= 0; j--) {
@@ -227,11 +282,11 @@ XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c) {
 }
 
 template <class F>
-hipError_t MsmEngine<F>::finish_host(const MsmSort& sort, XYZZ<HF>* out, hipStream_t st) {
-  std::vector<XYZZ<HF>> win(sort.plan.nwin);
-  hipError_t e = finish_host_windows(sort, win.data(), st);
+hipError_t MsmEngine<F>::finish_host(XYZZ<HF>* out, int slot) {
+  std::vector<XYZZ<HF>> win(slot_plan[slot].nwin);
+  hipError_t e = finish_host_windows(win.data(), slot);
   if (e != hipSuccess) return e;
-  *out = msm_combine_windows(win.data(), sort.plan.nwin, sort.plan.c);
+  *out = msm_combine_windows(win.data(), slot_plan[slot].nwin, slot_plan[slot].c);
   return hipSuccess;
 }
 

@@ -129,6 +129,44 @@ k_bucket_bases(uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ be
   blockhist[g] += begin[w * nb + b];
 }
 
+// Pass 2d: one workgroup per window orders its buckets by descending load so that
+// the 64 lanes of a wave in k_accum own buckets of (nearly) equal size (a
+// thread-per-bucket loop otherwise runs at the pace of the fullest bucket:
+// Poisson(32) loads give ~65 % lane utilisation).  Buckets above MSM_HEAVY
+// points (repeated scalars: booleans, small values) go to a separate list that
+// k_accum_heavy reduces with a whole workgroup each.
+__global__ void __launch_bounds__(1024)
+k_bucket_order(const uint32_t* __restrict__ count, uint32_t* __restrict__ perm, uint32_t* __restrict__ heavy,
+               uint32_t* __restrict__ n_heavy, uint32_t nb) {
+  __shared__ uint32_t bins[MSM_HEAVY + 2];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t i = tid; i < MSM_HEAVY + 2; i += 1024) bins[i] = 0;
+  __syncthreads();
+  // key: 0 = heaviest light bucket ... MSM_HEAVY = empty; heavy buckets sort last (key MSM_HEAVY + 1)
+  for (uint32_t b = tid; b < nb; b += 1024) {
+    const uint32_t cnt = count[w * nb + b];
+    const uint32_t key = cnt > MSM_HEAVY ? MSM_HEAVY + 1 : MSM_HEAVY - cnt;
+    atomicAdd(&bins[key], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < MSM_HEAVY + 2; i++) {
+      const uint32_t v = bins[i];
+      bins[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < nb; b += 1024) {
+    const uint32_t cnt = count[w * nb + b];
+    const uint32_t key = cnt > MSM_HEAVY ? MSM_HEAVY + 1 : MSM_HEAVY - cnt;
+    const uint32_t pos = atomicAdd(&bins[key], 1u);
+    perm[w * nb + pos] = w * nb + b;
+    if (cnt > MSM_HEAVY) heavy[atomicAdd(n_heavy, 1u)] = w * nb + b;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -202,10 +240,12 @@ static uint64_t msm_max_hist(uint64_t n) {
 
 void MsmSort::release() {
   if (count) (void)hipFree(count);
+  if (perm) (void)hipFree(perm);
+  if (heavy) (void)hipFree(heavy);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
 }
 
@@ -219,6 +259,8 @@ hipError_t MsmSort::reserve(uint64_t n) {
   hipError_t e;
   if ((e = hipMalloc(&count, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
   if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * nh)) != hipSuccess) return e;
   if ((e = hipMalloc(&sorted, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
   cap_entries = ne;
@@ -266,6 +308,9 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   hipLaunchKernelGGL(k_window_scan, dim3(nwin), dim3(1024), 0, st, count, begin, nb, (uint32_t)n);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
+  hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
+  if (e0 != hipSuccess) return e0;
+  hipLaunchKernelGGL(k_bucket_order, dim3(nwin), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb);
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);

@@ -65,6 +65,18 @@ extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* o
     Fq28 zero_like = (t0 + t0) - t1 - t1;  // |v| < 4p
     if (!zero_like.is_zero()) bad++;
     if (!Fq28::zero().is_zero() || Fq28::one().is_zero()) bad++;
+    // Fq2 over the limb representation (lazy-reduction product/square)
+    {
+      Fq2 x = {a, b}, y = {c, a * b};
+      Fq2_28 X = {A, B}, Y = {C, A * B};
+      Fq2 m = x * y, q2 = x.sqr(), chain = (m - q2) * x + y.dbl();
+      Fq2_28 M = X * Y, Q2 = X.sqr(), CH = (M - Q2) * X + Y.dbl();
+      if (fq_from_fq28(M) != m) bad++;
+      if (fq_from_fq28(Q2) != q2) bad++;
+      if (fq_from_fq28(CH) != chain) bad++;
+      if (!(X * Y - Y * X).is_zero()) bad++;
+      if ((X * Y).is_zero() != m.is_zero()) bad++;
+    }
     // lazy forms feeding a product
     if (fq_from_fq28(A.add_lazy(B) * C.sub_lazy(A)) != (a + b) * (c - a)) bad++;
   }
