@@ -181,6 +181,11 @@ int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, c
  * elements are trusted to be < r) — the entry point bench.py times. */
 int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z, const uint8_t r[32], const uint8_t s[32],
                                uint8_t out_proof[192]);
+/* Batch of n_proofs independent proofs over one resident key (BASELINE config 2):
+ * d_z[i] = device pointer to witness i, r/s = n_proofs x 32 B, out = n_proofs x 192 B.
+ * Two proofs are kept in flight (GPU works on proof i+1 while the CPU finishes proof i). */
+int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
+                                     const uint8_t* r, const uint8_t* s, uint8_t* out_proofs);
 /* h-polynomial coefficients only (row a7), N x 32 B canonical LE */
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h);
 /* row a11: pairing check on the host CPU.  publics excludes the leading 1. */

@@ -227,3 +227,24 @@ def test_groth16_self_verifies(ctx, zk, lg):
     proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
     assert zk.groth16_verify(vk, z[32 : 32 * r1.n_pub], proof) is True
     pk.free()
+
+
+def test_groth16_batch_matches_single(ctx, zk):
+    """Pipelined batch (two proofs in flight) returns the same bytes as one-at-a-time proving."""
+    import torch
+
+    lg = 12
+    r1 = zk.shielder_r1cs(lg)
+    rng = ec.SplitMix64(99)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    wits = [zk.shielder_witness(lg, 500 + i) for i in range(5)]
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(5)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(5)]
+    single = [ctx.groth16_prove(pk, w, r, s) for w, r, s in zip(wits, rs, ss)]
+    d = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
+    torch.cuda.synchronize()
+    batch = ctx.groth16_prove_batch_dev(pk, [t.data_ptr() for t in d], rs, ss)
+    assert batch == single
+    for w, pf in zip(wits, batch):
+        assert zk.groth16_verify(vk, w[32 : 32 * r1.n_pub], pf) is True
+    pk.free()

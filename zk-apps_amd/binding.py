@@ -446,6 +446,14 @@ class Context:
         self._chk(self.lib.zkmi_groth16_prove_dev(self.h, pk.h, C.c_void_p(d_z_ptr), _buf(r), _buf(s), out))
         return bytes(out)
 
+    def groth16_prove_batch_dev(self, pk, d_z_ptrs, rs, ss):
+        n = len(d_z_ptrs)
+        ptrs = (C.c_void_p * n)(*d_z_ptrs)
+        out = (C.c_uint8 * (192 * n))()
+        self._chk(self.lib.zkmi_groth16_prove_batch_dev(self.h, pk.h, C.c_uint32(n), ptrs, _buf(b"".join(rs)), _buf(b"".join(ss)), out))
+        raw = bytes(out)
+        return [raw[192 * i : 192 * i + 192] for i in range(n)]
+
     def groth16_witness_map(self, pk, z):
         out = (C.c_uint8 * (32 << pk.r1cs.log_n))()
         self._chk(self.lib.zkmi_groth16_witness_map(self.h, pk.h, _buf(z), out))

@@ -76,7 +76,10 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   zkmi_ctx* c = new (std::nothrow) zkmi_ctx();
   if (!c) return ZKMI_ERR_BAD_ARG;
   c->device = device;
-  if (hipStreamCreate(&c->stream) != hipSuccess) {
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreate(&c->stream) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     delete c;
     return ZKMI_ERR_HIP;
   }
@@ -94,12 +97,14 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_aux) (void)hipStreamSynchronize(ctx->stream_aux);
   ctx->domains.clear();
   ctx->sort.release();
   ctx->g1.release();
   ctx->g2.release();
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
   delete ctx;
   return ZKMI_OK;
 }
@@ -109,6 +114,7 @@ const char* zkmi_last_error(const zkmi_ctx* ctx) { return ctx ? ctx->err.c_str()
 int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -126,6 +132,7 @@ int32_t zkmi_prof_reset(zkmi_ctx* ctx) {
 int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64_t* out_launches) {
   if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
   (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream_aux);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];
@@ -257,7 +264,7 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g1.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   G1XYZZ res;
   ZK_HIP(ctx, ctx->g1.finish_host(&res));
   g1_to_wire(res.to_affine(), out_affine);
@@ -270,7 +277,7 @@ int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g2.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
   G2XYZZ res;
   ZK_HIP(ctx, ctx->g2.finish_host(&res));
   g2_to_wire(res.to_affine(), out_affine);
@@ -313,7 +320,7 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
   hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
   ctx->sort.plan_override = 0;
   if (e != hipSuccess) return ctx->hip_fail(e, "sort");
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   std::vector<G1XYZZ> win(ctx->sort.plan.nwin);
   ZK_HIP(ctx, ctx->g1.finish_host_windows(win.data()));
   for (int w = 0; w < ctx->sort.plan.nwin; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);

@@ -13,6 +13,7 @@
 struct zkmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_aux = nullptr;  // MSM reductions: overlap the next accumulation
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;

@@ -451,37 +451,43 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   return ZKMI_OK;
 }
 
-static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, const uint8_t r_bytes[32],
-                          const uint8_t s_bytes[32], uint8_t out_proof[192]) {
-  if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
-  if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
+// Device work of one proof (witness map, two digit sorts, five MSMs) queued on
+// the ctx streams; MSM partials land in slot set `par` (0/1).  Does not block.
+static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, int par) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   hipStream_t st = ctx->stream;
   int32_t rc = witness_map_dev(ctx, pk, z, d_z);
   if (rc != ZKMI_OK) return rc;
   ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, st));  // h as canonical integers for the digit sort
   PhaseTimer* t = ctx->timer();
-  // MSMs over the assignment z[1..): one digit sort, four bucket passes
+  const int s0 = 4 * par, g2s = par;
+  // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
+  // MSM's reduction runs on the aux stream behind its accumulation and leaves the
+  // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z + 1);
   ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
-  G1XYZZ acc_a, acc_b1, acc_l, acc_h;
-  G2XYZZ acc_b2;
-  // every MSM's device work is queued back to back; each leaves its per-window
-  // partials in a pinned host slot + an event, and the CPU combines them while
-  // the GPU is already busy with the next MSM
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 0));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 1));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 2));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, 0));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 0));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
   // H: h[0..N-1) against h_query (re-uses the sort buffers: stream order keeps it behind the four above)
   ZK_HIP(ctx, ctx->sort.run(reinterpret_cast<const uint32_t*>(pk->d_a), N - 1, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 3));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_a, 0));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1, 1));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_l, 2));
-  ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2, 0));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_h, 3));
-  // assembly
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 3));
+  return ZKMI_OK;
+}
+
+// Host part: wait for the slot set's partials, combine windows, assemble A, B, C
+//  and compress.  The GPU may already be running the next proof.
+static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t r_bytes[32], const uint8_t s_bytes[32],
+                            int par, uint8_t out_proof[192]) {
+  const int s0 = 4 * par, g2s = par;
+  G1XYZZ acc_a, acc_b1, acc_l, acc_h;
+  G2XYZZ acc_b2;
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_a, s0 + 0));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1, s0 + 1));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_l, s0 + 2));
+  ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2, g2s));
+  ZK_HIP(ctx, ctx->g1.finish_host(&acc_h, s0 + 3));
   uint32_t rk[8], sk[8], rsk[8];
   memcpy(rk, r_bytes, 32);
   memcpy(sk, s_bytes, 32);
@@ -513,6 +519,15 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   return ZKMI_OK;
 }
 
+static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, const uint8_t r_bytes[32],
+                          const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
+  if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
+  int32_t rc = prove_enqueue(ctx, pk, z, d_z, 0);
+  if (rc != ZKMI_OK) return rc;
+  return prove_finish(ctx, pk, r_bytes, s_bytes, 0, out_proof);
+}
+
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
                            const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   if (!z) return ZKMI_ERR_BAD_ARG;
@@ -523,6 +538,30 @@ int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z
                                const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   if (!d_z) return ZKMI_ERR_BAD_ARG;
   return prove_impl(ctx, pk, nullptr, d_z, r_bytes, s_bytes, out_proof);
+}
+
+// Batch of independent proofs over one key (BASELINE config 2), two in flight:
+// proof i+1's device work is queued before the CPU combines proof i.
+int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
+                                     const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
+  if (!ctx || !pk || !d_z || !r_bytes || !s_bytes || !out_proofs) return ZKMI_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n_proofs; i++) {
+    if (!d_z[i]) return ZKMI_ERR_BAD_ARG;
+    if (!fr_is_canonical(r_bytes + 32ull * i) || !fr_is_canonical(s_bytes + 32ull * i))
+      return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
+  }
+  if (n_proofs == 0) return ZKMI_OK;
+  int32_t rc = prove_enqueue(ctx, pk, nullptr, d_z[0], 0);
+  if (rc != ZKMI_OK) return rc;
+  for (uint32_t i = 0; i < n_proofs; i++) {
+    if (i + 1 < n_proofs) {
+      rc = prove_enqueue(ctx, pk, nullptr, d_z[i + 1], (int)((i + 1) & 1));
+      if (rc != ZKMI_OK) return rc;
+    }
+    rc = prove_finish(ctx, pk, r_bytes + 32ull * i, s_bytes + 32ull * i, (int)(i & 1), out_proofs + 192ull * i);
+    if (rc != ZKMI_OK) return rc;
+  }
+  return ZKMI_OK;
 }
 
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]) {

@@ -71,15 +71,16 @@ template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
 template <class F>
 struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
-  enum { SLOTS = 4, SLOT_PTS = 64 * 32 };
-  XYZZ<F>* buckets = nullptr;
+  enum { SLOTS = 8, SLOT_PTS = 64 * 32 };  // two proofs in flight x four G1 MSMs
+  XYZZ<F>* buckets = nullptr;  // SLOTS x cap_buckets: one bucket array per MSM in flight
   XYZZ<F>* segsum = nullptr;
   XYZZ<F>* segw = nullptr;
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event
   XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS
   XYZZ<HF>* h_partial = nullptr;  // pinned host, SLOTS x SLOT_PTS
-  hipEvent_t done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t done[SLOTS] = {};      // partials landed in h_partial
+  hipEvent_t acc_done[SLOTS] = {};  // bucket accumulation finished
   MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }
@@ -87,8 +88,10 @@ struct MsmEngine {
   hipError_t reserve(uint64_t n);
   // device part: bucket accumulation + reduction down to per-window partials,
   // async copy of the partials to the host and an event; does not block
-  hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, PhaseTimer* prof,
-                        int ph_accum, int ph_reduce, int slot = 0);
+  // accumulation runs on `st`; the (low-occupancy, latency-bound) reduction runs on
+  // `st_reduce` behind an event so it overlaps the next MSM's accumulation
+  hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, hipStream_t st_reduce,
+                        PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0);
   // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points

@@ -183,11 +183,11 @@ void MsmEngine<F>::release() {
   if (segw) (void)hipFree(segw);
   if (partial) (void)hipFree(partial);
   if (h_partial) (void)hipHostFree(h_partial);
-  for (int i = 0; i < SLOTS; i++)
-    if (done[i]) {
-      (void)hipEventDestroy(done[i]);
-      done[i] = nullptr;
-    }
+  for (int i = 0; i < SLOTS; i++) {
+    if (done[i]) (void)hipEventDestroy(done[i]);
+    if (acc_done[i]) (void)hipEventDestroy(acc_done[i]);
+    done[i] = acc_done[i] = nullptr;
+  }
   buckets = segsum = segw = nullptr;
   partial = h_partial = nullptr;
   cap_buckets = 0;
@@ -203,13 +203,15 @@ hipError_t MsmEngine<F>::reserve(uint64_t n) {
   if (need <= cap_buckets) return hipSuccess;
   release();
   hipError_t e;
-  if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need)) != hipSuccess) return e;
+  if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need * SLOTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
-  for (int i = 0; i < SLOTS; i++)
+  for (int i = 0; i < SLOTS; i++) {
     if ((e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&acc_done[i], hipEventDisableTiming)) != hipSuccess) return e;
+  }
   cap_buckets = need;
   return hipSuccess;
 }
@@ -223,30 +225,34 @@ static inline int msm_seg_bits(const MsmPlan& pl) {
 
 template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
-                                    PhaseTimer* prof, int ph_accum, int ph_reduce, int slot) {
+                                    hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot) {
   const MsmPlan& pl = sort.plan;
   slot_plan[slot] = pl;
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
+  XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
+  hipError_t e;
   if (prof) prof->begin(ph_accum, st);
   hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                     sort.perm, sort.sorted, buckets, tot_b);
+                     sort.perm, sort.sorted, bk, tot_b);
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(512), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
-                     sort.begin, sort.count, sort.heavy, sort.sorted, buckets);
+                     sort.begin, sort.count, sort.heavy, sort.sorted, bk);
   if (prof) prof->end(ph_accum, st);
-  if (prof) prof->begin(ph_reduce, st);
+  if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
+  if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
+  if (prof) prof->begin(ph_reduce, st_reduce);
   const uint32_t segs_per_win = pl.nb / MSM_SEG;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
-  hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st, buckets, segsum, segw, tot_segs);
+  hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs);
   const int njobs = 1 + msm_seg_bits(pl);
   XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
-  hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, segsum,
-                     segw, segs_per_win, dp);
-  if (prof) prof->end(ph_reduce, st);
-  hipError_t e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
-                                hipMemcpyDeviceToHost, st);
+  hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+                     segsum, segw, segs_per_win, dp);
+  if (prof) prof->end(ph_reduce, st_reduce);
+  e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
+                     hipMemcpyDeviceToHost, st_reduce);
   if (e != hipSuccess) return e;
-  if ((e = hipEventRecord(done[slot], st)) != hipSuccess) return e;
+  if ((e = hipEventRecord(done[slot], st_reduce)) != hipSuccess) return e;
   return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // zkmi — bucket scatter for the Pippenger MSM: signed-digit decomposition of
 // the scalars and a counting sort of point indices by (window, bucket).
 // See msm_impl.hpp for the full kernel chain and HBM layout.
+#include <stdlib.h>
 #include "msm_impl.hpp"
 
 namespace zkmi {
@@ -188,7 +189,15 @@ MsmPlan msm_make_plan_c(uint64_t n, int c) {
   p.n = n;
   return p;
 }
-MsmPlan msm_make_plan(uint64_t n) { return msm_make_plan_c(n, pick_window(n)); }
+MsmPlan msm_make_plan(uint64_t n) {
+  // ZKMI_WINDOW_BITS: tuning override (5..16), read once
+  static const int forced = [] {
+    const char* e = getenv("ZKMI_WINDOW_BITS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 5 && v <= 16) ? v : 0;
+  }();
+  return msm_make_plan_c(n, forced ? forced : pick_window(n));
+}
 
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
