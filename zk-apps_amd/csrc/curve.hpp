@@ -12,6 +12,16 @@
 
 namespace zkmi {
 
+// Building blocks of the XYZZ addition formulas.  The generic forms are plain
+// field expressions; field28.hpp overloads them for the lazily reduced device
+// limbs (skipped carry sweeps, two products under one Montgomery reduction).
+template <class F>
+ZK_HD F f_sub_lazy(const F& a, const F& b) { return a - b; }  // result only feeds products
+template <class F>
+ZK_HD F f_x3(const F& rr, const F& ppp, const F& q) { return rr - ppp - q.dbl(); }
+template <class F>
+ZK_HD F f_mul_sub_mul(const F& a, const F& b, const F& c, const F& d) { return a * b - c * d; }
+
 template <class F>
 struct Affine {
   F x, y;
@@ -79,13 +89,14 @@ struct XYZZ {
     }
     F u2 = p.x * zz;
     F s2 = p.y * zzz;
-    F pp_ = u2 - x;
-    F r = s2 - y;
+    F pp_ = f_sub_lazy(u2, x);
+    F r = f_sub_lazy(s2, y);
     // zero tests are made on products (P = 0 <=> P^2 = 0): exact for every
     // field representation, including the lazily reduced device limbs
     F pp = pp_.sqr();
+    F rr = r.sqr();
     if (pp.is_zero()) {
-      if (r.sqr().is_zero()) {
+      if (rr.is_zero()) {
         *this = dbl_affine_slow(p);
       } else {
         *this = infinity();
@@ -94,8 +105,8 @@ struct XYZZ {
     }
     F ppp = pp_ * pp;
     F q = x * pp;
-    F x3 = r.sqr() - ppp - q.dbl();
-    y = r * (q - x3) - y * ppp;
+    F x3 = f_x3(rr, ppp, q);
+    y = f_mul_sub_mul(r, f_sub_lazy(q, x3), y, ppp);
     x = x3;
     zz = zz * pp;
     zzz = zzz * ppp;
@@ -112,11 +123,12 @@ struct XYZZ {
     F u2 = o.x * zz;
     F s1 = y * o.zzz;
     F s2 = o.y * zzz;
-    F pp_ = u2 - u1;
-    F r = s2 - s1;
+    F pp_ = f_sub_lazy(u2, u1);
+    F r = f_sub_lazy(s2, s1);
     F pp = pp_.sqr();
+    F rr = r.sqr();
     if (pp.is_zero()) {
-      if (r.sqr().is_zero()) {
+      if (rr.is_zero()) {
         *this = dbl_slow(*this);
       } else {
         *this = infinity();
@@ -125,8 +137,8 @@ struct XYZZ {
     }
     F ppp = pp_ * pp;
     F q = u1 * pp;
-    F x3 = r.sqr() - ppp - q.dbl();
-    y = r * (q - x3) - s1 * ppp;
+    F x3 = f_x3(rr, ppp, q);
+    y = f_mul_sub_mul(r, f_sub_lazy(q, x3), s1, ppp);
     x = x3;
     zz = zz * o.zz * pp;
     zzz = zzz * o.zzz * ppp;

@@ -284,6 +284,71 @@ ZK_FQ2_28 Fq28 fq2_sqr_c1(const Fq28& a0, const Fq28& a1) {
 
 using Fq2_28 = Fq2T<Fq28>;
 
+// ---- XYZZ building blocks (overloads of curve.hpp's generic forms) ------------
+// Fq28: differences that only feed products skip the carry sweep (limbs < 2^29,
+// 14 products of < 2^59 stay below 2^63 together with the reduction's share).
+ZK_HD Fq28 f_sub_lazy(const Fq28& a, const Fq28& b) { return a.sub_lazy(b); }
+ZK_HD Fq28 f_x3(const Fq28& rr, const Fq28& ppp, const Fq28& q) {
+  Fq28 r;
+#pragma unroll
+  for (int i = 0; i < Fq28::NL; i++) r.l[i] = rr.l[i] - ppp.l[i] - 2 * q.l[i];
+  r.carry();
+  return r;
+}
+// a b - c d under one reduction (a, b may be lazy differences; c, d normalised)
+ZK_HD Fq28 f_mul_sub_mul(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+  constexpr int NL = Fq28::NL;
+  int64_t T[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int32_t nc = -c.l[i];
+#pragma unroll
+    for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.l[i] * b.l[j] + (int64_t)nc * d.l[j];
+  }
+  return Fq28::reduce(T);
+}
+// Fq2 over the limbs: operands stay normalised (a component already sums two
+// products), but a b - c d needs only one reduction per component (4 x 14 products
+// of < 2^56 plus the reduction stay below 2^62).
+ZK_HD Fq2_28 f_x3(const Fq2_28& rr, const Fq2_28& ppp, const Fq2_28& q) {
+  return {f_x3(rr.c0, ppp.c0, q.c0), f_x3(rr.c1, ppp.c1, q.c1)};
+}
+ZK_HD Fq2_28 f_mul_sub_mul(const Fq2_28& a, const Fq2_28& b, const Fq2_28& c, const Fq2_28& d) {
+  constexpr int NL = Fq28::NL;
+  Fq2_28 out;
+  {
+    int64_t T[2 * NL];
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int32_t na1 = -a.c1.l[i], nc0 = -c.c0.l[i];
+#pragma unroll
+      for (int j = 0; j < NL; j++)
+        T[i + j] += (int64_t)a.c0.l[i] * b.c0.l[j] + (int64_t)na1 * b.c1.l[j] + (int64_t)nc0 * d.c0.l[j] +
+                    (int64_t)c.c1.l[i] * d.c1.l[j];
+    }
+    out.c0 = Fq28::reduce(T);
+  }
+  {
+    int64_t T[2 * NL];
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int32_t nc0 = -c.c0.l[i], nc1 = -c.c1.l[i];
+#pragma unroll
+      for (int j = 0; j < NL; j++)
+        T[i + j] += (int64_t)a.c0.l[i] * b.c1.l[j] + (int64_t)a.c1.l[i] * b.c0.l[j] + (int64_t)nc0 * d.c1.l[j] +
+                    (int64_t)nc1 * d.c0.l[j];
+    }
+    out.c1 = Fq28::reduce(T);
+  }
+  return out;
+}
+
 // conversions between the host/old representation (12x32, R = 2^384) and Fq28
 ZK_HD Fq28 fq28_from_fq(const Fq& a) {
   Fq c = a.from_mont();

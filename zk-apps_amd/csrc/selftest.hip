@@ -2,6 +2,7 @@
 // (field28.hpp is __host__ __device__): random chains of mul/sqr/add/sub/neg/dbl
 // in Fq28 limbs against the 32-bit-limb Fq, plus the zero test on k*p forms.
 #include "ctx.hpp"
+#include "curve.hpp"
 #include "field28.hpp"
 
 using namespace zkmi;
@@ -76,6 +77,39 @@ extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* o
       if (fq_from_fq28(CH) != chain) bad++;
       if (!(X * Y - Y * X).is_zero()) bad++;
       if ((X * Y).is_zero() != m.is_zero()) bad++;
+    }
+    // whole mixed / full additions through curve.hpp in both representations
+    {
+      Affine<Fq> p1 = {a, b}, p2 = {c, a * c};
+      XYZZ<Fq> h = XYZZ<Fq>::from_affine(p1);
+      h.madd(p2);
+      XYZZ<Fq> h2 = h;
+      h2.madd(p1);
+      h.add(h2);
+      Affine<Fq28> P1 = {A, B}, P2 = {C, A * C};
+      XYZZ<Fq28> d = XYZZ<Fq28>::from_affine(P1);
+      d.madd(P2);
+      XYZZ<Fq28> d2 = d;
+      d2.madd(P1);
+      d.add(d2);
+      if (fq_from_fq28(d.x) != h.x || fq_from_fq28(d.y) != h.y || fq_from_fq28(d.zz) != h.zz ||
+          fq_from_fq28(d.zzz) != h.zzz)
+        bad++;
+      Affine<Fq2> q1 = {{a, b}, {c, a}}, q2 = {{b, c}, {a * b, c}};
+      XYZZ<Fq2> g = XYZZ<Fq2>::from_affine(q1);
+      g.madd(q2);
+      XYZZ<Fq2> g2 = g;
+      g2.madd(q1);
+      g.add(g2);
+      Affine<Fq2_28> Q1 = {{A, B}, {C, A}}, Q2 = {{B, C}, {A * B, C}};
+      XYZZ<Fq2_28> e = XYZZ<Fq2_28>::from_affine(Q1);
+      e.madd(Q2);
+      XYZZ<Fq2_28> e2 = e;
+      e2.madd(Q1);
+      e.add(e2);
+      if (fq_from_fq28(e.x) != g.x || fq_from_fq28(e.y) != g.y || fq_from_fq28(e.zz) != g.zz ||
+          fq_from_fq28(e.zzz) != g.zzz)
+        bad++;
     }
     // lazy forms feeding a product
     if (fq_from_fq28(A.add_lazy(B) * C.sub_lazy(A)) != (a + b) * (c - a)) bad++;
