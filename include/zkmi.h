@@ -78,11 +78,8 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
  * Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft}_in_place + coset
  * variants [not in reference tree; SURVEY.md row a6]. */
 int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset);
-/* Same on a device buffer holding Montgomery-form elements (the pipeline's
- * internal representation). */
-int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data_mont, uint32_t log_n, int32_t inverse, int32_t coset);
-int32_t zkmi_fr_to_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n);
-int32_t zkmi_fr_from_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n);
+/* Same on a device buffer of 2^log_n x 32 B canonical LE elements (in place). */
+int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inverse, int32_t coset);
 
 /* ---- rows a8 / a9: multi-scalar multiplication --------------------------- */
 /* Upload n affine points (wire format) and keep them resident in HBM in

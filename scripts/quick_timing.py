@@ -33,7 +33,6 @@ if lg <= 20:
         t = time.time(); out = ctx.msm_g2_dev(d.data_ptr(), n, b2); dt = time.time() - t
         print(f"msm_g2 2^{lg}: wall {dt*1e3:.2f} ms", {k: ctx.prof_get(k) for k in ("msm_sort", "msm_accum_g2", "msm_reduce_g2")})
 x = d.clone()
-ctx.fr_to_mont_dev(x.data_ptr(), n)
 for it in range(3):
     ctx.prof_reset()
     t = time.time(); ctx.ntt_dev(x.data_ptr(), lg); dt = time.time() - t

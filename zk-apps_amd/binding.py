@@ -361,12 +361,6 @@ class Context:
     def ntt_dev(self, dptr, log_n, inverse=False, coset=False):
         self._chk(self.lib.zkmi_ntt_fr_dev(self.h, C.c_void_p(dptr), C.c_uint32(log_n), C.c_int32(inverse), C.c_int32(coset)))
 
-    def fr_to_mont_dev(self, dptr, n):
-        self._chk(self.lib.zkmi_fr_to_mont_dev(self.h, C.c_void_p(dptr), C.c_uint64(n)))
-
-    def fr_from_mont_dev(self, dptr, n):
-        self._chk(self.lib.zkmi_fr_from_mont_dev(self.h, C.c_void_p(dptr), C.c_uint64(n)))
-
     # bases
     def bases_g1(self, affine, check=True):
         h = C.c_void_p()

@@ -103,6 +103,7 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   ctx->g1.release();
   ctx->g2.release();
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
   delete ctx;
@@ -142,44 +143,41 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
 // ---------------------------------------------------------------------------
 // NTT
 // ---------------------------------------------------------------------------
-int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data_mont, uint32_t log_n, int32_t inverse, int32_t coset) {
-  if (!ctx || !d_data_mont || log_n > 28) return ZKMI_ERR_BAD_ARG;
+int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  if (!ctx || !d_data || log_n > 26) return ZKMI_ERR_BAD_ARG;
   hipError_t e;
   NttDomain* dom = ctx->domain((int)log_n, &e);
   if (!dom) return ctx->hip_fail(e, "ntt domain init");
+  const uint32_t n = 1u << log_n;
+  // canonical words <-> limb form around the transform (not part of the timed phase)
+  if (ctx->d_work_cap < (uint64_t)n * sizeof(Fr28)) {
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
+    ctx->d_work = nullptr;
+    ctx->d_work_cap = 0;
+    ZK_HIP(ctx, hipMalloc(&ctx->d_work, (uint64_t)n * sizeof(Fr28)));
+    ctx->d_work_cap = (uint64_t)n * sizeof(Fr28);
+  }
+  Fr28* work = static_cast<Fr28*>(ctx->d_work);
+  ZK_HIP(ctx, ntt_from_canonical(static_cast<const uint32_t*>(d_data), work, n, ctx->stream));
   PhaseTimer* t = ctx->timer();
   if (t) t->begin(PH_NTT, ctx->stream);
-  e = dom->transform(static_cast<Fr*>(d_data_mont), inverse != 0, coset != 0, ctx->stream);
+  e = dom->transform(work, inverse != 0, coset != 0, ctx->stream);
   if (t) t->end(PH_NTT, ctx->stream);
   if (e != hipSuccess) return ctx->hip_fail(e, "ntt transform");
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZKMI_OK;
-}
-
-int32_t zkmi_fr_to_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n) {
-  if (!ctx || !d_data) return ZKMI_ERR_BAD_ARG;
-  ZK_HIP(ctx, ntt_to_mont(static_cast<Fr*>(d_data), (uint32_t)n, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ZKMI_OK;
-}
-int32_t zkmi_fr_from_mont_dev(zkmi_ctx* ctx, void* d_data, uint64_t n) {
-  if (!ctx || !d_data) return ZKMI_ERR_BAD_ARG;
-  ZK_HIP(ctx, ntt_from_mont(static_cast<Fr*>(d_data), (uint32_t)n, ctx->stream));
+  ZK_HIP(ctx, ntt_to_canonical(work, static_cast<uint32_t*>(d_data), n, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKMI_OK;
 }
 
 int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset) {
-  if (!ctx || !data || log_n > 28) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !data || log_n > 26) return ZKMI_ERR_BAD_ARG;
   const uint64_t n = 1ull << log_n;
   for (uint64_t i = 0; i < n; i++)
     if (!fr_is_canonical(data + 32 * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "ntt input >= r");
   ZK_HIP(ctx, ctx->staging(n * 32));
   ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  ZK_HIP(ctx, ntt_to_mont(static_cast<Fr*>(ctx->d_tmp), (uint32_t)n, ctx->stream));
   int32_t rc = zkmi_ntt_fr_dev(ctx, ctx->d_tmp, log_n, inverse, coset);
   if (rc != ZKMI_OK) return rc;
-  ZK_HIP(ctx, ntt_from_mont(static_cast<Fr*>(ctx->d_tmp), (uint32_t)n, ctx->stream));
   ZK_HIP(ctx, hipMemcpyAsync(data, ctx->d_tmp, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKMI_OK;

@@ -22,6 +22,8 @@ struct zkmi_ctx {
   zkmi::MsmEngine<zkmi::Fq2_28> g2;
   void* d_tmp = nullptr;  // staging for host-buffer entry points
   uint64_t d_tmp_cap = 0;
+  void* d_work = nullptr;  // limb-form work buffer of the NTT entry points
+  uint64_t d_work_cap = 0;
 
   zkmi::PhaseTimer* timer() { return prof.enabled ? &prof : nullptr; }
   int32_t fail(int32_t code, const std::string& msg) {

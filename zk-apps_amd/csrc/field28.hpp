@@ -37,6 +37,18 @@ struct Fq28Params {
                                      0x5d74088, 0xc10ea72, 0x865d118, 0x7320a75, 0xfd5cd50, 0xcc8a759, 0x000c8d4};
 };
 
+struct Fr28Params {
+  static constexpr int NL = 10;  // 280-bit radix, 25 spare bits
+  static constexpr int N32 = 8;
+  static constexpr uint32_t INV = 0xfffffffu;  // -r^-1 mod 2^28
+  static constexpr int32_t MOD[10] = {0x0000001, 0xffffff0, 0xe5bfeff, 0xa402fff, 0x80553bd,
+                                      0x0809a1d, 0x83339d8, 0x299d7d4, 0x3eda753, 0x0000007};
+  static constexpr int32_t ONE[10] = {0xdcaaf6c, 0x355093f, 0x8209402, 0x41e37a6, 0x135587d,
+                                      0x26172ba, 0x6854f56, 0x3973f39, 0xbc66e55, 0x0000006};
+  static constexpr int32_t R2[10] = {0xc31bba9, 0x3b3440e, 0xe045fb0, 0x8929657, 0x57c6e1a,
+                                     0x2d645cf, 0x012ecf5, 0xea6a1c5, 0xc7b9d12, 0x0000003};
+};
+
 template <class P>
 struct Fp28 {
   static constexpr int NL = P::NL;
@@ -242,6 +254,7 @@ struct Fp28 {
 };
 
 using Fq28 = Fp28<Fq28Params>;
+using Fr28 = Fp28<Fr28Params>;  // scalar field: NTT / witness map (values may grow to ~2^21 r between products)
 
 // ---- Fq2 components with lazy reduction (overloads of field.hpp's generic forms) ----
 // a0 b0 + s a1 b1 summed in the 64-bit columns: 28 products of < 2^56 plus the

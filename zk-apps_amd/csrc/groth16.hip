@@ -45,25 +45,35 @@ __device__ __forceinline__ void stv(T* p, const T& v) {
 
 // out[i] = <M_i, z> for i < nc; rows [nc, nc+n_pub) = z_j if is_a else 0; rest 0
 __global__ void __launch_bounds__(256)
-k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ val,
-         const Fr* __restrict__ z, Fr* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a) {
+k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr28* __restrict__ val,
+         const Fr28* __restrict__ z, Fr28* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr acc = Fr::zero();
+  Fr28 acc = Fr28::zero();
   if (i < nc) {
     const uint32_t b = rowptr[i], e = rowptr[i + 1];
-    for (uint32_t k = b; k < e; k++) acc = acc + ldv(val + k) * ldv(z + col[k]);
+    for (uint32_t k = b; k < e; k++) acc = acc + ld28(val + k) * ld28(z + col[k]);
   } else if (is_a && i < nc + n_pub) {
-    acc = ldv(z + (i - nc));
+    acc = ld28(z + (i - nc));
   }
-  stv(out + i, acc);
+  st28(out + i, acc);
 }
 
 __global__ void __launch_bounds__(256)
-k_quotient(Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, Fr zinv, uint32_t n) {
+k_quotient(Fr28* __restrict__ a, const Fr28* __restrict__ b, const Fr28* __restrict__ c, Fr28 zinv, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  stv(a + i, (ldv(a + i) * ldv(b + i) - ldv(c + i)) * zinv);
+  st28(a + i, (ld28(a + i) * ld28(b + i) - ld28(c + i)) * zinv);
+}
+
+// out[p] = in[rev(p)]: bases of the H MSM follow the bit-reversed coefficient order
+template <class A>
+__global__ void __launch_bounds__(256)
+k_bitrev_points(const A* __restrict__ in, A* __restrict__ out, int log_n) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (1u << log_n)) return;
+  const uint32_t r = log_n ? (__brev(p) >> (32 - log_n)) : 0u;
+  stv(out + p, ldv(in + r));
 }
 
 // fixed-base multiplication out[i] = s_i * B with 8-bit windows:
@@ -95,22 +105,24 @@ struct zkmi_pk {
   uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
   uint32_t* d_rowptr[3] = {nullptr, nullptr, nullptr};
   uint32_t* d_col[3] = {nullptr, nullptr, nullptr};
-  Fr* d_val[3] = {nullptr, nullptr, nullptr};
+  Fr28* d_val[3] = {nullptr, nullptr, nullptr};
   G1Affine *a_query = nullptr, *b_g1_query = nullptr, *h_query = nullptr, *l_query = nullptr;  // l padded to n_vars
   G2Affine* b_g2_query = nullptr;
   // the same queries in the device MSM representation (28-bit limbs)
-  Affine<Fq28>*a28 = nullptr, *b1_28 = nullptr, *h28 = nullptr, *l28 = nullptr;
+  Affine<Fq28>*a28 = nullptr, *b1_28 = nullptr, *h28 = nullptr, *h28_rev = nullptr, *l28 = nullptr;
   Affine<Fq2_28>* b2_28 = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
-  Fr *d_z = nullptr, *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+  Fr* d_z = nullptr;  // witness, canonical words (digit source of the A/B/L MSMs)
+  Fr28 *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;  // limb form (field28.hpp)
+  uint32_t* d_h = nullptr;  // h coefficients, canonical words, bit-reversed order
   ~zkmi_pk() {
     for (int m = 0; m < 3; m++) {
       if (d_rowptr[m]) (void)hipFree(d_rowptr[m]);
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
-    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, a28, b1_28, h28, l28, b2_28};
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, d_h, a28, b1_28, h28, h28_rev, l28, b2_28};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
   }
@@ -129,11 +141,17 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
     const size_t nnz = c.col.size();
     if ((e = hipMalloc(&pk->d_rowptr[m], sizeof(uint32_t) * c.rowptr.size())) != hipSuccess) return e;
     if ((e = hipMalloc(&pk->d_col[m], sizeof(uint32_t) * (nnz ? nnz : 1))) != hipSuccess) return e;
-    if ((e = hipMalloc(&pk->d_val[m], sizeof(Fr) * (nnz ? nnz : 1))) != hipSuccess) return e;
+    if ((e = hipMalloc(&pk->d_val[m], sizeof(Fr28) * (nnz ? nnz : 1))) != hipSuccess) return e;
     if ((e = hipMemcpy(pk->d_rowptr[m], c.rowptr.data(), sizeof(uint32_t) * c.rowptr.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if (nnz) {
       if ((e = hipMemcpy(pk->d_col[m], c.col.data(), sizeof(uint32_t) * nnz, hipMemcpyHostToDevice)) != hipSuccess) return e;
-      if ((e = hipMemcpy(pk->d_val[m], c.val.data(), sizeof(Fr) * nnz, hipMemcpyHostToDevice)) != hipSuccess) return e;
+      // matrix values: canonical words on the host -> limb form on the device
+      std::vector<Fr> canon(nnz);
+      for (size_t k = 0; k < nnz; k++) canon[k] = c.val[k].from_mont();
+      if ((e = ctx->staging(sizeof(Fr) * nnz)) != hipSuccess) return e;
+      if ((e = hipMemcpy(ctx->d_tmp, canon.data(), sizeof(Fr) * nnz, hipMemcpyHostToDevice)) != hipSuccess) return e;
+      if ((e = ntt_from_canonical(static_cast<const uint32_t*>(ctx->d_tmp), pk->d_val[m], (uint32_t)nnz, ctx->stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
     }
   }
   if ((e = hipMalloc(&pk->a_query, sizeof(G1Affine) * r->n_vars)) != hipSuccess) return e;
@@ -146,11 +164,13 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->b2_28, sizeof(Affine<Fq2_28>) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->l28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->h28_rev, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_z, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_zm, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_a, sizeof(Fr) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_b, sizeof(Fr) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_c, sizeof(Fr) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_zm, sizeof(Fr28) * r->n_vars)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_b, sizeof(Fr28) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_h, 32ull * N)) != hipSuccess) return e;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap)) != hipSuccess) return e;
   if ((e = ctx->g1.reserve(cap)) != hipSuccess) return e;
@@ -168,6 +188,9 @@ static hipError_t pk_convert_queries(zkmi_pk* pk) {
   if ((e = bases_convert<Fq2_28>(pk->b_g2_query, pk->b2_28, pk->n_vars, st)) != hipSuccess) return e;
   if ((e = bases_convert<Fq28>(pk->l_query, pk->l28, pk->n_vars, st)) != hipSuccess) return e;
   if ((e = bases_convert<Fq28>(pk->h_query, pk->h28, N, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bitrev_points<Affine<Fq28>>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->h28,
+                     pk->h28_rev, (int)pk->log_n);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
   return hipStreamSynchronize(st);
 }
 
@@ -414,9 +437,8 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
     ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, d_z_in, 32ull * nv, hipMemcpyDeviceToDevice, st));
   }
   if (t) t->begin(PH_WITNESS, st);
-  ZK_HIP(ctx, hipMemcpyAsync(pk->d_zm, pk->d_z, 32ull * nv, hipMemcpyDeviceToDevice, st));
-  ZK_HIP(ctx, ntt_to_mont(pk->d_zm, nv, st));
-  Fr* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
+  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z), pk->d_zm, nv, st));
+  Fr28* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
   for (int m = 0; m < 3; m++)
     hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
                        pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0);
@@ -425,16 +447,19 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   NttDomain* dom = ctx->domain((int)pk->log_n, &e);
   if (!dom) return ctx->hip_fail(e, "ntt domain");
   if (t) t->begin(PH_NTT, st);
+  // evaluations -> coefficients (bit-reversed, scaled by g^i / N) -> evaluations on the coset
   for (int m = 0; m < 3; m++) {
-    ZK_HIP(ctx, dom->transform(outv[m], true, false, st));
-    ZK_HIP(ctx, dom->transform(outv[m], false, true, st));
+    ZK_HIP(ctx, dom->inverse_to_rev(outv[m], dom->rev_coset_n, nullptr, st));
+    ZK_HIP(ctx, dom->forward_from_rev(outv[m], st));
   }
   // 1 / Z(g) with Z(g) = g^N - 1, g = 7
   Fr gn = fr_from_u64(7);
   for (uint32_t i = 0; i < pk->log_n; i++) gn = gn.sqr();
-  const Fr zinv = (gn - Fr::one()).inv();
-  hipLaunchKernelGGL(k_quotient, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv, N);
-  ZK_HIP(ctx, dom->transform(pk->d_a, true, true, st));
+  const Fr zinv = (gn - Fr::one()).inv().from_mont();
+  const Fr28 zinv28 = Fr28::from_canonical(zinv.l);
+  hipLaunchKernelGGL(k_quotient, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv28, N);
+  // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
+  ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h, st));
   if (t) t->end(PH_NTT, st);
   ZK_HIP(ctx, hipGetLastError());
   return ZKMI_OK;
@@ -445,9 +470,14 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   int32_t rc = witness_map_dev(ctx, pk, z, nullptr);
   if (rc != ZKMI_OK) return rc;
   const uint32_t N = 1u << pk->log_n;
-  ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, ctx->stream));
-  ZK_HIP(ctx, hipMemcpyAsync(out_h, pk->d_a, 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint8_t> rev(32ull * N);
+  ZK_HIP(ctx, hipMemcpyAsync(rev.data(), pk->d_h, 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t p = 0; p < N; p++) {
+    uint32_t i = 0;
+    for (uint32_t b = 0; b < pk->log_n; b++) i |= ((p >> b) & 1u) << (pk->log_n - 1 - b);
+    memcpy(out_h + 32ull * i, rev.data() + 32ull * p, 32);
+  }
   return ZKMI_OK;
 }
 
@@ -458,7 +488,6 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
   hipStream_t st = ctx->stream;
   int32_t rc = witness_map_dev(ctx, pk, z, d_z);
   if (rc != ZKMI_OK) return rc;
-  ZK_HIP(ctx, ntt_from_mont(pk->d_a, N, st));  // h as canonical integers for the digit sort
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
   // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
@@ -470,9 +499,10 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 1));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 2));
   ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
-  // H: h[0..N-1) against h_query (re-uses the sort buffers: stream order keeps it behind the four above)
-  ZK_HIP(ctx, ctx->sort.run(reinterpret_cast<const uint32_t*>(pk->d_a), N - 1, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 3));
+  // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
+  // infinity.  Re-uses the sort buffers: stream order keeps it behind the four MSMs above.
+  ZK_HIP(ctx, ctx->sort.run(pk->d_h, N, st, t));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 3));
   return ZKMI_OK;
 }
 

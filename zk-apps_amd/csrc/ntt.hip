@@ -4,140 +4,157 @@
 // = ark_poly::Radix2EvaluationDomain::{fft,ifft}_in_place and the coset
 // variants (generator 7), as restated in oracle/ntt.py.
 //
-// Data layout: N Fr elements, 32 B each, Montgomery form, natural order in and
-// out.  Twiddles w^k (k < N/2) and coset powers g^i live in HBM (precomputed
-// per domain size, stay resident in the 256 MiB Infinity Cache).
+// Element type: Fr28 = 10 signed 28-bit limbs (40 B), Montgomery R = 2^280,
+// lazily reduced (field28.hpp): a butterfly is one 270-instruction product
+// plus two carry-swept add/sub; values may grow by ~1.5 r per stage, which the
+// 25 spare bits of the radix absorb, so nothing is reduced between stages.
 //
-// Kernel plan (LDS-staged butterflies): a transform is a bit-reversal copy
-// followed by ceil(log N / S) decimation-in-time passes.  A pass owns S
-// consecutive butterfly stages [t0, t0+S): every workgroup stages a tile of
-// 2^S x 2^Q elements in LDS (2^S strided sub-problem points x 2^Q adjacent
-// columns so that global loads stay >= 128 B contiguous), runs the S stages
-// out of LDS with one barrier per stage, and writes the tile back.  With
-// S = 10, Q = 2 a tile is 4096 x 32 B = 128 KiB of the CU's 160 KiB LDS, so
-// N = 2^20 is exactly two passes over HBM (algorithmic minimum for a tile that
-// must fit one CU).
-#include "field.hpp"
+// Kernel plan (LDS-staged butterflies).  A pass owns up to 10 consecutive
+// butterfly stages: every workgroup stages a tile of 2^S x 2^Q elements in LDS
+// (2^S strided sub-problem points x 2^Q adjacent columns), runs the S stages out
+// of LDS with one barrier per stage, and writes the tile back.  N = 2^20 is two
+// passes over HBM (1024 x 40 B contiguous tiles, then 1024 x 2 strided tiles of
+// 80 KiB).  Two orderings avoid every bit-reversal copy inside the prover:
+//   DIF (Gentleman-Sande): natural in  -> bit-reversed out   (inverse transforms)
+//   DIT (Cooley-Tukey)   : bit-reversed in -> natural out    (forward transforms)
+// and the coset / 1/N scalings are folded into the last pass of the DIF
+// transforms (table indexed by position).  The natural-order public entry point
+// adds one bit-reversal copy in front of a DIT transform.
 #include "ntt.hpp"
 
 namespace zkmi {
 
 namespace {
 
-struct alignas(16) FrV {
-  uint4 lo, hi;
-};
-
-__device__ __forceinline__ Fr load_fr(const Fr* p) {
+__device__ __forceinline__ void ld_words8(const uint32_t* p, uint32_t* w) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1];
-  Fr r;
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  return r;
+  const uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 }
-__device__ __forceinline__ void store_fr(Fr* p, const Fr& v) {
+__device__ __forceinline__ void st_words8(uint32_t* p, const uint32_t* w) {
   uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-__global__ void k_bitrev_copy(const Fr* __restrict__ in, Fr* __restrict__ out, int log_n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n = 1u << log_n;
-  if (i >= n) return;
-  uint32_t r = __brev(i) >> (32 - log_n);
-  store_fr(out + r, load_fr(in + i));
+__global__ void k_bitrev_copy(const Fr28* __restrict__ in, Fr28* __restrict__ out, int log_n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  const uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0u;
+  st28(out + r, ld28(in + i));
 }
 
-// One DIT pass: stages [t0, t0+S) on an LDS tile of 2^S x 2^Q elements.
-// tw[k] = w_N^k (forward) or w_N^-k (inverse), k < N/2.
-// If scale != nullptr (last pass) every output is multiplied by scale[0]
-// (N^-1 for the inverse) and, if post != nullptr, additionally by post[i]
-// (coset inverse: g^-i).
-template <int THREADS>
+// One pass over stages [t0, t0+S).  DIF runs them high -> low, DIT low -> high.
+// tw[k] = w^k (or w^-k), k < N/2.  post (optional): every output is multiplied by
+// post[position].  canon_out (optional): outputs are written as canonical 32-byte
+// integers (8 words) instead of limbs — the digit source of the H MSM.
+template <bool DIF, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-k_ntt_dit_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int log_n, int t0, int S, int Q,
-               const Fr* __restrict__ scale, const Fr* __restrict__ post) {
+k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int t0, int S, int Q,
+           const Fr28* __restrict__ post, uint32_t* __restrict__ canon_out) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  Fr* tile = reinterpret_cast<Fr*>(lds_raw);
-  const int tile_log = S + Q;
-  const uint32_t tile_n = 1u << tile_log;
+  Fr28* tile = reinterpret_cast<Fr28*>(lds_raw);
+  const uint32_t tile_n = 1u << (S + Q);
   const uint32_t blk = blockIdx.x;
-
-  // global index of tile element L:
-  //   t0 == 0 : contiguous, g = blk * tile_n + L
-  //   t0 >  0 : L = e * 2^Q + c ; g = hi << (t0+S) | e << t0 | mid << Q | c
-  //             where blk = hi * 2^(t0-Q) + mid
+  // tile element L -> global index g:
+  //   t0 == 0 : g = blk * tile_n + L
+  //   t0 >  0 : L = e * 2^Q + c ; g = hi << (t0+S) | e << t0 | mid << Q | c, blk = hi * 2^(t0-Q) + mid
   const uint32_t mid_bits = (t0 > 0) ? (uint32_t)(t0 - Q) : 0u;
   const uint32_t mid = blk & ((1u << mid_bits) - 1u);
   const uint32_t hi = blk >> mid_bits;
   auto gindex = [&](uint32_t L) -> uint32_t {
     if (t0 == 0) return blk * tile_n + L;
-    uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
+    const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
     return (hi << (t0 + S)) | (e << t0) | (mid << Q) | c;
   };
-
-  for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) tile[L] = load_fr(data + gindex(L));
+  for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) tile[L] = ld28(data + gindex(L));
   __syncthreads();
 
   const uint32_t half = tile_n >> 1;
-  for (int u = 0; u < S; u++) {
-    const int t = t0 + u;  // global stage, butterfly distance 2^t
-    // distance inside the tile
+  for (int s = 0; s < S; s++) {
+    const int u = DIF ? (S - 1 - s) : s;
+    const int t = t0 + u;  // global stage: butterfly distance 2^t
     const uint32_t dist_log = (t0 == 0) ? (uint32_t)u : (uint32_t)(u + Q);
     const uint32_t dist = 1u << dist_log;
     for (uint32_t b = threadIdx.x; b < half; b += THREADS) {
-      // insert a zero bit at position dist_log
-      uint32_t lo = b & (dist - 1u);
-      uint32_t L0 = ((b >> dist_log) << (dist_log + 1)) | lo;
-      uint32_t L1 = L0 | dist;
-      uint32_t g0 = gindex(L0);
-      uint32_t j = g0 & ((1u << t) - 1u);
-      uint32_t k = j << (log_n - 1 - t);
-      Fr w = load_fr(tw + k);
-      Fr x = tile[L0];
-      Fr y = tile[L1] * w;
-      tile[L0] = x + y;
-      tile[L1] = x - y;
+      const uint32_t lo = b & (dist - 1u);
+      const uint32_t L0 = ((b >> dist_log) << (dist_log + 1)) | lo;
+      const uint32_t L1 = L0 | dist;
+      const uint32_t j = gindex(L0) & ((1u << t) - 1u);
+      const Fr28 w = ld28(tw + ((size_t)j << (log_n - 1 - t)));
+      const Fr28 x = tile[L0];
+      if (DIF) {
+        const Fr28 y = tile[L1];
+        tile[L0] = x + y;
+        tile[L1] = x.sub_lazy(y) * w;
+      } else {
+        const Fr28 y = tile[L1] * w;
+        tile[L0] = x + y;
+        tile[L1] = x - y;
+      }
     }
     __syncthreads();
   }
 
   for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
-    uint32_t g = gindex(L);
-    Fr v = tile[L];
-    if (scale) v = v * load_fr(scale);
-    if (post) v = v * load_fr(post + g);
-    store_fr(data + g, v);
+    const uint32_t g = gindex(L);
+    Fr28 v = tile[L];
+    if (post) v = v * ld28(post + g);
+    if (canon_out) {
+      uint32_t w[8];
+      v.to_canonical(w);
+      st_words8(canon_out + (size_t)g * 8, w);
+    } else {
+      st28(data + g, v);
+    }
   }
 }
 
-__global__ void k_mul_pointwise(Fr* __restrict__ a, const Fr* __restrict__ b, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) store_fr(a + i, load_fr(a + i) * load_fr(b + i));
+__global__ void __launch_bounds__(256)
+k_mul_table(Fr28* __restrict__ a, const Fr28* __restrict__ b, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st28(a + i, ld28(a + i) * ld28(b + i));
 }
 
-// table[i] = base^i * first, i < n, built by 2^12-element chunks:
-// thread t of a chunk starts from base^(chunk*4096 + t*16) via square-and-multiply.
-__global__ void k_power_table(Fr* __restrict__ out, Fr base, Fr first, uint32_t n) {
-  uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+__global__ void __launch_bounds__(256)
+k_scale(Fr28* __restrict__ a, Fr28 s, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st28(a + i, ld28(a + i) * s);
+}
+
+// out[i] = first * base^i, i < n: thread t starts at base^(16 t) by square-and-multiply
+__global__ void __launch_bounds__(256)
+k_power_table(Fr28* __restrict__ out, Fr28 base, Fr28 first, uint32_t n) {
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
   if (i0 >= n) return;
-  uint32_t e[1] = {i0};
-  Fr v = base.pow(e, 1) * first;
+  Fr28 v = first, sq = base;
+  for (uint32_t e = i0; e; e >>= 1) {
+    if (e & 1u) v = v * sq;
+    sq = sq * sq;
+  }
   for (uint32_t k = 0; k < 16u && i0 + k < n; k++) {
-    store_fr(out + i0 + k, v);
+    st28(out + i0 + k, v);
     v = v * base;
   }
 }
 
-__global__ void k_to_mont(Fr* __restrict__ a, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) store_fr(a + i, load_fr(a + i).to_mont());
+// canonical 32-byte integers <-> limbs (Montgomery R = 2^280)
+__global__ void __launch_bounds__(256)
+k_from_canonical(const uint32_t* __restrict__ in, Fr28* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  ld_words8(in + (size_t)i * 8, w);
+  st28(out + i, Fr28::from_canonical(w));
 }
-__global__ void k_from_mont(Fr* __restrict__ a, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) store_fr(a + i, load_fr(a + i).from_mont());
+__global__ void __launch_bounds__(256)
+k_to_canonical(const Fr28* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  ld28(in + i).to_canonical(w);
+  st_words8(out + (size_t)i * 8, w);
 }
 
 }  // namespace
@@ -145,13 +162,6 @@ __global__ void k_from_mont(Fr* __restrict__ a, uint32_t n) {
 // ---------------------------------------------------------------------------
 // host-side driver
 // ---------------------------------------------------------------------------
-static Fr host_fr_from_u64(uint64_t v) {
-  Fr a = Fr::zero();
-  a.l[0] = (uint32_t)v;
-  a.l[1] = (uint32_t)(v >> 32);
-  return a.to_mont();
-}
-
 Fr fr_root_of_unity(int log_n) {
   // 7^((r-1)/2^32), then square down to order 2^log_n
   static const uint32_t ROOT_2_32[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
@@ -163,13 +173,21 @@ Fr fr_root_of_unity(int log_n) {
   return w;
 }
 
+static Fr host_fr_from_u64(uint64_t v) {
+  Fr a = Fr::zero();
+  a.l[0] = (uint32_t)v;
+  a.l[1] = (uint32_t)(v >> 32);
+  return a.to_mont();
+}
+static Fr28 to28(const Fr& a) {
+  Fr c = a.from_mont();
+  return Fr28::from_canonical(c.l);
+}
+
 NttDomain::~NttDomain() {
-  if (tw_fwd) (void)hipFree(tw_fwd);
-  if (tw_inv) (void)hipFree(tw_inv);
-  if (coset_fwd) (void)hipFree(coset_fwd);
-  if (coset_inv) (void)hipFree(coset_inv);
-  if (n_inv) (void)hipFree(n_inv);
-  if (scratch) (void)hipFree(scratch);
+  Fr28* ptrs[] = {tw_fwd, tw_inv, coset_fwd, coset_inv_n, rev_coset_n, rev_coset_inv_n, n_inv, scratch};
+  for (Fr28* p : ptrs)
+    if (p) (void)hipFree(p);
 }
 
 hipError_t NttDomain::init(int log_n_, hipStream_t stream) {
@@ -177,80 +195,125 @@ hipError_t NttDomain::init(int log_n_, hipStream_t stream) {
   const uint32_t n = 1u << log_n;
   const uint32_t half = n > 1 ? n / 2 : 1;
   hipError_t e;
-  if ((e = hipMalloc(&tw_fwd, sizeof(Fr) * half)) != hipSuccess) return e;
-  if ((e = hipMalloc(&tw_inv, sizeof(Fr) * half)) != hipSuccess) return e;
-  if ((e = hipMalloc(&coset_fwd, sizeof(Fr) * n)) != hipSuccess) return e;
-  if ((e = hipMalloc(&coset_inv, sizeof(Fr) * n)) != hipSuccess) return e;
-  if ((e = hipMalloc(&n_inv, sizeof(Fr))) != hipSuccess) return e;
-  if ((e = hipMalloc(&scratch, sizeof(Fr) * n)) != hipSuccess) return e;
-  Fr w = fr_root_of_unity(log_n);
-  Fr wi = w.inv();
-  Fr g = host_fr_from_u64(7);
-  Fr gi = g.inv();
-  Fr ninv = host_fr_from_u64(n).inv();
+  Fr28** alloc_n[] = {&coset_fwd, &coset_inv_n, &rev_coset_n, &rev_coset_inv_n, &scratch};
+  if ((e = hipMalloc(&tw_fwd, sizeof(Fr28) * half)) != hipSuccess) return e;
+  if ((e = hipMalloc(&tw_inv, sizeof(Fr28) * half)) != hipSuccess) return e;
+  if ((e = hipMalloc(&n_inv, sizeof(Fr28))) != hipSuccess) return e;
+  for (Fr28** p : alloc_n)
+    if ((e = hipMalloc(p, sizeof(Fr28) * n)) != hipSuccess) return e;
+  const Fr w = fr_root_of_unity(log_n);
+  const Fr g = host_fr_from_u64(7);
+  const Fr ninv = host_fr_from_u64(n).inv();
+  const Fr28 one28 = Fr28::one(), ninv28 = to28(ninv);
+  n_inv_host = ninv28;
   const int T = 256;
   auto blocks = [&](uint32_t cnt) { return (cnt + 16 * T - 1) / (16 * T); };
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_fwd, w, Fr::one(), half);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_inv, wi, Fr::one(), half);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_fwd, g, Fr::one(), n);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_inv, gi, Fr::one(), n);
-  if ((e = hipMemcpyAsync(n_inv, &ninv, sizeof(Fr), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_fwd, to28(w), one28, half);
+  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_inv, to28(w.inv()), one28, half);
+  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_fwd, to28(g), one28, n);
+  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_inv_n, to28(g.inv()), ninv28, n);
+  // position-indexed tables for bit-reversed coefficient order: entry p <- index rev(p)
+  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, scratch, to28(g), ninv28, n);
+  hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, scratch, rev_coset_n, log_n);
+  hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, coset_inv_n, rev_coset_inv_n, log_n);
+  if ((e = hipMemcpyAsync(n_inv, &ninv28, sizeof(Fr28), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   return hipGetLastError();
 }
 
-// In-place transform of d_data (Montgomery form, natural order).
-hipError_t NttDomain::transform(Fr* d_data, bool inverse, bool coset, hipStream_t stream) {
+// stages [0, log_n) split into passes of <= 10 stages; pass k of a DIT transform
+// covers the low stages first, of a DIF transform the high stages first
+template <bool DIF>
+static hipError_t run_passes(Fr28* buf, const Fr28* tw, int log_n, const Fr28* post, uint32_t* canon_out,
+                             hipStream_t stream) {
   const uint32_t n = 1u << log_n;
-  const int T = 256;
-  if (log_n == 0) return hipSuccess;
-  if (coset && !inverse)
-    hipLaunchKernelGGL(k_mul_pointwise, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_fwd, n);
-  hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, scratch, log_n);
-  // pass plan: S <= 10 stages per pass, Q = 2 adjacent columns for strided passes
-  const Fr* tw = inverse ? tw_inv : tw_fwd;
-  int t0 = 0;
-  Fr* buf = scratch;
-  while (t0 < log_n) {
+  struct Pass {
+    int t0, S, Q;
+  } passes[4];
+  int np = 0;
+  for (int t0 = 0; t0 < log_n;) {
     int S = log_n - t0;
     if (S > 10) S = 10;
-    int Q = 0;
-    if (t0 > 0) Q = (t0 >= 2) ? 2 : t0;
-    // keep tile <= 4096 elements (128 KiB)
-    while (S + Q > 12) S--;
-    const bool last = (t0 + S == log_n);
-    const uint32_t tile_n = 1u << (S + Q);
-    const uint32_t nblk = n / tile_n;
-    const size_t lds = (size_t)tile_n * sizeof(Fr);
-    const Fr* scale = (last && inverse) ? n_inv : nullptr;
-    const Fr* post = (last && inverse && coset) ? coset_inv : nullptr;
-    if (tile_n >= 1024) {
-      hipLaunchKernelGGL(k_ntt_dit_pass<1024>, dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, t0, S, Q,
-                         scale, post);
-    } else {
-      hipLaunchKernelGGL(k_ntt_dit_pass<64>, dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, t0, S, Q,
-                         scale, post);
-    }
+    const int Q = (t0 > 0) ? 1 : 0;
+    passes[np++] = {t0, S, Q};
     t0 += S;
   }
-  hipError_t e = hipMemcpyAsync(d_data, scratch, sizeof(Fr) * n, hipMemcpyDeviceToDevice, stream);
-  if (e != hipSuccess) return e;
+  for (int k = 0; k < np; k++) {
+    const Pass& p = DIF ? passes[np - 1 - k] : passes[k];
+    const bool last = (k == np - 1);
+    const uint32_t tile_n = 1u << (p.S + p.Q);
+    const uint32_t nblk = n / tile_n;
+    const size_t lds = (size_t)tile_n * sizeof(Fr28);
+    const Fr28* pp = last ? post : nullptr;
+    uint32_t* co = last ? canon_out : nullptr;
+    if (tile_n >= 1024)
+      hipLaunchKernelGGL((k_ntt_pass<DIF, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp,
+                         co);
+    else
+      hipLaunchKernelGGL((k_ntt_pass<DIF, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp, co);
+  }
   return hipGetLastError();
 }
 
-hipError_t ntt_to_mont(Fr* d, uint32_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_to_mont, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
+hipError_t NttDomain::inverse_to_rev(Fr28* d, const Fr28* post_table, uint32_t* canon_out, hipStream_t st) {
+  if (log_n == 0) {
+    // single element: only the post factor / output format applies
+    if (post_table) hipLaunchKernelGGL(k_mul_table, dim3(1), dim3(256), 0, st, d, post_table, 1u);
+    if (canon_out) hipLaunchKernelGGL(k_to_canonical, dim3(1), dim3(256), 0, st, d, canon_out, 1u);
+    return hipGetLastError();
+  }
+  return run_passes<true>(d, tw_inv, log_n, post_table, canon_out, st);
+}
+
+hipError_t NttDomain::forward_from_rev(Fr28* d, hipStream_t st) {
+  if (log_n == 0) return hipSuccess;
+  return run_passes<false>(d, tw_fwd, log_n, nullptr, nullptr, st);
+}
+
+// natural order in and out (public entry point)
+hipError_t NttDomain::transform(Fr28* d_data, bool inverse, bool coset, hipStream_t stream) {
+  const uint32_t n = 1u << log_n;
+  const int T = 256;
+  if (coset && !inverse)
+    hipLaunchKernelGGL(k_mul_table, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_fwd, n);
+  if (log_n > 0) {
+    hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, scratch, log_n);
+    hipError_t e = run_passes<false>(scratch, inverse ? tw_inv : tw_fwd, log_n, nullptr, nullptr, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_data, scratch, sizeof(Fr28) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+  }
+  if (inverse) {
+    if (coset) {
+      hipLaunchKernelGGL(k_mul_table, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_inv_n, n);
+    } else {
+      hipLaunchKernelGGL(k_scale, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, n_inv_host, n);
+    }
+  }
   return hipGetLastError();
 }
-hipError_t ntt_from_mont(Fr* d, uint32_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_from_mont, dim3((n + 255) / 256), dim3(256), 0, s, d, n);
+
+hipError_t ntt_from_canonical(const uint32_t* d_in, Fr28* d_out, uint32_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_from_canonical, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  return hipGetLastError();
+}
+hipError_t ntt_to_canonical(const Fr28* d_in, uint32_t* d_out, uint32_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_to_canonical, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  return hipGetLastError();
+}
+hipError_t ntt_mul_table(Fr28* d, const Fr28* table, uint32_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_mul_table, dim3((n + 255) / 256), dim3(256), 0, s, d, table, n);
   return hipGetLastError();
 }
 
 hipError_t ntt_enable_big_lds() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_dit_pass<1024>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass<true, 1024>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e;
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass<false, 1024>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace zkmi
