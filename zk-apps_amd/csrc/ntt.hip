@@ -46,16 +46,22 @@ __global__ void k_bitrev_copy(const Fr28* __restrict__ in, Fr28* __restrict__ ou
 }
 
 // One pass over stages [t0, t0+S).  DIF runs them high -> low, DIT low -> high.
-// tw[k] = w^k (or w^-k), k < N/2.  post (optional): every output is multiplied by
-// post[position].  canon_out (optional): outputs are written as canonical 32-byte
-// integers (8 words) instead of limbs — the digit source of the H MSM.
-template <bool DIF, int THREADS>
+// tw[k] = w^k (or w^-k), k < N/2.
+// LOCAL_TW (transforms of one or two passes): the pass is a pure 2^S-point transform whose
+// 2^(S-1) twiddles are staged in LDS once per workgroup; the cross terms w^(column * row) of
+// the two-pass split are applied once per element ("twist") — at the load of the strided
+// DIT pass, at the store of the strided DIF pass — instead of one global twiddle gather
+// per butterfly.  Without LOCAL_TW (three passes, N > 2^20) twiddles are gathered per butterfly.
+// post (optional): every output is multiplied by post[position].  canon_out (optional):
+// outputs are written as canonical 32-byte integers instead of limbs (H MSM digits).
+template <bool DIF, bool LOCAL_TW, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int t0, int S, int Q,
            const Fr28* __restrict__ post, uint32_t* __restrict__ canon_out) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   Fr28* tile = reinterpret_cast<Fr28*>(lds_raw);
   const uint32_t tile_n = 1u << (S + Q);
+  Fr28* ctw = tile + tile_n;  // LOCAL_TW: w_{2^S}^k, k < 2^(S-1)
   const uint32_t blk = blockIdx.x;
   // tile element L -> global index g:
   //   t0 == 0 : g = blk * tile_n + L
@@ -63,26 +69,47 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
   const uint32_t mid_bits = (t0 > 0) ? (uint32_t)(t0 - Q) : 0u;
   const uint32_t mid = blk & ((1u << mid_bits) - 1u);
   const uint32_t hi = blk >> mid_bits;
+  const uint32_t qeff = (t0 > 0) ? (uint32_t)Q : 0u;
   auto gindex = [&](uint32_t L) -> uint32_t {
     if (t0 == 0) return blk * tile_n + L;
     const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
     return (hi << (t0 + S)) | (e << t0) | (mid << Q) | c;
   };
-  for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) tile[L] = ld28(data + gindex(L));
+  // w^(column * rev_S(row)) for the element at tile position L of a strided pass
+  auto twist = [&](uint32_t L) -> Fr28 {
+    const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
+    const uint32_t col = (mid << Q) | c;
+    const uint32_t ex = col * (__brev(e) >> (32 - S));
+    const uint32_t halfn = 1u << (log_n - 1);
+    Fr28 f = ld28(tw + (ex & (halfn - 1u)));
+    return (ex & halfn) ? f.neg() : f;
+  };
+  if (LOCAL_TW)
+    for (uint32_t k = threadIdx.x; k < (1u << (S - 1)); k += THREADS) ctw[k] = ld28(tw + ((size_t)k << (log_n - S)));
+  for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
+    Fr28 v = ld28(data + gindex(L));
+    if (LOCAL_TW && !DIF && t0 > 0) v = v * twist(L);
+    tile[L] = v;
+  }
   __syncthreads();
 
   const uint32_t half = tile_n >> 1;
   for (int s = 0; s < S; s++) {
     const int u = DIF ? (S - 1 - s) : s;
     const int t = t0 + u;  // global stage: butterfly distance 2^t
-    const uint32_t dist_log = (t0 == 0) ? (uint32_t)u : (uint32_t)(u + Q);
+    const uint32_t dist_log = (uint32_t)u + qeff;
     const uint32_t dist = 1u << dist_log;
     for (uint32_t b = threadIdx.x; b < half; b += THREADS) {
       const uint32_t lo = b & (dist - 1u);
       const uint32_t L0 = ((b >> dist_log) << (dist_log + 1)) | lo;
       const uint32_t L1 = L0 | dist;
-      const uint32_t j = gindex(L0) & ((1u << t) - 1u);
-      const Fr28 w = ld28(tw + ((size_t)j << (log_n - 1 - t)));
+      Fr28 w;
+      if (LOCAL_TW) {
+        w = ctw[(lo >> qeff) << (S - 1 - u)];
+      } else {
+        const uint32_t j = gindex(L0) & ((1u << t) - 1u);
+        w = ld28(tw + ((size_t)j << (log_n - 1 - t)));
+      }
       const Fr28 x = tile[L0];
       if (DIF) {
         const Fr28 y = tile[L1];
@@ -100,6 +127,7 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
   for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
     const uint32_t g = gindex(L);
     Fr28 v = tile[L];
+    if (LOCAL_TW && DIF && t0 > 0) v = v * twist(L);
     if (post) v = v * ld28(post + g);
     if (canon_out) {
       uint32_t w[8];
@@ -234,23 +262,35 @@ static hipError_t run_passes(Fr28* buf, const Fr28* tw, int log_n, const Fr28* p
   for (int t0 = 0; t0 < log_n;) {
     int S = log_n - t0;
     if (S > 10) S = 10;
-    const int Q = (t0 > 0) ? 1 : 0;
+    // strided passes: 2 adjacent columns; the contiguous pass: 2 sub-transforms per
+    // workgroup so that all 1024 threads own a butterfly in every stage
+    const int Q = (t0 > 0) ? 1 : ((log_n > S) ? 1 : 0);
     passes[np++] = {t0, S, Q};
     t0 += S;
   }
+  const bool local_tw = np <= 2;
   for (int k = 0; k < np; k++) {
     const Pass& p = DIF ? passes[np - 1 - k] : passes[k];
     const bool last = (k == np - 1);
     const uint32_t tile_n = 1u << (p.S + p.Q);
     const uint32_t nblk = n / tile_n;
-    const size_t lds = (size_t)tile_n * sizeof(Fr28);
+    const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(Fr28);
     const Fr28* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
-    if (tile_n >= 1024)
-      hipLaunchKernelGGL((k_ntt_pass<DIF, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp,
-                         co);
-    else
-      hipLaunchKernelGGL((k_ntt_pass<DIF, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp, co);
+    if (tile_n >= 1024) {
+      if (local_tw)
+        hipLaunchKernelGGL((k_ntt_pass<DIF, true, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
+                           p.Q, pp, co);
+      else
+        hipLaunchKernelGGL((k_ntt_pass<DIF, false, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
+                           p.S, p.Q, pp, co);
+    } else if (local_tw) {
+      hipLaunchKernelGGL((k_ntt_pass<DIF, true, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+                         pp, co);
+    } else {
+      hipLaunchKernelGGL((k_ntt_pass<DIF, false, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+                         pp, co);
+    }
   }
   return hipGetLastError();
 }
@@ -309,11 +349,15 @@ hipError_t ntt_mul_table(Fr28* d, const Fr28* table, uint32_t n, hipStream_t s) 
 }
 
 hipError_t ntt_enable_big_lds() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass<true, 1024>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_pass<false, 1024>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass<true, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<false, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<true, false, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<false, false, 1024>)};
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace zkmi
