@@ -248,3 +248,71 @@ def test_groth16_batch_matches_single(ctx, zk):
     for w, pf in zip(wits, batch):
         assert zk.groth16_verify(vk, w[32 : 32 * r1.n_pub], pf) is True
     pk.free()
+
+
+def _torch_scalars(n, seed):
+    """n canonical scalars (< 2^254) generated in HBM + the two sums the closed form needs."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x3F
+    idx = torch.arange(n, dtype=torch.int64, device="cuda")
+    s0 = raw.to(torch.int64).sum(dim=0).cpu().tolist()
+    s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0).cpu().tolist()
+    tot = sum(v << (8 * k) for k, v in enumerate(s0)) % R
+    wtot = sum(v << (8 * k) for k, v in enumerate(s1)) % R
+    return raw, tot, wtot
+
+
+def _closed_form_g1(tot, wtot):
+    q = ec.g1_mul(0xC0FFEE)
+    return ec.g1_to_bytes(ec.pt_add(ec.Fq, ec.g1_mul(tot), ec.g1_mul(wtot, q)))
+
+
+def test_msm_g1_point_split_matches_full(ctx, zk):
+    """BASELINE config 3 logic on one GPU: two point-slices -> per-window partials ->
+    zkmi_msm_g1_combine == the unsplit MSM == the closed form."""
+    import torch
+
+    n = 1 << 18
+    raw, tot, wtot = _torch_scalars(n, 11)
+    b = ctx.bases_g1_synthetic(n)
+    full = ctx.msm_g1_dev(raw.data_ptr(), n, b)
+    assert full == _closed_form_g1(tot, wtot)
+    half = n // 2
+    lo = ctx.bases_g1(b.read(0, half), check=False)
+    hi = ctx.bases_g1(b.read(half, half), check=False)
+    w0, nwin, cb = ctx.msm_g1_windows_dev(raw.data_ptr(), half, lo, n)
+    w1, nwin1, cb1 = ctx.msm_g1_windows_dev(raw[half:].data_ptr(), half, hi, n)
+    assert (nwin, cb) == (nwin1, cb1)
+    assert zk.msm_g1_combine(w0 + w1, 2, nwin, cb) == full
+    for x in (b, lo, hi):
+        x.free()
+
+
+def test_msm_g1_2p26_single_gpu(ctx):
+    """BASELINE config 3 size (n = 2^26, 8 GiB of algorithmic bytes) on one GPU."""
+    import torch
+
+    n = 1 << 26
+    raw, tot, wtot = _torch_scalars(n, 26)
+    b = ctx.bases_g1_synthetic(n)
+    got = ctx.msm_g1_dev(raw.data_ptr(), n, b)
+    assert got == _closed_form_g1(tot, wtot)
+    b.free()
+    del raw
+    torch.cuda.empty_cache()
+
+
+def test_groth16_2p22_with_g2_and_pairing(ctx, zk):
+    """BASELINE config 4: full proof at N = 2^22 (G2 MSM of 2^22 - 1 terms on the Fq2
+    path), checked by the CPU pairing verifier."""
+    lg = 22
+    r1 = zk.shielder_r1cs(lg)
+    z = zk.shielder_witness(lg, 0x5A4B0004)
+    rng = ec.SplitMix64(0x5A4B0044)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
+    assert zk.groth16_verify(vk, z[32 : 32 * r1.n_pub], proof) is True
+    pk.free()
