@@ -79,7 +79,9 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreate(&c->stream) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+      hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ZKMI_ERR_HIP;
   }
@@ -106,6 +108,8 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
+  if (ctx->stream_g2) (void)hipStreamDestroy(ctx->stream_g2);
+  if (ctx->ev_sort) (void)hipEventDestroy(ctx->ev_sort);
   delete ctx;
   return ZKMI_OK;
 }
@@ -116,6 +120,7 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_g2));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -134,6 +139,7 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream_aux);
+  (void)hipStreamSynchronize(ctx->stream_g2);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];

@@ -14,6 +14,8 @@ struct zkmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_aux = nullptr;  // MSM reductions: overlap the next accumulation
+  hipStream_t stream_g2 = nullptr;   // G2 accumulation beside the G1 ones
+  hipEvent_t ev_sort = nullptr;
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;

@@ -495,10 +495,15 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
   // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z + 1);
   ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
+  // the G2 accumulation runs on its own stream beside the three G1 ones (same sort, disjoint
+  // outputs): the kernels' drain tails overlap instead of adding up
+  ZK_HIP(ctx, hipEventRecord(ctx->ev_sort, st));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort, 0));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 0));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 1));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 2));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
+  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->g2.acc_done[g2s], 0));  // the next sort re-uses the sort buffers
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
   // infinity.  Re-uses the sort buffers: stream order keeps it behind the four MSMs above.
   ZK_HIP(ctx, ctx->sort.run(pk->d_h, N, st, t));

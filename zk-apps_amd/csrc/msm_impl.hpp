@@ -57,7 +57,7 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
-template <class F>
+template <class F, bool PREFETCH>
 __global__ void __launch_bounds__(256)
 k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
         const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
@@ -69,11 +69,27 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
   if (cnt > MSM_HEAVY) return;  // k_accum_heavy owns it
   const uint32_t beg = begin[b], end = beg + cnt;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  for (uint32_t j = beg; j < end; j++) {
-    const uint32_t v = sorted[j];
-    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
-    if (v >> 31) p.y = p.y.neg();
-    acc.madd(p);
+  if (PREFETCH) {
+    // software pipeline: the next point's gather is in flight during this mixed addition
+    uint32_t vn = cnt ? sorted[beg] : 0u;
+    Affine<F> pn = load_vec(bases + (vn & 0x7fffffffu));
+    for (uint32_t j = beg; j < end; j++) {
+      const uint32_t v = vn;
+      Affine<F> p = pn;
+      if (j + 1 < end) {
+        vn = sorted[j + 1];
+        pn = load_vec(bases + (vn & 0x7fffffffu));
+      }
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+  } else {
+    for (uint32_t j = beg; j < end; j++) {
+      const uint32_t v = sorted[j];
+      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
   }
   store_vec(buckets + b, acc);
 }
@@ -233,7 +249,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
   if (prof) prof->begin(ph_accum, st);
-  hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+  hipLaunchKernelGGL((k_accum<F, (sizeof(F) <= 64)>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
                      sort.perm, sort.sorted, bk, tot_b);
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(512), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
                      sort.begin, sort.count, sort.heavy, sort.sorted, bk);
