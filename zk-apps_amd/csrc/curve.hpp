@@ -87,10 +87,10 @@ struct XYZZ {
       zzz = F::one();
       return;
     }
-    F u2 = p.x * zz;
-    F s2 = p.y * zzz;
-    F pp_ = f_sub_lazy(u2, x);
-    F r = f_sub_lazy(s2, y);
+    // statement order keeps live ranges short (the accumulator, one point and the
+    // 64-bit product columns must fit 256 VGPRs for 2 waves per SIMD)
+    F pp_ = f_sub_lazy(p.x * zz, x);
+    F r = f_sub_lazy(p.y * zzz, y);
     // zero tests are made on products (P = 0 <=> P^2 = 0): exact for every
     // field representation, including the lazily reduced device limbs
     F pp = pp_.sqr();
@@ -104,12 +104,11 @@ struct XYZZ {
       return;
     }
     F ppp = pp_ * pp;
-    F q = x * pp;
-    F x3 = f_x3(rr, ppp, q);
-    y = f_mul_sub_mul(r, f_sub_lazy(q, x3), y, ppp);
-    x = x3;
     zz = zz * pp;
     zzz = zzz * ppp;
+    F q = x * pp;
+    x = f_x3(rr, ppp, q);
+    y = f_mul_sub_mul(r, f_sub_lazy(q, x), y, ppp);
   }
 
   // this += o

@@ -57,8 +57,18 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
+#ifndef ZK_ACCUM_PREFETCH
+#define ZK_ACCUM_PREFETCH false
+#endif
+// G1 (14-limb coordinates): 248 VGPRs -> 2 waves per SIMD.  G2 needs ~330 registers
+// (accumulator 112 + point 56 + columns 56 + temporaries) and runs at 1 wave per SIMD with
+// cheap AGPR spills; forcing 2 waves sends 350+ values to scratch and is 2x slower.
+template <class F>
+struct AccumWaves {
+  static constexpr int value = (sizeof(F) <= 64) ? 2 : 1;  // measured: forcing 3 for G1 spills around the rare-path calls and is 25 % slower
+};
 template <class F, bool PREFETCH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, AccumWaves<F>::value)
 k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
         const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
         const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets) {
@@ -249,7 +259,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
   if (prof) prof->begin(ph_accum, st);
-  hipLaunchKernelGGL((k_accum<F, (sizeof(F) <= 64)>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+  hipLaunchKernelGGL((k_accum<F, ZK_ACCUM_PREFETCH>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
                      sort.perm, sort.sorted, bk, tot_b);
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(512), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
                      sort.begin, sort.count, sort.heavy, sort.sorted, bk);
