@@ -362,6 +362,102 @@ ZK_HD Fq2_28 f_mul_sub_mul(const Fq2_28& a, const Fq2_28& b, const Fq2_28& c, co
   return out;
 }
 
+// ---- Fq2 split across a lane pair (device only) ----------------------------------
+// A full Fq2 mixed addition needs ~330 registers per lane (1 wave per SIMD).  Here the
+// two components of every Fq2 value live in two adjacent lanes (even lane: c0, odd
+// lane: c1), the partner's limbs are fetched with DPP quad_perm(1,0,3,2) moves when a
+// product needs them, and each lane computes one component with ONE Montgomery
+// reduction.  State per lane is that of a G1 addition (2 waves per SIMD), the pair
+// does the same number of partial products as the unsplit form.
+#if defined(__HIPCC__)
+struct Fq2P {
+  Fq28 v;  // this lane's component
+  __device__ __forceinline__ static bool odd() { return (threadIdx.x & 1u) != 0; }
+  __device__ __forceinline__ static Fq28 partner(const Fq28& a) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], 0xB1, 0xF, 0xF, true);
+    return r;
+  }
+  __device__ __forceinline__ static Fq28 sel(bool c, const Fq28& a, const Fq28& b) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+  }
+  __device__ __forceinline__ static Fq28 negl(const Fq28& a) {  // lazy negation (limb-wise)
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) r.l[i] = -a.l[i];
+    return r;
+  }
+  __device__ __forceinline__ static Fq2P zero() { return {Fq28::zero()}; }
+  __device__ __forceinline__ static Fq2P one() { return {odd() ? Fq28::zero() : Fq28::one()}; }
+  __device__ __forceinline__ bool is_zero() const {
+    const int mine = v.is_zero() ? 1 : 0;
+    const int other = __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xF, 0xF, true);
+    return (mine & other) != 0;
+  }
+  __device__ __forceinline__ friend Fq2P operator+(const Fq2P& a, const Fq2P& b) { return {a.v + b.v}; }
+  __device__ __forceinline__ friend Fq2P operator-(const Fq2P& a, const Fq2P& b) { return {a.v - b.v}; }
+  __device__ __forceinline__ Fq2P neg() const { return {v.neg()}; }
+  __device__ __forceinline__ Fq2P dbl() const { return {v.dbl()}; }
+  // component = a.v * X + partner(a) * Y with
+  //   even lane (c0 = a0 b0 - a1 b1): X = b.v,        Y = -partner(b)
+  //   odd  lane (c1 = a1 b0 + a0 b1): X = partner(b), Y = b.v
+  __device__ __forceinline__ static void mul_cols(int64_t* T, const Fq2P& a, const Fq2P& b, bool negate) {
+    constexpr int NL = Fq28::NL;
+    const bool o = odd();
+    // two sequential product phases keep only one partner copy + one selected operand live
+    {
+      const Fq28 pb = partner(b.v);
+      Fq28 X = sel(o, pb, b.v);
+      if (negate) X = negl(X);
+#pragma unroll
+      for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.v.l[i] * X.l[j];
+    }
+    {
+      const Fq28 pa = partner(a.v);
+      Fq28 Y = sel(o, b.v, negl(partner(b.v)));
+      if (negate) Y = negl(Y);
+#pragma unroll
+      for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) T[i + j] += (int64_t)pa.l[i] * Y.l[j];
+    }
+  }
+  __device__ __forceinline__ friend Fq2P operator*(const Fq2P& a, const Fq2P& b) {
+    int64_t T[2 * Fq28::NL];
+#pragma unroll
+    for (int i = 0; i < 2 * Fq28::NL; i++) T[i] = 0;
+    mul_cols(T, a, b, false);
+    return {Fq28::reduce(T)};
+  }
+  // even: (a0 + a1)(a0 - a1); odd: (2 a0) a1   — one product per lane
+  __device__ __forceinline__ Fq2P sqr() const {
+    const bool o = odd();
+    const Fq28 p = partner(v);
+    const Fq28 X = sel(o, p.add_lazy(p), v.add_lazy(p));
+    const Fq28 Y = sel(o, v, v.sub_lazy(p));
+    return {Fq28::mul_inline(X, Y)};
+  }
+};
+// a b - c d, one reduction per lane (4 x 14 products of < 2^56 per column)
+__device__ __forceinline__ Fq2P f_mul_sub_mul(const Fq2P& a, const Fq2P& b, const Fq2P& c, const Fq2P& d) {
+  int64_t T[2 * Fq28::NL];
+#pragma unroll
+  for (int i = 0; i < 2 * Fq28::NL; i++) T[i] = 0;
+  Fq2P::mul_cols(T, a, b, false);
+  Fq2P::mul_cols(T, c, d, true);
+  return {Fq28::reduce(T)};
+}
+__device__ __forceinline__ Fq2P f_x3(const Fq2P& rr, const Fq2P& ppp, const Fq2P& q) {
+  return {f_x3(rr.v, ppp.v, q.v)};
+}
+#endif  // __HIPCC__
+
 // conversions between the host/old representation (12x32, R = 2^384) and Fq28
 ZK_HD Fq28 fq28_from_fq(const Fq& a) {
   Fq c = a.from_mont();

@@ -27,6 +27,7 @@
 //                 segsum over {t : bit j of t set}
 //   host: window_w = P[w][0] + SEG * sum_j 2^j P[w][1+j];  result = sum_w 2^(c w) window_w
 #pragma once
+#include <type_traits>
 #include <vector>
 #include "curve.hpp"
 #include "msm.hpp"
@@ -102,6 +103,56 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
     }
   }
   store_vec(buckets + b, acc);
+}
+
+// G2 accumulation with every Fq2 value split across a lane pair (field28.hpp Fq2P):
+// two adjacent lanes own one bucket; per-lane state is that of a G1 addition, so the
+// kernel runs at 2 waves per SIMD instead of 1.  Memory layouts are the unsplit ones
+// (x.c0, x.c1, y.c0, y.c1, ...): a lane simply reads / writes its own components.
+__device__ __forceinline__ Fq28 ld_comp(const Fq28* p) {
+  Fq28 r;
+  const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const uint2 w = q[i];
+    r.l[2 * i] = (int32_t)w.x;
+    r.l[2 * i + 1] = (int32_t)w.y;
+  }
+  return r;
+}
+__device__ __forceinline__ void st_comp(Fq28* p, const Fq28& v) {
+  uint2* q = reinterpret_cast<uint2*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; i++) q[i] = make_uint2((uint32_t)v.l[2 * i], (uint32_t)v.l[2 * i + 1]);
+}
+
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256, 2)
+k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+                 const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
+                 const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt >> 1, comp = gt & 1u;
+  if (t >= total_buckets) return;  // pair-uniform
+  const uint32_t b = perm[t];
+  const uint32_t cnt = count[b];
+  if (cnt > MSM_HEAVY) return;
+  const uint32_t beg = begin[b], end = beg + cnt;
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  for (uint32_t j = beg; j < end; j++) {
+    const uint32_t v = sorted[j];
+    const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
+    Affine<Fq2P> p;
+    p.x.v = ld_comp(src + comp);
+    p.y.v = ld_comp(src + 2 + comp);
+    if (v >> 31) p.y = p.y.neg();
+    acc.madd(p);
+  }
+  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+  st_comp(dst + comp, acc.x.v);
+  st_comp(dst + 2 + comp, acc.y.v);
+  st_comp(dst + 4 + comp, acc.zz.v);
+  st_comp(dst + 6 + comp, acc.zzz.v);
 }
 
 // one workgroup per heavy bucket: strided partial sums, then an LDS tree
@@ -259,8 +310,13 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
   if (prof) prof->begin(ph_accum, st);
-  hipLaunchKernelGGL((k_accum<F, ZK_ACCUM_PREFETCH>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                     sort.perm, sort.sorted, bk, tot_b);
+  if constexpr (std::is_same<F, Fq2_28>::value) {
+    hipLaunchKernelGGL(k_accum_g2_split<0>, dim3((2 * tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+                       sort.perm, sort.sorted, bk, tot_b);
+  } else {
+    hipLaunchKernelGGL((k_accum<F, ZK_ACCUM_PREFETCH>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,
+                       sort.count, sort.perm, sort.sorted, bk, tot_b);
+  }
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(512), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
                      sort.begin, sort.count, sort.heavy, sort.sorted, bk);
   if (prof) prof->end(ph_accum, st);
