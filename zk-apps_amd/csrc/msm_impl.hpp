@@ -206,6 +206,42 @@ k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, X
   store_vec(segw + t, acc);
 }
 
+// lane-pair split forms of the two reduction kernels for G2 (see k_accum_g2_split)
+__device__ __forceinline__ XYZZ<Fq2P> ld_xyzz_split(const XYZZ<Fq2_28>* p, uint32_t comp) {
+  const Fq28* s = reinterpret_cast<const Fq28*>(p);
+  XYZZ<Fq2P> r;
+  r.x.v = ld_comp(s + comp);
+  r.y.v = ld_comp(s + 2 + comp);
+  r.zz.v = ld_comp(s + 4 + comp);
+  r.zzz.v = ld_comp(s + 6 + comp);
+  return r;
+}
+__device__ __forceinline__ void st_xyzz_split(XYZZ<Fq2_28>* p, const XYZZ<Fq2P>& v, uint32_t comp) {
+  Fq28* d = reinterpret_cast<Fq28*>(p);
+  st_comp(d + comp, v.x.v);
+  st_comp(d + 2 + comp, v.y.v);
+  st_comp(d + 4 + comp, v.zz.v);
+  st_comp(d + 6 + comp, v.zzz.v);
+}
+
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256, 2)
+k_segreduce_g2_split(const XYZZ<Fq2_28>* __restrict__ buckets, XYZZ<Fq2_28>* __restrict__ segsum,
+                     XYZZ<Fq2_28>* __restrict__ segw, uint32_t total_segs) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt >> 1, comp = gt & 1u;
+  if (t >= total_segs) return;  // pair-uniform
+  XYZZ<Fq2P> run = XYZZ<Fq2P>::infinity();
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  for (int i = MSM_SEG - 1; i >= 0; i--) {
+    XYZZ<Fq2P> bk = ld_xyzz_split(buckets + (size_t)t * MSM_SEG + i, comp);
+    run.add(bk);
+    acc.add(run);
+  }
+  st_xyzz_split(segsum + t, run, comp);
+  st_xyzz_split(segw + t, acc, comp);
+}
+
 // grid = (njobs, nwin).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t]
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
@@ -325,7 +361,12 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   if (prof) prof->begin(ph_reduce, st_reduce);
   const uint32_t segs_per_win = pl.nb / MSM_SEG;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
-  hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs);
+  if constexpr (std::is_same<F, Fq2_28>::value) {
+    hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw,
+                       tot_segs);
+  } else {
+    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs);
+  }
   const int njobs = 1 + msm_seg_bits(pl);
   XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
   hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
