@@ -181,6 +181,29 @@ struct Fp28 {
     return reduce(T);
   }
 
+  // Fermat inverse x^(m-2) (0 -> 0); table construction only, never on the proving path
+  __host__ __device__ Fp28 inv() const {
+    int32_t e[NL];
+    for (int i = 0; i < NL; i++) e[i] = P::MOD[i];
+    e[0] -= 2;
+    for (int i = 0; i < NL - 1; i++)
+      if (e[i] < 0) {
+        e[i] += (1 << 28);
+        e[i + 1] -= 1;
+      }
+    Fp28 res = one();
+    bool started = false;
+    for (int i = NL - 1; i >= 0; i--)
+      for (int b = 27; b >= 0; b--) {
+        if (started) res = res.sqr();
+        if ((e[i] >> b) & 1) {
+          res = started ? res * (*this) : *this;
+          started = true;
+        }
+      }
+    return res;
+  }
+
   // exact for |v| <= 4p (see header): v == k p for some |k| <= 4
   ZK_HD bool is_zero() const {
     // top limbs of the normalised representations of k*p, k = -4..4

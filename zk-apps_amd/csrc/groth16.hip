@@ -17,6 +17,7 @@
 //                          stored padded with n_pub-1 infinities so it lines up)
 //   MSM G1 x3, MSM G2 x1, digit-sort(h), MSM G1 (H)
 //   host: O(1) scalar multiplications, compression to 192 bytes
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -111,6 +112,10 @@ struct zkmi_pk {
   // the same queries in the device MSM representation (28-bit limbs)
   Affine<Fq28>*a28 = nullptr, *b1_28 = nullptr, *h28 = nullptr, *h28_rev = nullptr, *l28 = nullptr;
   Affine<Fq2_28>* b2_28 = nullptr;
+  // shared-bucket MSM tables: entry [w * n + i] = 2^(c w) * query[i] (msm_impl.hpp)
+  bool shared = false;
+  Affine<Fq28>*a_tab = nullptr, *b1_tab = nullptr, *l_tab = nullptr, *h_tab = nullptr;
+  Affine<Fq2_28>* b2_tab = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
   Fr* d_z = nullptr;  // witness, canonical words (digit source of the A/B/L MSMs)
@@ -122,7 +127,8 @@ struct zkmi_pk {
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
-    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, d_h, a28, b1_28, h28, h28_rev, l28, b2_28};
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, d_h, a28, b1_28, h28, h28_rev, l28, b2_28,
+                    a_tab, b1_tab, l_tab, h_tab, b2_tab};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
   }
@@ -191,7 +197,24 @@ static hipError_t pk_convert_queries(zkmi_pk* pk) {
   hipLaunchKernelGGL(k_bitrev_points<Affine<Fq28>>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->h28,
                      pk->h28_rev, (int)pk->log_n);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  return hipStreamSynchronize(st);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  // Precomputed tables 2^(c w) * P_i for every digit position (HBM is 288 GB: ~9 GB of
+  // tables at N = 2^20): all digits of a scalar then share ONE bucket set, so the digit
+  // width can grow to c = 20 (13 digits instead of 16 -> 19 % fewer bucket insertions)
+  // and the host no longer walks a 255-doubling Horner chain.  ZKMI_MSM_SHARED=0 disables.
+  const char* env = getenv("ZKMI_MSM_SHARED");
+  pk->shared = !(env && env[0] == '0');
+  if (pk->shared) {
+    const uint64_t nz = pk->n_vars - 1;
+    const MsmPlan pz = msm_make_plan_shared(nz), ph = msm_make_plan_shared(N);
+    if ((e = msm_build_table<Fq28>(pk->a28 + 1, nz, pz, &pk->a_tab, st)) != hipSuccess) return e;
+    if ((e = msm_build_table<Fq28>(pk->b1_28 + 1, nz, pz, &pk->b1_tab, st)) != hipSuccess) return e;
+    if ((e = msm_build_table<Fq28>(pk->l28 + 1, nz, pz, &pk->l_tab, st)) != hipSuccess) return e;
+    if ((e = msm_build_table<Fq2_28>(pk->b2_28 + 1, nz, pz, &pk->b2_tab, st)) != hipSuccess) return e;
+    if ((e = msm_build_table<Fq28>(pk->h28_rev, N, ph, &pk->h_tab, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 static Fr fr_from_u64(uint64_t v) {
@@ -494,20 +517,32 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
   // MSM's reduction runs on the aux stream behind its accumulation and leaves the
   // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z + 1);
-  ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
+  const bool sh = pk->shared;
+  if (sh)
+    ZK_HIP(ctx, ctx->sort.run_shared(zs, nv - 1, st, t));
+  else
+    ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
   // the G2 accumulation runs on its own stream beside the three G1 ones (same sort, disjoint
   // outputs): the kernels' drain tails overlap instead of adding up
   ZK_HIP(ctx, hipEventRecord(ctx->ev_sort, st));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort, 0));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 0));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 1));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 2));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t,
+                                 PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->a_tab : pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, s0 + 0));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->b1_tab : pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, s0 + 1));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, s0 + 2));
   ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->g2.acc_done[g2s], 0));  // the next sort re-uses the sort buffers
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
   // infinity.  Re-uses the sort buffers: stream order keeps it behind the four MSMs above.
-  ZK_HIP(ctx, ctx->sort.run(pk->d_h, N, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 3));
+  if (sh)
+    ZK_HIP(ctx, ctx->sort.run_shared(pk->d_h, N, st, t));
+  else
+    ZK_HIP(ctx, ctx->sort.run(pk->d_h, N, st, t));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->h_tab : pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, s0 + 3));
   return ZKMI_OK;
 }
 

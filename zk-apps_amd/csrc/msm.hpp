@@ -37,13 +37,18 @@ enum Phase {
 };
 
 struct MsmPlan {
-  int c = 0;        // window bits (signed digits)
-  int nwin = 0;     // number of windows
-  uint32_t nb = 0;  // buckets per window = 2^(c-1)
+  int c = 0;        // digit bits (signed digits)
+  int nwin = 0;     // windowed: number of windows;  shared: number of 2^15-bucket partitions
+  uint32_t nb = 0;  // windowed: buckets per window = 2^(c-1);  shared: buckets per partition
   uint64_t n = 0;
+  // shared-bucket mode (precomputed tables 2^(c w) P_i, see msm_impl.hpp): all
+  // ndigits digits of a scalar land in ONE bucket set of 2^(c-1) = nwin * nb buckets
+  bool shared = false;
+  int ndigits = 0;
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);
+MsmPlan msm_make_plan_shared(uint64_t n);
 
 // Bucket scatter: signed-digit decomposition + counting sort of point indices
 // by (window, bucket).  Shared by every MSM over the same scalar vector.
@@ -53,6 +58,7 @@ struct MsmSort {
   uint32_t* blockhist = nullptr;  // nwin*nch*nb  per-(window, chunk) tile histogram -> tile base slots
   uint32_t* perm = nullptr;       // nwin*nb   bucket ids ordered by descending load (per window)
   uint32_t* heavy = nullptr;      // [0] = number of heavy buckets, [1..] their ids
+  uint32_t* part_total = nullptr; // shared mode: entries per partition
   uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
@@ -61,6 +67,8 @@ struct MsmSort {
   void release();
   hipError_t reserve(uint64_t n);
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
+  // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
+  hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
 };
 
 // device field F (lazily reduced 28-bit limbs) <-> host field (32-bit limbs)
@@ -105,8 +113,15 @@ hipError_t bases_convert(const Affine<typename HostFieldOf<F>::type>* d_in, Affi
 template <class HF>
 XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c);
 
+// table[w * n + i] = 2^(c w) * bases[i], w < ndigits (device format, affine)
+template <class F>
+hipError_t msm_build_table(const Affine<F>* d_bases, uint64_t n, const MsmPlan& plan, Affine<F>** out_table,
+                           hipStream_t st);
+
 extern template struct MsmEngine<Fq28>;
 extern template struct MsmEngine<Fq2_28>;
+extern template hipError_t msm_build_table<Fq28>(const Affine<Fq28>*, uint64_t, const MsmPlan&, Affine<Fq28>**, hipStream_t);
+extern template hipError_t msm_build_table<Fq2_28>(const Affine<Fq2_28>*, uint64_t, const MsmPlan&, Affine<Fq2_28>**, hipStream_t);
 extern template hipError_t bases_convert<Fq28>(const Affine<Fq>*, Affine<Fq28>*, uint64_t, hipStream_t);
 extern template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
 

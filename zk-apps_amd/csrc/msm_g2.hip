@@ -4,6 +4,7 @@
 #include "msm_impl.hpp"
 namespace zkmi {
 template struct MsmEngine<Fq2_28>;
+template hipError_t msm_build_table<Fq2_28>(const Affine<Fq2_28>*, uint64_t, const MsmPlan&, Affine<Fq2_28>**, hipStream_t);
 template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
 template XYZZ<Fq2> msm_combine_windows<Fq2>(const XYZZ<Fq2>*, int, int);
 }  // namespace zkmi

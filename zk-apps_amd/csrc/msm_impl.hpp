@@ -242,11 +242,12 @@ k_segreduce_g2_split(const XYZZ<Fq2_28>* __restrict__ buckets, XYZZ<Fq2_28>* __r
   st_xyzz_split(segw + t, acc, comp);
 }
 
-// grid = (njobs, nwin).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t]
+// grid = (njobs, nwin).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t];
+// job plain_job (shared-bucket mode only): sum_t segsum[w][t]
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, uint32_t segs_per_win,
-          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial) {
+          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial, int plain_job) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const int job = blockIdx.x;
@@ -254,7 +255,7 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
   const XYZZ<F>* src = (job == 0 ? segw : segsum) + (size_t)w * segs_per_win;
   XYZZ<F> acc = XYZZ<F>::infinity();
   for (uint32_t t = threadIdx.x; t < segs_per_win; t += blockDim.x) {
-    if (job == 0 || ((t >> (job - 1)) & 1u)) {
+    if (job == 0 || job == plain_job || ((t >> (job - 1)) & 1u)) {
       XYZZ<F> v = load_vec(src + t);
       acc.add(v);
     }
@@ -367,10 +368,11 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   } else {
     hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs);
   }
-  const int njobs = 1 + msm_seg_bits(pl);
+  const int plain_job = pl.shared ? 1 + msm_seg_bits(pl) : -1;
+  const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
   XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
   hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                     segsum, segw, segs_per_win, dp);
+                     segsum, segw, segs_per_win, dp, plain_job);
   if (prof) prof->end(ph_reduce, st_reduce);
   e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
                      hipMemcpyDeviceToHost, st_reduce);
@@ -383,7 +385,7 @@ template <class F>
 hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
   const MsmPlan& pl = slot_plan[slot];
   const int seg_bits = msm_seg_bits(pl);
-  const int njobs = 1 + seg_bits;
+  const int njobs = 1 + seg_bits + (pl.shared ? 1 : 0);
   hipError_t e = hipEventSynchronize(done[slot]);
   if (e != hipSuccess) return e;
   const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
@@ -412,11 +414,60 @@ XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c) {
 
 template <class F>
 hipError_t MsmEngine<F>::finish_host(XYZZ<HF>* out, int slot) {
-  std::vector<XYZZ<HF>> win(slot_plan[slot].nwin);
+  const MsmPlan& pl = slot_plan[slot];
+  std::vector<XYZZ<HF>> win(pl.nwin);
   hipError_t e = finish_host_windows(win.data(), slot);
   if (e != hipSuccess) return e;
-  *out = msm_combine_windows(win.data(), slot_plan[slot].nwin, slot_plan[slot].c);
+  if (!pl.shared) {
+    *out = msm_combine_windows(win.data(), pl.nwin, pl.c);
+    return hipSuccess;
+  }
+  // shared buckets: partition q holds buckets q*nb + j (digit value q*nb + j + 1):
+  //   sum_b (b+1) B_b = sum_q U_q + nb * sum_q q * S_q,   S_q = plain sum of partition q
+  const int njobs = 2 + msm_seg_bits(pl);
+  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
+  XYZZ<HF> run = XYZZ<HF>::infinity(), t = XYZZ<HF>::infinity(), total = XYZZ<HF>::infinity();
+  for (int q = pl.nwin - 1; q >= 1; q--) {
+    run.add(h[(size_t)q * njobs + (njobs - 1)]);
+    t.add(run);
+  }
+  for (uint32_t b = pl.nb; b > 1; b >>= 1) t.dbl_inplace();
+  for (int q = 0; q < pl.nwin; q++) total.add(win[q]);
+  total.add(t);
+  *out = total;
   return hipSuccess;
+}
+
+// table[w * n + i] = 2^(c w) * bases[i]: one thread per base point walks the digits
+template <class F>
+__global__ void __launch_bounds__(64)
+k_build_table(const Affine<F>* __restrict__ bases, Affine<F>* __restrict__ table, uint32_t n, int ndigits, int c) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine<F> p = load_vec(bases + i);
+  XYZZ<F> cur = XYZZ<F>::from_affine(p);
+  store_vec(table + i, p);
+  for (int w = 1; w < ndigits; w++) {
+    for (int k = 0; k < c; k++) cur.dbl_inplace();
+    const Affine<F> a = cur.to_affine();
+    // points at infinity must be exact zeros (the accumulate kernels test limbs)
+    Affine<F> o = cur.is_inf() ? Affine<F>::infinity() : a;
+    store_vec(table + (size_t)w * n + i, o);
+  }
+}
+
+template <class F>
+hipError_t msm_build_table(const Affine<F>* d_bases, uint64_t n, const MsmPlan& plan, Affine<F>** out_table,
+                           hipStream_t st) {
+  *out_table = nullptr;
+  hipError_t e = hipMalloc(out_table, sizeof(Affine<F>) * (size_t)plan.ndigits * (n ? n : 1));
+  if (e != hipSuccess) return e;
+  if (n) {
+    hipLaunchKernelGGL(k_build_table<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_bases, *out_table,
+                       (uint32_t)n, plan.ndigits, plan.c);
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 template <class F>

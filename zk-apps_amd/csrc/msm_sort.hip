@@ -77,6 +77,57 @@ k_bucket_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, uint32_t 
   }
 }
 
+// Shared-bucket mode: one bucket set of P * nb buckets for all digits.  Tile (chunk, q)
+// scans its scalars' ndigits digits and keeps those whose bucket falls in partition q.
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024)
+k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log,
+                     uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t ch = blockIdx.x, q = blockIdx.y, nch = gridDim.x;
+  uint32_t* gh = blockhist + ((size_t)q * nch + ch) * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
+  __syncthreads();
+  const uint32_t beg = ch * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    uint32_t k[9];
+    load_biased(scalars, i, rc, k);
+    for (int w = 0; w < ndigits; w++) {
+      bool neg;
+      const uint32_t d = digit_of(k, w, c, neg);
+      if (d == 0) continue;
+      const uint32_t bkt = d - 1;
+      if ((bkt >> nb_log) != q) continue;
+      const uint32_t local = bkt & (nb - 1u);
+      if (SCATTER) {
+        const uint32_t pos = atomicAdd(&hist[local], 1u);
+        sorted[pos] = ((uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
+      } else {
+        atomicAdd(&hist[local], 1u);
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) gh[b] = hist[b];
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_part_totals(const uint32_t* __restrict__ count, uint32_t* __restrict__ part_total, uint32_t nb) {
+  __shared__ uint32_t part[1024];
+  uint32_t s = 0;
+  for (uint32_t b = threadIdx.x; b < nb; b += 1024) s += count[blockIdx.x * nb + b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part_total[blockIdx.x] = part[0];
+}
+
 // Pass 2a: per (window, bucket) exclusive prefix over the chunks (in place) and the bucket total.
 __global__ void __launch_bounds__(256)
 k_bucket_totals(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ count, uint32_t nb, uint32_t nch,
@@ -96,9 +147,16 @@ k_bucket_totals(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ count, 
 
 // Pass 2b: one workgroup per window: begin[w][b] = w*n + exclusive prefix of count[w][*].
 __global__ void __launch_bounds__(1024)
-k_window_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t nb, uint32_t n) {
+k_window_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t nb, uint32_t n,
+              const uint32_t* __restrict__ part_total) {
   __shared__ uint32_t part[1024];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  // region of this window / partition in sorted[]: fixed w*n, or (shared mode) packed
+  uint32_t region = w * n;
+  if (part_total) {
+    region = 0;
+    for (uint32_t q = 0; q < w; q++) region += part_total[q];
+  }
   const uint32_t per = (nb + 1023u) / 1024u;
   const uint32_t b0 = tid * per;
   const uint32_t b1 = (b0 + per < nb) ? b0 + per : nb;
@@ -112,7 +170,7 @@ k_window_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ begin, 
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = w * n + ((tid == 0) ? 0u : part[tid - 1]);
+  uint32_t run = region + ((tid == 0) ? 0u : part[tid - 1]);
   for (uint32_t b = b0; b < b1; b++) {
     begin[w * nb + b] = run;
     run += count[w * nb + b];
@@ -199,6 +257,25 @@ MsmPlan msm_make_plan(uint64_t n) {
   return msm_make_plan_c(n, forced ? forced : pick_window(n));
 }
 
+MsmPlan msm_make_plan_shared(uint64_t n) {
+  // total buckets 2^(c-1) ~ n / 2: mean bucket load = ndigits, so a thread-per-bucket
+  // accumulation has >= 4 full rounds of waves at n = 2^20 (c = 20: 13 digits instead of 16)
+  int lg = 0;
+  while ((1ull << lg) < n) lg++;
+  int c = lg;
+  if (c < 6) c = 6;
+  if (c > 20) c = 20;
+  MsmPlan p;
+  p.c = c;
+  p.shared = true;
+  p.ndigits = 255 / c + 1;
+  const int nb_log = (c - 1 < 15) ? c - 1 : 15;
+  p.nb = 1u << nb_log;
+  p.nwin = 1 << (c - 1 - nb_log);
+  p.n = n;
+  return p;
+}
+
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
 uint64_t msm_max_buckets(uint64_t n) {
@@ -251,10 +328,11 @@ void MsmSort::release() {
   if (count) (void)hipFree(count);
   if (perm) (void)hipFree(perm);
   if (heavy) (void)hipFree(heavy);
+  if (part_total) (void)hipFree(part_total);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = perm = heavy = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = part_total = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
 }
 
@@ -263,12 +341,24 @@ hipError_t MsmSort::reserve(uint64_t n) {
   const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);
   if (nbk < forced) nbk = forced;  // allow plan_override = 16 for any n
   if (16 * n > ne) ne = 16 * n;
+  {
+    // shared-bucket plan for the same n
+    const MsmPlan sp = msm_make_plan_shared(n);
+    const uint64_t se = (uint64_t)sp.ndigits * n, sb = (uint64_t)sp.nwin * sp.nb;
+    uint64_t snch = (256 + sp.nwin - 1) / sp.nwin;
+    const uint64_t mx = (n + 1023) / 1024;
+    if (snch > mx) snch = mx ? mx : 1;
+    if (se > ne) ne = se;
+    if (sb > nbk) nbk = sb;
+    if (sb * snch > nh) nh = sb * snch;
+  }
   if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
   release();
   hipError_t e;
   if ((e = hipMalloc(&count, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
+  if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
   if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * nh)) != hipSuccess) return e;
   if ((e = hipMalloc(&sorted, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
@@ -280,6 +370,10 @@ hipError_t MsmSort::reserve(uint64_t n) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -314,7 +408,8 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   hipLaunchKernelGGL(k_bucket_pass<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
-  hipLaunchKernelGGL(k_window_scan, dim3(nwin), dim3(1024), 0, st, count, begin, nb, (uint32_t)n);
+  hipLaunchKernelGGL(k_window_scan, dim3(nwin), dim3(1024), 0, st, count, begin, nb, (uint32_t)n,
+                     (const uint32_t*)nullptr);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
   hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
@@ -322,6 +417,50 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   hipLaunchKernelGGL(k_bucket_order, dim3(nwin), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb);
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
+  if (prof) prof->end(PH_MSM_SORT, st);
+  return hipGetLastError();
+}
+
+hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
+  plan = msm_make_plan_shared(n);
+  const uint32_t nb = plan.nb, P = (uint32_t)plan.nwin;
+  int nb_log = 0;
+  while ((1u << nb_log) < nb) nb_log++;
+  const uint32_t tot_b = P * nb;
+  uint32_t nch = (256 + P - 1) / P;
+  const uint64_t max_by_n = (n + 1023) / 1024;
+  if (nch > max_by_n) nch = (uint32_t)(max_by_n ? max_by_n : 1);
+  const uint32_t chunk = (uint32_t)((n + nch - 1) / nch);
+  RecodeConst rc;
+  for (int j = 0; j < 9; j++) rc.m[j] = 0;
+  for (int w = 0; w < plan.ndigits; w++) {
+    const uint64_t v = (1ull << (plan.c - 1)) - 1;
+    const int bit = w * plan.c, limb = bit >> 5, sh = bit & 31;
+    if (limb < 9) {
+      uint64_t carry = v << sh;  // c <= 20, sh <= 31: fits 64 bits
+      for (int j = limb; j < 9 && carry; j++) {
+        const uint64_t sum = (uint64_t)rc.m[j] + (uint32_t)carry;
+        rc.m[j] = (uint32_t)sum;
+        carry = (carry >> 32) + (sum >> 32);
+      }
+    }
+  }
+  if (prof) prof->begin(PH_MSM_SORT, st);
+  const size_t lds = sizeof(uint32_t) * nb;
+  const dim3 grid(nch, P);
+  hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
+                     nb, nb_log, chunk, rc, blockhist, sorted);
+  hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
+  hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
+  hipLaunchKernelGGL(k_window_scan, dim3(P), dim3(1024), 0, st, count, begin, nb, (uint32_t)n,
+                     (const uint32_t*)part_total);
+  const uint32_t tot_h = tot_b * nch;
+  hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
+  hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
+  if (e0 != hipSuccess) return e0;
+  hipLaunchKernelGGL(k_bucket_order, dim3(P), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb);
+  hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
+                     nb, nb_log, chunk, rc, blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
