@@ -59,7 +59,7 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
 }
 
 #ifndef ZK_ACCUM_PREFETCH
-#define ZK_ACCUM_PREFETCH false
+#define ZK_ACCUM_PREFETCH false  // measured: prefetching the next point costs 28 VGPRs and gains nothing
 #endif
 // G1 (14-limb coordinates): 248 VGPRs -> 2 waves per SIMD.  G2 needs ~330 registers
 // (accumulator 112 + point 56 + columns 56 + temporaries) and runs at 1 wave per SIMD with
