@@ -37,3 +37,20 @@ for it in range(3):
     ctx.prof_reset()
     t = time.time(); ctx.ntt_dev(x.data_ptr(), lg); dt = time.time() - t
     print(f"ntt 2^{lg}: wall {dt*1e3:.3f} ms", ctx.prof_get("ntt"))
+# witness-like scalars (SURVEY §8d secondary): 40 % zero, 20 % one, 10 % < 2^16, 30 % uniform
+import numpy as np
+rs = np.random.RandomState(3)
+arr = np.frombuffer(bytes(raw), dtype=np.uint8).reshape(n, 32).copy()
+kind = rs.randint(0, 10, size=n)
+arr[kind < 4] = 0
+ones = (kind >= 4) & (kind < 6)
+arr[ones] = 0
+arr[ones, 0] = 1
+small = kind == 6
+arr[small, 2:] = 0
+dw = torch.from_numpy(arr).cuda()
+torch.cuda.synchronize()
+for it in range(3):
+    ctx.prof_reset()
+    t = time.time(); out = ctx.msm_g1_dev(dw.data_ptr(), n, b1); dt = time.time() - t
+    print(f"msm_g1 witness-like 2^{lg}: wall {dt*1e3:.2f} ms", {k: ctx.prof_get(k) for k in ("msm_sort", "msm_accum_g1", "msm_reduce_g1")})

@@ -83,6 +83,7 @@ struct MsmEngine {
   XYZZ<F>* buckets = nullptr;  // SLOTS x cap_buckets: one bucket array per MSM in flight
   XYZZ<F>* segsum = nullptr;
   XYZZ<F>* segw = nullptr;
+  XYZZ<F>* heavy_partial = nullptr;  // MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event
   XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS
