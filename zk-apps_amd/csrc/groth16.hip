@@ -178,9 +178,9 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_h, 32ull * N)) != hipSuccess) return e;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
-  if ((e = ctx->sort.reserve(cap)) != hipSuccess) return e;
-  if ((e = ctx->g1.reserve(cap)) != hipSuccess) return e;
-  if ((e = ctx->g2.reserve(cap)) != hipSuccess) return e;
+  if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
+  if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
+  if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
   return hipSuccess;
 }
 

@@ -45,6 +45,10 @@ struct MsmPlan {
   // ndigits digits of a scalar land in ONE bucket set of 2^(c-1) = nwin * nb buckets
   bool shared = false;
   int ndigits = 0;
+  // buckets above heavy_thr points (>= 8x the mean load, >= 256) are reduced by whole
+  // workgroups; load ordering uses the key (count >> heavy_shift) <= 256
+  uint32_t heavy_thr = 256;
+  int heavy_shift = 0;
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);
@@ -59,13 +63,17 @@ struct MsmSort {
   uint32_t* perm = nullptr;       // nwin*nb   bucket ids ordered by descending load (per window)
   uint32_t* heavy = nullptr;      // [0] = number of heavy buckets, [1..] their ids
   uint32_t* part_total = nullptr; // shared mode: entries per partition
+  uint32_t* blkcnt = nullptr;     // shared mode record pre-pass: per-(block, partition) counts -> slots
+  uint32_t* rec_entry = nullptr;  // records grouped by partition: table index | sign
+  uint32_t* rec_bkt = nullptr;    //                               bucket id inside the partition
   uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
   int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
   ~MsmSort() { release(); }
   void release();
-  hipError_t reserve(uint64_t n);
+  bool has_shared = false;  // buffers sized for the shared-bucket plan too
+  hipError_t reserve(uint64_t n, bool shared_too = false);
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
   // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
   hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
@@ -94,7 +102,8 @@ struct MsmEngine {
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }
   void release();
-  hipError_t reserve(uint64_t n);
+  bool has_shared = false;
+  hipError_t reserve(uint64_t n, bool shared_too = false);
   // device part: bucket accumulation + reduction down to per-window partials,
   // async copy of the partials to the host and an event; does not block
   // accumulation runs on `st`; the (low-occupancy, latency-bound) reduction runs on

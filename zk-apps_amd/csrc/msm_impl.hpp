@@ -36,8 +36,8 @@ namespace zkmi {
 
 constexpr int MSM_SEG = 16;  // buckets per segment in k_segreduce
 constexpr int MSM_SEG_LOG = 4;
-constexpr int MSM_TREE_T = 128;
-constexpr uint32_t MSM_HEAVY = 256;  // buckets above this load are reduced by a whole workgroup  // k_treesum block: 128 x XYZZ<Fq2> = 48 KiB LDS
+constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
+constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
 template <class T>
 __device__ __forceinline__ T load_vec(const T* p) {
@@ -72,12 +72,13 @@ template <class F, bool PREFETCH>
 __global__ void __launch_bounds__(256, AccumWaves<F>::value)
 k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
         const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
-        const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets) {
+        const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
+        uint32_t heavy_thr) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_buckets) return;
   const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
   const uint32_t cnt = count[b];
-  if (cnt > MSM_HEAVY) return;  // k_accum_heavy owns it
+  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
   const uint32_t beg = begin[b], end = beg + cnt;
   XYZZ<F> acc = XYZZ<F>::infinity();
   if (PREFETCH) {
@@ -130,13 +131,14 @@ template <int UNUSED = 0>
 __global__ void __launch_bounds__(256, 2)
 k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
                  const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
-                 const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets) {
+                 const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets,
+                 uint32_t heavy_thr) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = gt >> 1, comp = gt & 1u;
   if (t >= total_buckets) return;  // pair-uniform
   const uint32_t b = perm[t];
   const uint32_t cnt = count[b];
-  if (cnt > MSM_HEAVY) return;
+  if (cnt > heavy_thr) return;
   const uint32_t beg = begin[b], end = beg + cnt;
   XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
   for (uint32_t j = beg; j < end; j++) {
@@ -353,10 +355,17 @@ void MsmEngine<F>::release() {
 uint64_t msm_max_buckets(uint64_t n);
 
 template <class F>
-hipError_t MsmEngine<F>::reserve(uint64_t n) {
+hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   uint64_t need = msm_max_buckets(n);
   const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);  // plan_override = 16 for any n
   if (need < forced) need = forced;
+  shared_too = shared_too || has_shared;
+  if (shared_too) {
+    const MsmPlan sp = msm_make_plan_shared(n);  // shared-bucket plan of the same n
+    const uint64_t sb = (uint64_t)sp.nwin * sp.nb;
+    if (need < sb) need = sb;
+  }
+  has_shared = shared_too;
   if (need <= cap_buckets) return hipSuccess;
   release();
   hipError_t e;
@@ -393,10 +402,10 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     hipLaunchKernelGGL(k_accum_g2_split<0>, dim3((2 * tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                       sort.perm, sort.sorted, bk, tot_b);
+                       sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   } else {
     hipLaunchKernelGGL((k_accum<F, ZK_ACCUM_PREFETCH>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,
-                       sort.count, sort.perm, sort.sorted, bk, tot_b);
+                       sort.count, sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,

@@ -114,6 +114,95 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
   }
 }
 
+// ---- record pre-pass (shared mode with several partitions) -----------------------
+// Scanning every scalar's digits once per partition costs P x the digit extraction.  With
+// P > 1 the digits are extracted ONCE into (table index, local bucket) records grouped by
+// partition; the LDS-histogram passes then stream their own partition's records.
+template <bool WRITE>
+__global__ void __launch_bounds__(1024)
+k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P,
+            uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry,
+            uint32_t* __restrict__ rec_bkt) {
+  __shared__ uint32_t cnt[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = (WRITE && threadIdx.x < P) ? blkcnt[blockIdx.x * P + threadIdx.x] : 0u;
+  __syncthreads();
+  const uint32_t beg = blockIdx.x * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    uint32_t k[9];
+    load_biased(scalars, i, rc, k);
+    for (int w = 0; w < ndigits; w++) {
+      bool neg;
+      const uint32_t d = digit_of(k, w, c, neg);
+      if (d == 0) continue;
+      const uint32_t bkt = d - 1;
+      const uint32_t q = bkt >> nb_log;
+      const uint32_t pos = atomicAdd(&cnt[q], 1u);
+      if (WRITE) {
+        rec_entry[pos] = ((uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
+        rec_bkt[pos] = bkt & (nb - 1u);
+      }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    if (threadIdx.x < P) blkcnt[blockIdx.x * P + threadIdx.x] = cnt[threadIdx.x];
+  }
+}
+
+// blkcnt[blk][q] -> first record slot of (blk, q); part_total[q] = records of partition q
+__global__ void __launch_bounds__(64)
+k_part_scan(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t P, uint32_t* __restrict__ part_total) {
+  __shared__ uint32_t tot[64];
+  const uint32_t q = threadIdx.x;
+  uint32_t s = 0;
+  if (q < P)
+    for (uint32_t b = 0; b < nblk; b++) s += blkcnt[b * P + q];
+  tot[q] = (q < P) ? s : 0u;
+  __syncthreads();
+  if (q < P) {
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < q; j++) run += tot[j];
+    for (uint32_t b = 0; b < nblk; b++) {
+      const uint32_t v = blkcnt[b * P + q];
+      blkcnt[b * P + q] = run;
+      run += v;
+    }
+    part_total[q] = s;
+  }
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024)
+k_bucket_pass_rec(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt,
+                  const uint32_t* __restrict__ part_total, uint32_t nb, uint32_t* __restrict__ blockhist,
+                  uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t ch = blockIdx.x, q = blockIdx.y, nch = gridDim.x;
+  uint32_t* gh = blockhist + ((size_t)q * nch + ch) * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
+  uint32_t pbase = 0;
+  for (uint32_t j = 0; j < q; j++) pbase += part_total[j];
+  const uint32_t ptot = part_total[q];
+  const uint32_t len = (ptot + nch - 1) / nch;
+  const uint32_t lo = ch * len;
+  const uint32_t hi = (lo + len < ptot) ? lo + len : ptot;
+  __syncthreads();
+  for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+    const uint32_t local = rec_bkt[pbase + r];
+    if (SCATTER) {
+      const uint32_t pos = atomicAdd(&hist[local], 1u);
+      sorted[pos] = rec_entry[pbase + r];
+    } else {
+      atomicAdd(&hist[local], 1u);
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) gh[b] = hist[b];
+  }
+}
+
 __global__ void __launch_bounds__(1024)
 k_part_totals(const uint32_t* __restrict__ count, uint32_t* __restrict__ part_total, uint32_t nb) {
   __shared__ uint32_t part[1024];
@@ -196,7 +285,7 @@ k_bucket_bases(uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ be
 // k_accum_heavy reduces with a whole workgroup each.
 __global__ void __launch_bounds__(1024)
 k_bucket_order(const uint32_t* __restrict__ count, uint32_t* __restrict__ perm, uint32_t* __restrict__ heavy,
-               uint32_t* __restrict__ n_heavy, uint32_t nb) {
+               uint32_t* __restrict__ n_heavy, uint32_t nb, uint32_t thr, int shift) {
   __shared__ uint32_t bins[MSM_HEAVY + 2];
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   for (uint32_t i = tid; i < MSM_HEAVY + 2; i += 1024) bins[i] = 0;
@@ -204,7 +293,7 @@ k_bucket_order(const uint32_t* __restrict__ count, uint32_t* __restrict__ perm, 
   // key: 0 = heaviest light bucket ... MSM_HEAVY = empty; heavy buckets sort last (key MSM_HEAVY + 1)
   for (uint32_t b = tid; b < nb; b += 1024) {
     const uint32_t cnt = count[w * nb + b];
-    const uint32_t key = cnt > MSM_HEAVY ? MSM_HEAVY + 1 : MSM_HEAVY - cnt;
+    const uint32_t key = cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
     atomicAdd(&bins[key], 1u);
   }
   __syncthreads();
@@ -219,10 +308,10 @@ k_bucket_order(const uint32_t* __restrict__ count, uint32_t* __restrict__ perm, 
   __syncthreads();
   for (uint32_t b = tid; b < nb; b += 1024) {
     const uint32_t cnt = count[w * nb + b];
-    const uint32_t key = cnt > MSM_HEAVY ? MSM_HEAVY + 1 : MSM_HEAVY - cnt;
+    const uint32_t key = cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
     const uint32_t pos = atomicAdd(&bins[key], 1u);
     perm[w * nb + pos] = w * nb + b;
-    if (cnt > MSM_HEAVY) heavy[atomicAdd(n_heavy, 1u)] = w * nb + b;
+    if (cnt > thr) heavy[atomicAdd(n_heavy, 1u)] = w * nb + b;
   }
 }
 
@@ -239,12 +328,23 @@ static int pick_window(uint64_t n) {
   return 16;  // 2^15 buckets = 128 KiB of LDS counters per (window, chunk) tile
 }
 
+static void plan_set_heavy(MsmPlan& p, uint64_t items) {
+  const uint64_t buckets = (uint64_t)p.nwin * p.nb;
+  const uint64_t mean = (items + buckets - 1) / buckets;
+  uint64_t thr = 256;
+  while (thr < 8 * mean) thr <<= 1;
+  p.heavy_thr = (uint32_t)thr;
+  p.heavy_shift = 0;
+  while ((thr >> p.heavy_shift) > 256) p.heavy_shift++;
+}
+
 MsmPlan msm_make_plan_c(uint64_t n, int c) {
   MsmPlan p;
   p.c = c;
   p.nwin = 255 / p.c + 1;
   p.nb = 1u << (p.c - 1);
   p.n = n;
+  plan_set_heavy(p, n * (uint64_t)p.nwin);
   return p;
 }
 MsmPlan msm_make_plan(uint64_t n) {
@@ -259,12 +359,13 @@ MsmPlan msm_make_plan(uint64_t n) {
 
 MsmPlan msm_make_plan_shared(uint64_t n) {
   // total buckets 2^(c-1) ~ n / 2: mean bucket load = ndigits, so a thread-per-bucket
-  // accumulation has >= 4 full rounds of waves at n = 2^20 (c = 20: 13 digits instead of 16)
+  // accumulation has >= 4 full rounds of waves at n = 2^20 (c = 20: 13 digits instead of 16;
+  // n = 2^22: c = 22, 12 digits)
   int lg = 0;
   while ((1ull << lg) < n) lg++;
   int c = lg;
   if (c < 6) c = 6;
-  if (c > 20) c = 20;
+  if (c > 22) c = 22;  // <= 64 partitions of 2^15 buckets
   MsmPlan p;
   p.c = c;
   p.shared = true;
@@ -273,6 +374,7 @@ MsmPlan msm_make_plan_shared(uint64_t n) {
   p.nb = 1u << nb_log;
   p.nwin = 1 << (c - 1 - nb_log);
   p.n = n;
+  plan_set_heavy(p, n * (uint64_t)p.ndigits);
   return p;
 }
 
@@ -329,20 +431,25 @@ void MsmSort::release() {
   if (perm) (void)hipFree(perm);
   if (heavy) (void)hipFree(heavy);
   if (part_total) (void)hipFree(part_total);
+  if (blkcnt) (void)hipFree(blkcnt);
+  if (rec_entry) (void)hipFree(rec_entry);
+  if (rec_bkt) (void)hipFree(rec_bkt);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = perm = heavy = part_total = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
+  has_shared = false;
 }
 
-hipError_t MsmSort::reserve(uint64_t n) {
+hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   uint64_t ne = msm_max_entries(n), nbk = msm_max_buckets(n), nh = msm_max_hist(n);
   const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);
   if (nbk < forced) nbk = forced;  // allow plan_override = 16 for any n
   if (16 * n > ne) ne = 16 * n;
-  {
-    // shared-bucket plan for the same n
+  shared_too = shared_too || has_shared;
+  if (shared_too) {
+    // shared-bucket plan for the same n (only the prover uses it)
     const MsmPlan sp = msm_make_plan_shared(n);
     const uint64_t se = (uint64_t)sp.ndigits * n, sb = (uint64_t)sp.nwin * sp.nb;
     uint64_t snch = (256 + sp.nwin - 1) / sp.nwin;
@@ -352,6 +459,7 @@ hipError_t MsmSort::reserve(uint64_t n) {
     if (sb > nbk) nbk = sb;
     if (sb * snch > nh) nh = sb * snch;
   }
+  if (shared_too && !has_shared) cap_entries = 0;  // force re-allocation with the record buffers
   if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
   release();
   hipError_t e;
@@ -359,6 +467,12 @@ hipError_t MsmSort::reserve(uint64_t n) {
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
+  if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
+  if (shared_too) {
+    if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
+    if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
+  }
+  has_shared = shared_too;
   if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
   if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * nh)) != hipSuccess) return e;
   if ((e = hipMalloc(&sorted, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
@@ -374,6 +488,10 @@ hipError_t MsmSort::reserve(uint64_t n) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_rec<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_rec<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -414,7 +532,8 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
   hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
   if (e0 != hipSuccess) return e0;
-  hipLaunchKernelGGL(k_bucket_order, dim3(nwin), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb);
+  hipLaunchKernelGGL(k_bucket_order, dim3(nwin), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb, plan.heavy_thr,
+                     plan.heavy_shift);
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);
@@ -448,19 +567,40 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   if (prof) prof->begin(PH_MSM_SORT, st);
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
-  hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
-                     nb, nb_log, chunk, rc, blockhist, sorted);
+  const bool records = P > 1;
+  uint32_t nblk_a = 0, chunk_a = 0;
+  if (records) {
+    nblk_a = (uint32_t)((n + 4095) / 4096);
+    if (nblk_a > 256) nblk_a = 256;
+    chunk_a = (uint32_t)((n + nblk_a - 1) / nblk_a);
+    hipLaunchKernelGGL(k_part_pass<false>, dim3(nblk_a), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
+                       nb, nb_log, P, chunk_a, rc, blkcnt, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(64), 0, st, blkcnt, nblk_a, P, part_total);
+    hipLaunchKernelGGL(k_part_pass<true>, dim3(nblk_a), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
+                       nb, nb_log, P, chunk_a, rc, blkcnt, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_bucket_pass_rec<false>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist,
+                       sorted);
+  } else {
+    hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted);
+  }
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
-  hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
+  if (!records) hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
   hipLaunchKernelGGL(k_window_scan, dim3(P), dim3(1024), 0, st, count, begin, nb, (uint32_t)n,
                      (const uint32_t*)part_total);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
   hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
   if (e0 != hipSuccess) return e0;
-  hipLaunchKernelGGL(k_bucket_order, dim3(P), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb);
-  hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
-                     nb, nb_log, chunk, rc, blockhist, sorted);
+  hipLaunchKernelGGL(k_bucket_order, dim3(P), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb, plan.heavy_thr,
+                     plan.heavy_shift);
+  if (records) {
+    hipLaunchKernelGGL(k_bucket_pass_rec<true>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist,
+                       sorted);
+  } else {
+    hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted);
+  }
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
