@@ -98,8 +98,8 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
