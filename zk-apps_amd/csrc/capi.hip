@@ -81,7 +81,10 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   if (hipStreamCreate(&c->stream) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ZKMI_ERR_HIP;
   }
@@ -110,6 +113,9 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
   if (ctx->stream_g2) (void)hipStreamDestroy(ctx->stream_g2);
   if (ctx->ev_sort) (void)hipEventDestroy(ctx->ev_sort);
+  if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
+  if (ctx->ev_z) (void)hipEventDestroy(ctx->ev_z);
+  if (ctx->ev_h) (void)hipEventDestroy(ctx->ev_h);
   delete ctx;
   return ZKMI_OK;
 }
@@ -121,6 +127,7 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_g2));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -140,6 +147,7 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream_aux);
   (void)hipStreamSynchronize(ctx->stream_g2);
+  (void)hipStreamSynchronize(ctx->stream_front);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];

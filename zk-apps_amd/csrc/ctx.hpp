@@ -15,7 +15,8 @@ struct zkmi_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream_aux = nullptr;  // MSM reductions: overlap the next accumulation
   hipStream_t stream_g2 = nullptr;   // G2 accumulation beside the G1 ones
-  hipEvent_t ev_sort = nullptr;
+  hipStream_t stream_front = nullptr;  // witness map + NTTs beside the MSMs over z
+  hipEvent_t ev_sort = nullptr, ev_z = nullptr, ev_h = nullptr;
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;

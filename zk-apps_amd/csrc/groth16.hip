@@ -448,16 +448,23 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
 }
 
 // z -> h coefficients (Montgomery form, natural order) in pk->d_a
-static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z_in) {
+// The witness lands in pk->d_z on the main stream (the digit sort of the A/B/L MSMs reads it
+// there); everything downstream of it (limb conversion, mat-vec, NTTs -> d_h) runs on `st`,
+// which the prover points at its front stream so that it overlaps the z-MSMs.
+static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z_in,
+                               hipStream_t st) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
-  hipStream_t st = ctx->stream;
   PhaseTimer* t = ctx->timer();
   if (z) {
     for (uint32_t i = 0; i < nv; i++)
       if (!fr_is_canonical(z + 32ull * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
-    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, st));
+    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, ctx->stream));
   } else {
-    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, d_z_in, 32ull * nv, hipMemcpyDeviceToDevice, st));
+    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, d_z_in, 32ull * nv, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (st != ctx->stream) {
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
+    ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z, 0));
   }
   if (t) t->begin(PH_WITNESS, st);
   ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z), pk->d_zm, nv, st));
@@ -484,13 +491,14 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
   ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h, st));
   if (t) t->end(PH_NTT, st);
+  if (st != ctx->stream) ZK_HIP(ctx, hipEventRecord(ctx->ev_h, st));
   ZK_HIP(ctx, hipGetLastError());
   return ZKMI_OK;
 }
 
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h) {
   if (!ctx || !pk || !z || !out_h) return ZKMI_ERR_BAD_ARG;
-  int32_t rc = witness_map_dev(ctx, pk, z, nullptr);
+  int32_t rc = witness_map_dev(ctx, pk, z, nullptr, ctx->stream);
   if (rc != ZKMI_OK) return rc;
   const uint32_t N = 1u << pk->log_n;
   std::vector<uint8_t> rev(32ull * N);
@@ -509,7 +517,9 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
 static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, int par) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   hipStream_t st = ctx->stream;
-  int32_t rc = witness_map_dev(ctx, pk, z, d_z);
+  // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the
+  // four MSMs over z, and the main stream picks h up just before the second digit sort
+  int32_t rc = witness_map_dev(ctx, pk, z, d_z, ctx->stream_front);
   if (rc != ZKMI_OK) return rc;
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
@@ -535,6 +545,7 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 2));
   ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->g2.acc_done[g2s], 0));  // the next sort re-uses the sort buffers
+  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_h, 0));               // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
   // infinity.  Re-uses the sort buffers: stream order keeps it behind the four MSMs above.
   if (sh)
