@@ -177,7 +177,7 @@ def main():
     avg_ms = ms_tot / max(1, launches)
     achieved = kernels[dom]["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {
-        "kernel": "k_accum<Fq>" if dom == "msm_accum_g1" else "k_accum<Fq2>",
+        "kernel": "k_accum<Fq28,false>" if dom == "msm_accum_g1" else "k_accum_g2_split<0>",
         "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
@@ -201,7 +201,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32-limb Montgomery (Fr 256-bit / Fq 384-bit integers)",
+        "dtype": "int: signed 28-bit limbs in 32-bit words, 64-bit column accumulators (Fr 255-bit / Fq 381-bit Montgomery)",
         "data": "synthetic",
         "config": {
             "workload": "single withdraw-shaped Groth16 proof, N=2^%d (7 Fr NTTs, 4 G1 MSM + 1 G2 MSM of 2^%d-1 terms), 1 proof per step per GPU"
