@@ -148,6 +148,26 @@ int32_t zkmi_r1cs_free(zkmi_r1cs* r);
  * (shielder/relations/src/relations/update_note.rs:47-88, :121, :127). */
 int32_t zkmi_shielder_r1cs(uint32_t log_n, zkmi_r1cs** out);
 int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z /* 2^log_n x 32 B */);
+/* Row a1: the same assignment from the relation's semantic inputs, in the order
+ * UpdateNoteInput::new loads them (update_note.rs:47-88): op_pub, new note, old note, Merkle
+ * path (shape bits + siblings, merkle_proof.rs:27-34), op_priv, old account.  The two public
+ * "hash outputs" new_note_hash and merkle_root are computed by the relation's stand-in chain
+ * and come back at indices 4 and 5 of out_z.  Public inputs = out_z[1..7). */
+typedef struct {
+  uint8_t bytes[32];
+} zkmi_fr;
+typedef struct {
+  zkmi_fr amount, token, user; /* op_pub.into()                                  */
+  zkmi_fr old_nullifier;       /* public: old_note.nullifier                     */
+  zkmi_fr new_note[4];         /* zk_id, trapdoor, nullifier, account_hash       */
+  zkmi_fr old_trapdoor, old_account_hash;
+  uint8_t path_shape[10];      /* MerkleProof::path_shape (0/1)                  */
+  zkmi_fr path[10];            /* MerkleProof::path                              */
+  zkmi_fr old_account[2];      /* TOKENS_NUMBER balances                         */
+} zkmi_update_note_input;
+int32_t zkmi_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input* in, uint8_t* out_z);
+/* value mod r (SHA-256 outputs used as Scalars by the mock can exceed r) */
+int32_t zkmi_fr_reduce(const uint8_t in[32], uint8_t out[32]);
 int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, uint32_t* n_constraints, uint32_t* log_n);
 /* export matrix m (0=A,1=B,2=C) as CSR; pass NULL buffers to query nnz */
 int32_t zkmi_r1cs_export(const zkmi_r1cs* r, int32_t m, uint32_t* rowptr, uint32_t* col, uint8_t* val, uint64_t* nnz);

@@ -229,3 +229,34 @@ def test_device_limb_representation_selftest(zk):
     bad = C.c_uint32(1)
     assert zk.lib.zkmi_selftest_fq28(C.c_uint64(7), C.c_uint32(5000), C.byref(bad)) == 0
     assert bad.value == 0
+
+
+def test_witness_from_semantic_inputs(zk):
+    """Row a1: the assignment built from the relation's semantic inputs (order of
+    UpdateNoteInput::new, update_note.rs:47-88) equals the seeded generator's and satisfies the relation."""
+    lg = 8
+    w = zk.shielder_witness(lg, 77)
+    f = lambda i: w[32 * i : 32 * i + 32]
+    shape = [f(14 + i)[0] for i in range(10)]
+    inp = zk.update_note_input(f(1), f(2), f(3), f(6), [f(7 + k) for k in range(4)], f(12), f(13), shape,
+                               [f(24 + i) for i in range(10)], [f(35), f(36)])
+    w2 = zk.shielder_witness_from_input(lg, inp)
+    assert w2 == w
+    r = zk.shielder_r1cs(lg)
+    assert r.is_satisfied(w2)
+    r.free()
+
+
+def test_fr_reduce(zk, pkg):
+    import hashlib
+
+    h = hashlib.sha256(b"note").digest()
+    v = int.from_bytes(h, "little")
+    assert int.from_bytes(zk.fr_reduce(h), "little") == v % ec.R
+    assert zk.fr_reduce(bytes(32)) == bytes(32)
+    assert int.from_bytes(zk.fr_reduce(b"\xff" * 32), "little") == (2**256 - 1) % ec.R
+    # a non-canonical scalar is rejected by the witness builder
+    inp = zk.update_note_input(*([b"\xff" * 32] * 4), [bytes(32)] * 4, bytes(32), bytes(32), [0] * 10, [bytes(32)] * 10, [bytes(32)] * 2)
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.shielder_witness_from_input(8, inp)
+    assert e.value.code == -2

@@ -316,3 +316,48 @@ def test_groth16_2p22_with_g2_and_pairing(ctx, zk):
     proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
     assert zk.groth16_verify(vk, z[32 : 32 * r1.n_pub], proof) is True
     pk.free()
+
+
+def test_mock_flow_with_real_proofs(ctx, zk):
+    """The reference's wallet flow (drink_tests/utils/shielder.rs:78-134: create -> deposit ->
+    withdraw) with the mock's bookkeeping AND a Groth16 proof per update: the mock's fields
+    (reduced into Fr) are loaded in the order of UpdateNoteInput::new, the proof is checked by
+    the pairing verifier against op_pub || new_note_hash || merkle_root || old_nullifier
+    (update_note.rs:121,127)."""
+    lg = 10
+    r1 = zk.shielder_r1cs(lg)
+    rng = ec.SplitMix64(2024)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    user = (1).to_bytes(16, "little") + bytes(16)
+    token = bytes([228] * 32)
+    tokens = [token, bytes(32)]
+    z32 = bytes(32)
+    ident = (7).to_bytes(16, "little") + bytes(16)
+    acc = zk.account_new(tokens)
+    null0, trap0 = (11).to_bytes(32, "little"), (12).to_bytes(32, "little")
+    proof_state = zk.zkproof_new(ident, trap0, null0, zk.op_priv(user), acc)
+    path = [z32] * 10
+    red = zk.fr_reduce
+    for step, (kind, amount) in enumerate((("deposit", 10), ("withdraw", 9))):
+        op = zk.op_pub(kind, amount, token, user)
+        trap, null = (20 + step).to_bytes(32, "little"), (30 + step).to_bytes(32, "little")
+        old = proof_state
+        h_new, proof_state = zk.zkproof_update_account(old, op, zk.op_priv(user), trap, null, path, 0)
+        inp = zk.update_note_input(
+            amount.to_bytes(32, "little"), red(token), red(user), red(bytes(old.nullifier_new.bytes)),
+            [red(ident), red(trap), red(null), red(zk.account_hash(proof_state.acc_new))],
+            red(bytes(old.trapdoor_new.bytes)), red(zk.account_hash(old.acc_new)),
+            [0] * 10, [red(p) for p in path],
+            [red(bytes(old.acc_new.balances[k][1].bytes)) for k in range(2)],
+        )
+        wit = zk.shielder_witness_from_input(lg, inp)
+        assert r1.is_satisfied(wit)
+        r_, s_ = ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr())
+        proof = ctx.groth16_prove(pk, wit, r_, s_)
+        publics = wit[32 : 32 * r1.n_pub]
+        assert publics[:32] == amount.to_bytes(32, "little") and publics[160:192] == red(bytes(old.nullifier_new.bytes))
+        assert zk.groth16_verify(vk, publics, proof) is True
+        tampered = bytearray(publics)
+        tampered[0] ^= 1  # a different amount
+        assert zk.groth16_verify(vk, bytes(tampered), proof) is False
+    pk.free()

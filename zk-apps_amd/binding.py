@@ -60,6 +60,20 @@ class OpPriv(C.Structure):
     _fields_ = [("user", Scalar)]
 
 
+class UpdateNoteInput(C.Structure):
+    """zkmi_update_note_input: semantic inputs of the withdraw-shaped relation (row a1)."""
+
+    _fields_ = [
+        ("amount", Scalar), ("token", Scalar), ("user", Scalar),
+        ("old_nullifier", Scalar),
+        ("new_note", Scalar * 4),
+        ("old_trapdoor", Scalar), ("old_account_hash", Scalar),
+        ("path_shape", C.c_uint8 * MERKLE_TREE_DEPTH),
+        ("path", Scalar * MERKLE_TREE_DEPTH),
+        ("old_account", Scalar * TOKENS_NUMBER),
+    ]
+
+
 class ZkProof(C.Structure):
     _fields_ = [
         ("id", Scalar),
@@ -197,6 +211,31 @@ class Zkmi:
     def shielder_witness(self, log_n, seed):
         out = (C.c_uint8 * (32 << log_n))()
         self._chk(self.lib.zkmi_shielder_witness(C.c_uint32(log_n), C.c_uint64(seed), out))
+        return bytes(out)
+
+    def fr_reduce(self, b32):
+        out = (C.c_uint8 * 32)()
+        self._chk(self.lib.zkmi_fr_reduce(_buf(b32), out))
+        return bytes(out)
+
+    def update_note_input(self, amount, token, user, old_nullifier, new_note, old_trapdoor, old_account_hash,
+                          path_shape, path, old_account):
+        """All scalar arguments are 32-byte canonical LE values (use fr_reduce for SHA-256 outputs)."""
+        i = UpdateNoteInput()
+        i.amount, i.token, i.user, i.old_nullifier = scalar(amount), scalar(token), scalar(user), scalar(old_nullifier)
+        for k in range(4):
+            i.new_note[k] = scalar(new_note[k])
+        i.old_trapdoor, i.old_account_hash = scalar(old_trapdoor), scalar(old_account_hash)
+        for k in range(MERKLE_TREE_DEPTH):
+            i.path_shape[k] = int(path_shape[k])
+            i.path[k] = scalar(path[k])
+        for k in range(TOKENS_NUMBER):
+            i.old_account[k] = scalar(old_account[k])
+        return i
+
+    def shielder_witness_from_input(self, log_n, inp):
+        out = (C.c_uint8 * (32 << log_n))()
+        self._chk(self.lib.zkmi_shielder_witness_from_input(C.c_uint32(log_n), C.byref(inp), out))
         return bytes(out)
 
     def r1cs_create(self, n_vars, n_pub, mats):

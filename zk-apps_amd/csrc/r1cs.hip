@@ -139,6 +139,22 @@ zkmi_r1cs* build_shielder_r1cs(uint32_t log_n) {
   return r;
 }
 
+// chain part of the assignment: s_{k+1} = s_k^2 + s_{k-1}, then the two public "hash outputs"
+static void fill_chain(uint32_t N, std::vector<Fr>& z) {
+  const uint32_t K = N - V_CHAIN, mid = K / 2;
+  Fr s_prev = z[V_AMOUNT] + fr_u64(2) * z[V_TOKEN] + fr_u64(3) * z[V_USER] + fr_u64(4) * z[V_OLD_NULLIFIER];
+  Fr s_cur = Fr::zero();
+  for (uint32_t j = 0; j < V_CHAIN - V_NEW_NOTE; j++) s_cur = s_cur + fr_u64(j + 1) * z[V_NEW_NOTE + j];
+  for (uint32_t k = 0; k < K; k++) {
+    Fr s_next = s_cur.sqr() + s_prev;
+    z[V_CHAIN + k] = s_next;
+    s_prev = s_cur;
+    s_cur = s_next;
+  }
+  z[V_NEW_NOTE_HASH] = z[V_CHAIN + mid - 1];
+  z[V_MERKLE_ROOT] = z[V_CHAIN + K - 1];
+}
+
 void build_shielder_witness(uint32_t log_n, uint64_t seed, std::vector<Fr>* zp) {
   const uint32_t N = 1u << log_n;
   std::vector<Fr>& z = *zp;
@@ -158,18 +174,32 @@ void build_shielder_witness(uint32_t log_n, uint64_t seed, std::vector<Fr>* zp) 
   z[V_OP_PRIV_USER] = z[V_USER];
   z[V_OLD_ACCOUNT] = fr_u64(rng.next() & 0xFFFFFFFFFFFFull);
   z[V_OLD_ACCOUNT + 1] = fr_u64(rng.next() & 0xFFFFFFFFFFFFull);
-  const uint32_t K = N - V_CHAIN, mid = K / 2;
-  Fr s_prev = z[V_AMOUNT] + fr_u64(2) * z[V_TOKEN] + fr_u64(3) * z[V_USER] + fr_u64(4) * z[V_OLD_NULLIFIER];
-  Fr s_cur = Fr::zero();
-  for (uint32_t j = 0; j < V_CHAIN - V_NEW_NOTE; j++) s_cur = s_cur + fr_u64(j + 1) * z[V_NEW_NOTE + j];
-  for (uint32_t k = 0; k < K; k++) {
-    Fr s_next = s_cur.sqr() + s_prev;
-    z[V_CHAIN + k] = s_next;
-    s_prev = s_cur;
-    s_cur = s_next;
+  fill_chain(N, z);
+}
+
+// Row a1: the assignment from the relation's semantic inputs, loaded in the order of
+// UpdateNoteInput::new (shielder/relations/src/relations/update_note.rs:47-88).
+bool build_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input& in, std::vector<Fr>* zp) {
+  const uint32_t N = 1u << log_n;
+  std::vector<Fr>& z = *zp;
+  z.assign(N, Fr::zero());
+  z[V_ONE] = Fr::one();
+  bool ok = fr_from_wire(in.amount.bytes, &z[V_AMOUNT]) && fr_from_wire(in.token.bytes, &z[V_TOKEN]) &&
+            fr_from_wire(in.user.bytes, &z[V_USER]) && fr_from_wire(in.old_nullifier.bytes, &z[V_OLD_NULLIFIER]);
+  for (int j = 0; j < 4 && ok; j++) ok = fr_from_wire(in.new_note[j].bytes, &z[V_NEW_NOTE + j]);
+  z[V_OLD_NOTE] = z[V_NEW_NOTE];  // same zk_id (mocked_zk relations.rs:57-77 keeps the id)
+  ok = ok && fr_from_wire(in.old_trapdoor.bytes, &z[V_OLD_NOTE + 1]) &&
+       fr_from_wire(in.old_account_hash.bytes, &z[V_OLD_NOTE + 2]);
+  for (int i = 0; i < TREE_HEIGHT && ok; i++) {
+    if (in.path_shape[i] > 1) ok = false;
+    z[V_PATH_SHAPE + i] = fr_u64(in.path_shape[i]);
+    ok = ok && fr_from_wire(in.path[i].bytes, &z[V_PATH + i]);
   }
-  z[V_NEW_NOTE_HASH] = z[V_CHAIN + mid - 1];
-  z[V_MERKLE_ROOT] = z[V_CHAIN + K - 1];
+  z[V_OP_PRIV_USER] = z[V_USER];  // Operation::combine requires equal users (ops.rs:47-63)
+  for (int i = 0; i < 2 && ok; i++) ok = fr_from_wire(in.old_account[i].bytes, &z[V_OLD_ACCOUNT + i]);
+  if (!ok) return false;
+  fill_chain(N, z);
+  return true;
 }
 
 static Fr eval_row(const zkmi_r1cs::Csr& m, uint32_t i, const std::vector<Fr>& z) {
@@ -245,6 +275,38 @@ int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z) {
   std::vector<Fr> z;
   build_shielder_witness(log_n, seed, &z);
   for (size_t i = 0; i < z.size(); i++) fr_to_wire(z[i], out_z + 32 * i);
+  return ZKMI_OK;
+}
+
+int32_t zkmi_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input* in, uint8_t* out_z) {
+  if (!in || !out_z || log_n < 7 || log_n > 26) return ZKMI_ERR_BAD_ARG;
+  std::vector<Fr> z;
+  if (!build_shielder_witness_from_input(log_n, *in, &z)) return ZKMI_ERR_NON_CANONICAL;
+  for (size_t i = 0; i < z.size(); i++) fr_to_wire(z[i], out_z + 32 * i);
+  return ZKMI_OK;
+}
+
+// value mod r: SHA-256 outputs used as scalars by the mock exceed r
+int32_t zkmi_fr_reduce(const uint8_t in[32], uint8_t out[32]) {
+  if (!in || !out) return ZKMI_ERR_BAD_ARG;
+  uint32_t w[8];
+  memcpy(w, in, 32);
+  for (int round = 0; round < 4; round++) {  // 2^256 / r < 3: at most two subtractions
+    bool ge = true;
+    for (int i = 7; i >= 0; i--)
+      if (w[i] != FrParams::MOD[i]) {
+        ge = w[i] > FrParams::MOD[i];
+        break;
+      }
+    if (!ge) break;
+    uint64_t borrow = 0;
+    for (int i = 0; i < 8; i++) {
+      const uint64_t d = (uint64_t)w[i] - FrParams::MOD[i] - borrow;
+      w[i] = (uint32_t)d;
+      borrow = (d >> 63) & 1;
+    }
+  }
+  memcpy(out, w, 32);
   return ZKMI_OK;
 }
 

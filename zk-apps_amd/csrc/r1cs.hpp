@@ -2,6 +2,7 @@
 // Shielder-shaped synthetic relation.
 #pragma once
 #include <vector>
+#include "../../include/zkmi.h"
 #include "field.hpp"
 
 struct zkmi_r1cs {
@@ -16,5 +17,6 @@ namespace zkmi {
 void r1cs_finish_shape(zkmi_r1cs* r);
 zkmi_r1cs* build_shielder_r1cs(uint32_t log_n);
 void build_shielder_witness(uint32_t log_n, uint64_t seed, std::vector<Fr>* z_mont);
+bool build_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input& in, std::vector<Fr>* z_mont);
 bool r1cs_satisfied(const zkmi_r1cs& r, const std::vector<Fr>& z_mont);
 }  // namespace zkmi
