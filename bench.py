@@ -95,6 +95,31 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n):
     }
 
 
+def pmc_traffic(path, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary.
+
+    PMC counters cannot be read from inside the timed process, so the separate `--pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes of this same command (profiles/r01/README.md) are summarised into a JSON
+    file that travels with the repo; this returns (FETCH_SIZE + WRITE_SIZE) * 1024 for one launch.
+    The kernel gathers 112/224-byte table entries with per-lane loads (64-byte fabric requests), so the
+    guide's x2 correction for 128-byte coalesced requests is NOT applied."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path)) as f:
+            rows = json.load(f)
+    except OSError:
+        return None, "no PMC summary at %s" % path
+    for r in rows:
+        if r.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
+            fetch = r.get("FETCH_SIZE_avg_per_dispatch")
+            write = r.get("WRITE_SIZE_avg_per_dispatch")
+            if fetch is None or write is None:
+                break
+            return (fetch + write) * 1024.0, (
+                "bytes/launch = (FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) from %s (separate rocprofv3 --pmc passes of "
+                "this command; uncorrected: per-lane gathers of table entries, 64-B requests)" % (fetch, write, path))
+    return None, "kernel not in %s" % path
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +128,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-summary", default="profiles/r01/pmc_summary_bench_steps2_final.json")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,14 +202,17 @@ def main():
     ms_tot, launches = phases[dom]
     avg_ms = ms_tot / max(1, launches)
     achieved = kernels[dom]["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    kname = "k_accum<Fq28, false>" if dom == "msm_accum_g1" else "k_accum_g2_split<0>"
+    traffic, traffic_note = pmc_traffic(args.pmc_summary, kname)
     roofline = {
-        "kernel": "k_accum<Fq28,false>" if dom == "msm_accum_g1" else "k_accum_g2_split<0>",
+        "kernel": kname,
         "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
         "avg_launch_ms": avg_ms,
         "launches": launches,
         "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
