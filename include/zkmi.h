@@ -114,6 +114,14 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
 int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uint32_t nwin, uint32_t window_bits,
                             uint8_t out_affine[96]);
 
+/* Same split driven from ONE process holding one ctx per GPU (SURVEY.md §8b
+ * "zkmi_msm_g1_multi", BASELINE config 3): device d holds counts[d] scalars at
+ * d_scalars[d] and the matching slice of the points in bases[d] (loaded on
+ * ctxs[d]).  All devices are enqueued before any is waited for, then the
+ * per-window partial sums are added on the host.  n_dev <= 64. */
+int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* const* d_scalars, const uint64_t* counts,
+                          const zkmi_bases_g1* const* bases, uint8_t out_affine[96]);
+
 /* Host-executed self-test of the device limb representation (field28.hpp)
  * against the 32-bit-limb host arithmetic; *out_mismatches must be 0. */
 int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);

@@ -291,6 +291,33 @@ def test_msm_g1_point_split_matches_full(ctx, zk):
         x.free()
 
 
+def test_msm_g1_multi_ctx_matches_full(ctx, zk):
+    """zkmi_msm_g1_multi: one process, one ctx per slice (second ctx on GPU 1 when the box has one,
+    otherwise a second ctx on GPU 0); uneven slices, result == unsplit MSM == closed form."""
+    import torch
+
+    n = (1 << 17) + 12345
+    raw, tot, wtot = _torch_scalars(n, 12)
+    b = ctx.bases_g1_synthetic(n)
+    full = ctx.msm_g1_dev(raw.data_ptr(), n, b)
+    assert full == _closed_form_g1(tot, wtot)
+    dev1 = 1 if torch.cuda.device_count() > 1 else 0
+    ctx1 = zk.context(dev1)
+    cut = 50001
+    lo = ctx.bases_g1(b.read(0, cut), check=False)
+    hi = ctx1.bases_g1(b.read(cut, n - cut), check=False)
+    raw_hi = raw[cut:].to("cuda:%d" % dev1).contiguous()
+    torch.cuda.synchronize()
+    got = zk.msm_g1_multi([ctx, ctx1], [raw.data_ptr(), raw_hi.data_ptr()], [cut, n - cut], [lo, hi])
+    assert got == full
+    # degenerate slices: one device holds everything, the other nothing
+    got = zk.msm_g1_multi([ctx, ctx1], [raw.data_ptr(), 0], [cut, 0], [lo, hi])
+    assert got == ctx.msm_g1_dev(raw.data_ptr(), cut, lo)
+    for x in (b, lo, hi):
+        x.free()
+    ctx1.close()
+
+
 def test_msm_g1_2p26_single_gpu(ctx):
     """BASELINE config 3 size (n = 2^26, 8 GiB of algorithmic bytes) on one GPU."""
     import torch

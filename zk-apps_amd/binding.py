@@ -192,6 +192,18 @@ class Zkmi:
         self._chk(self.lib.zkmi_msm_g1_combine(_buf(windows), C.c_uint32(n_ranks), C.c_uint32(nwin), C.c_uint32(window_bits), out))
         return bytes(out)
 
+    def msm_g1_multi(self, ctxs, dptrs, counts, bases):
+        """One MSM split by points over several contexts (one per GPU) of this process."""
+        k = len(ctxs)
+        assert k == len(dptrs) == len(counts) == len(bases) and k > 0
+        a_ctx = (C.c_void_p * k)(*[c.h.value for c in ctxs])
+        a_ptr = (C.c_void_p * k)(*[int(p) for p in dptrs])
+        a_cnt = (C.c_uint64 * k)(*counts)
+        a_bas = (C.c_void_p * k)(*[b.h.value for b in bases])
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_multi(a_ctx, C.c_uint32(k), a_ptr, a_cnt, a_bas, out))
+        return bytes(out)
+
     def groth16_verify(self, vk, publics, proof):
         n_pub = (len(vk) - 672) // 96
         assert len(publics) == 32 * (n_pub - 1)

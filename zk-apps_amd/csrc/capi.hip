@@ -123,6 +123,7 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
 const char* zkmi_last_error(const zkmi_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
@@ -133,16 +134,19 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
 }
 
 int32_t zkmi_prof_enable(zkmi_ctx* ctx, int32_t on) {
+  ZK_ENTER(ctx);
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ctx->prof.enabled = on != 0;
   return ZKMI_OK;
 }
 int32_t zkmi_prof_reset(zkmi_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ctx->prof.reset();
   return ZKMI_OK;
 }
 int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64_t* out_launches) {
+  ZK_ENTER(ctx);
   if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream_aux);
@@ -158,6 +162,7 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
 // NTT
 // ---------------------------------------------------------------------------
 int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  ZK_ENTER(ctx);
   if (!ctx || !d_data || log_n > 26) return ZKMI_ERR_BAD_ARG;
   hipError_t e;
   NttDomain* dom = ctx->domain((int)log_n, &e);
@@ -184,6 +189,7 @@ int32_t zkmi_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inv
 }
 
 int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  ZK_ENTER(ctx);
   if (!ctx || !data || log_n > 26) return ZKMI_ERR_BAD_ARG;
   const uint64_t n = 1ull << log_n;
   for (uint64_t i = 0; i < n; i++)
@@ -201,9 +207,11 @@ int32_t zkmi_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t invers
 // bases
 // ---------------------------------------------------------------------------
 int32_t zkmi_bases_g1_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g1** out) {
+  ZK_ENTER(ctx);
   return bases_load<zkmi_bases_g1, G1Affine, g1_from_wire, 96>(ctx, affine, n, check, out);
 }
 int32_t zkmi_bases_g2_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g2** out) {
+  ZK_ENTER(ctx);
   return bases_load<zkmi_bases_g2, G2Affine, g2_from_wire, 192>(ctx, affine, n, check, out);
 }
 int32_t zkmi_bases_g1_free(zkmi_bases_g1* b) {
@@ -218,6 +226,7 @@ int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
 }
 
 int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
+  ZK_ENTER(ctx);
   if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
   zkmi_bases_g1* b = new (std::nothrow) zkmi_bases_g1();
   if (!b) return ZKMI_ERR_BAD_ARG;
@@ -235,6 +244,7 @@ int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) 
   return ZKMI_OK;
 }
 int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) {
+  ZK_ENTER(ctx);
   if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
   zkmi_bases_g2* b = new (std::nothrow) zkmi_bases_g2();
   if (!b) return ZKMI_ERR_BAD_ARG;
@@ -253,6 +263,7 @@ int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) 
 }
 
 int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out) {
+  ZK_ENTER(ctx);
   if (!ctx || !b || !out || first + count > b->n) return ZKMI_ERR_BAD_ARG;
   std::vector<G1Affine> h(count);
   ZK_HIP(ctx, hipMemcpy(h.data(), b->d + first, sizeof(G1Affine) * count, hipMemcpyDeviceToHost));
@@ -260,6 +271,7 @@ int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first
   return ZKMI_OK;
 }
 int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first, uint64_t count, uint8_t* out) {
+  ZK_ENTER(ctx);
   if (!ctx || !b || !out || first + count > b->n) return ZKMI_ERR_BAD_ARG;
   std::vector<G2Affine> h(count);
   ZK_HIP(ctx, hipMemcpy(h.data(), b->d + first, sizeof(G2Affine) * count, hipMemcpyDeviceToHost));
@@ -272,6 +284,7 @@ int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first
 // ---------------------------------------------------------------------------
 int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
                         uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g1.reserve(n));
@@ -285,6 +298,7 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
 
 int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g2* bases,
                         uint8_t out_affine[192]) {
+  ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g2.reserve(n));
@@ -306,6 +320,7 @@ static int32_t upload_scalars(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n)
 
 int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g1* bases,
                     uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
   int32_t rc = upload_scalars(ctx, scalars, n);
   if (rc != ZKMI_OK) return rc;
@@ -313,6 +328,7 @@ int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkm
 }
 int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g2* bases,
                     uint8_t out_affine[192]) {
+  ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
   int32_t rc = upload_scalars(ctx, scalars, n);
   if (rc != ZKMI_OK) return rc;
@@ -322,6 +338,7 @@ int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkm
 int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
                                 uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin,
                                 uint32_t* out_window_bits) {
+  ZK_ENTER(ctx);
   if (!ctx || !bases || !out_windows_affine || !out_nwin || !out_window_bits || n > bases->n) return ZKMI_ERR_BAD_ARG;
   if (plan_n < n) plan_n = n;
   ZK_HIP(ctx, ctx->sort.reserve(plan_n));
@@ -338,6 +355,43 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
   for (int w = 0; w < ctx->sort.plan.nwin; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);
   *out_nwin = (uint32_t)ctx->sort.plan.nwin;
   *out_window_bits = (uint32_t)ctx->sort.plan.c;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* const* d_scalars, const uint64_t* counts,
+                          const zkmi_bases_g1* const* bases, uint8_t out_affine[96]) {
+  if (!ctxs || !d_scalars || !counts || !bases || !out_affine || n_dev == 0 || n_dev > 64) return ZKMI_ERR_BAD_ARG;
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < n_dev; d++) {
+    if (!ctxs[d] || !bases[d] || counts[d] > bases[d]->n || (counts[d] && !d_scalars[d])) return ZKMI_ERR_BAD_ARG;
+    total += counts[d];
+  }
+  if (total >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  // one window width for every slice, planned from the global size (as the multi-process path does)
+  MsmPlan pl = msm_make_plan(total);
+  // enqueue every device's sort + accumulation + reduction first, then collect: the devices run concurrently
+  for (uint32_t d = 0; d < n_dev; d++) {
+    zkmi_ctx* ctx = ctxs[d];
+    ZK_ENTER(ctx);
+    ZK_HIP(ctx, ctx->sort.reserve(total));  // sized for the global plan, like zkmi_msm_g1_windows_dev
+    ZK_HIP(ctx, ctx->g1.reserve(total));
+    ctx->sort.plan_override = pl.c;
+    hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars[d]), counts[d], ctx->stream, ctx->timer());
+    ctx->sort.plan_override = 0;
+    if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+    ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases[d]->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1,
+                                   PH_MSM_REDUCE_G1));
+  }
+  std::vector<G1XYZZ> sum(pl.nwin, G1XYZZ::infinity()), win(pl.nwin);
+  for (uint32_t d = 0; d < n_dev; d++) {
+    zkmi_ctx* ctx = ctxs[d];
+    ZK_ENTER(ctx);
+    if (ctx->sort.plan.nwin != pl.nwin) return ctx->fail(ZKMI_ERR_BAD_ARG, "window plan mismatch");
+    ZK_HIP(ctx, ctx->g1.finish_host_windows(win.data()));
+    for (int w = 0; w < pl.nwin; w++) sum[w].add(win[w]);
+  }
+  G1XYZZ res = msm_combine_windows<Fq>(sum.data(), pl.nwin, pl.c);
+  g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }
 

@@ -82,6 +82,14 @@ struct zkmi_bases_g2 {
     if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); \
   } while (0)
 
+// first statement of every entry point that takes a ctx: bind the calling thread to the ctx's device
+// (a process may hold one ctx per GPU; streams and allocations belong to their device)
+#define ZK_ENTER(ctx)                                   \
+  do {                                                  \
+    if (!(ctx)) return ZKMI_ERR_BAD_ARG;                \
+    ZK_HIP(ctx, hipSetDevice((ctx)->device));           \
+  } while (0)
+
 namespace zkmi {
 // wire <-> internal conversions (host)
 bool fr_from_wire(const uint8_t* b, Fr* out);  // canonical check, -> Montgomery

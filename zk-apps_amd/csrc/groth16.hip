@@ -268,6 +268,7 @@ extern "C" {
 
 int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t toxic[160], zkmi_pk** out_pk,
                            uint8_t* vk_out, uint64_t vk_cap) {
+  ZK_ENTER(ctx);
   if (!ctx || !r || !toxic || !out_pk || !vk_out) return ZKMI_ERR_BAD_ARG;
   if (vk_cap < 672 + 96ull * r->n_pub) return ctx->fail(ZKMI_ERR_BAD_ARG, "vk buffer too small");
   Fr tau, alpha, beta, gamma, delta;
@@ -380,6 +381,7 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t alpha_g1[9
                      const uint8_t beta_g2[192], const uint8_t delta_g1[96], const uint8_t delta_g2[192],
                      const uint8_t* a_query, const uint8_t* b_g1_query, const uint8_t* b_g2_query,
                      const uint8_t* h_query, const uint8_t* l_query, zkmi_pk** out_pk) {
+  ZK_ENTER(ctx);
   if (!ctx || !r || !alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !a_query || !b_g1_query ||
       !b_g2_query || !h_query || !l_query || !out_pk)
     return ZKMI_ERR_BAD_ARG;
@@ -429,6 +431,7 @@ int32_t zkmi_pk_free(zkmi_pk* pk) {
 
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count,
                              uint8_t* out) {
+  ZK_ENTER(ctx);
   if (!ctx || !pk || !out || which < 0 || which > 4) return ZKMI_ERR_BAD_ARG;
   const uint64_t N = 1ull << pk->log_n;
   if (which == 2) {
@@ -497,6 +500,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
 }
 
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h) {
+  ZK_ENTER(ctx);
   if (!ctx || !pk || !z || !out_h) return ZKMI_ERR_BAD_ARG;
   int32_t rc = witness_map_dev(ctx, pk, z, nullptr, ctx->stream);
   if (rc != ZKMI_OK) return rc;
@@ -611,12 +615,14 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
 
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
                            const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  ZK_ENTER(ctx);
   if (!z) return ZKMI_ERR_BAD_ARG;
   return prove_impl(ctx, pk, z, nullptr, r_bytes, s_bytes, out_proof);
 }
 
 int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z, const uint8_t r_bytes[32],
                                const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  ZK_ENTER(ctx);
   if (!d_z) return ZKMI_ERR_BAD_ARG;
   return prove_impl(ctx, pk, nullptr, d_z, r_bytes, s_bytes, out_proof);
 }
@@ -625,6 +631,7 @@ int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z
 // proof i+1's device work is queued before the CPU combines proof i.
 int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
                                      const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
+  ZK_ENTER(ctx);
   if (!ctx || !pk || !d_z || !r_bytes || !s_bytes || !out_proofs) return ZKMI_ERR_BAD_ARG;
   for (uint32_t i = 0; i < n_proofs; i++) {
     if (!d_z[i]) return ZKMI_ERR_BAD_ARG;
