@@ -114,10 +114,15 @@ def pmc_traffic(path, kernel):
             write = r.get("WRITE_SIZE_avg_per_dispatch")
             if fetch is None or write is None:
                 break
+            pmc_traffic.valu = r.get("SQ_INSTS_VALU_avg_per_dispatch")
             return (fetch + write) * 1024.0, (
                 "bytes/launch = (FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) from %s (separate rocprofv3 --pmc passes of "
                 "this command; uncorrected: per-lane gathers of table entries, 64-B requests)" % (fetch, write, path))
     return None, "kernel not in %s" % path
+
+
+pmc_traffic.valu = None
+VALU_ISSUE_PEAK = 520e9  # wave-instructions/s the chip sustains on v_mad_u64_u32 chains at 2 waves/SIMD (scripts/ubench.hip)
 
 
 def main():
@@ -137,7 +142,10 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (any world size, also 1): RCCL process group, used only for the
+    # barriers around the timed region and the max-over-ranks of the elapsed time -- no data-path collective
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_pkg()
@@ -169,7 +177,7 @@ def main():
 
     ctx.prof_enable(True)
     ctx.prof_reset()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.sync()
@@ -178,10 +186,10 @@ def main():
     proof = proofs[-1] if proofs else None
     ctx.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,6 +226,18 @@ def main():
         "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
         "note": "bucket accumulation is VALU-integer bound (384-bit Montgomery products), not HBM bound; see DESIGN.md",
     }
+    if pmc_traffic.valu and avg_ms > 0:
+        # secondary fraction SURVEY.md 8(d) asks for: integer-issue rate of the same kernel
+        rate = pmc_traffic.valu / (avg_ms * 1e-3)
+        roofline["valu_issue"] = {
+            "wave_insts_per_launch": pmc_traffic.valu,
+            "achieved": rate / 1e9,
+            "peak": VALU_ISSUE_PEAK / 1e9,
+            "unit": "G wave-instr/s",
+            "frac": rate / VALU_ISSUE_PEAK,
+            "note": "SQ_INSTS_VALU (PMC summary) / live avg launch time; the kernel shares the chip with the reductions, "
+            "NTTs and the G2 accumulation running on other streams, so its own rate understates chip utilisation",
+        }
 
     out = {
         "metric": "shielder_withdraw_groth16_proofs_per_sec_2^%d_constraints" % log_n,
@@ -250,7 +270,7 @@ def main():
         print(json.dumps(out), flush=True)
     pk.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
