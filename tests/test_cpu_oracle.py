@@ -122,3 +122,56 @@ def test_cpp_oracle_prover_golden(zk):
     assert ocpp.witness_map(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, wit) == H(gd["h"])
     pf = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, pk, wit, H(gd["r"]), H(gd["s"]))
     assert pf == H(gd["proof"])
+
+
+# ---- Poseidon ------------------------------------------------------------
+
+
+def test_poseidon_generator_matches_published_bn254_vectors():
+    """The Grain constant generator, the Cauchy MDS and the permutation reproduce circomlib's
+    published BN254 constants / test vectors (quoted from memory of circomlib's
+    poseidon_constants and test/poseidoncircuit.js; the same procedure pse-poseidon runs)."""
+    from oracle import poseidon as ps
+
+    assert ps.spec("bn254_fr", 2, 8, 56)[0][0][0] == 0x09C46E9EC68E9BD4FE1FAABA294CBA38A71AA177534CDD1B6C7DC0DBD0ABD7A7
+    assert ps.spec("bn254_fr", 3, 8, 57)[0][0][0] == 0x0EE9A592BA9A9518D05986D656F40C2114C4993C11BB29938D21D47304CD8E6E
+    assert ps.permute([0, 1, 2], "bn254_fr", 8, 57)[0] == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+    assert ps.permute([0, 1, 2, 3, 4], "bn254_fr", 8, 60)[0] == 0x299C867DB6C1FDD79DCEFA40E4510B9837E60EBB1CE0663DBAA525DF65250465
+
+
+def test_poseidon_spec_shape_and_mds_invertible():
+    from oracle import poseidon as ps
+
+    for field in ("bls12_381_fr", "bn254_fr"):
+        p, _ = ps.FIELDS[field]
+        rc, mds = ps.spec(field)
+        assert len(rc) == ps.R_F + ps.R_P and all(len(r) == ps.T_WIDTH for r in rc)
+        assert all(0 <= c < p for r in rc for c in r)
+        # Cauchy matrices are invertible: Gaussian elimination finds 5 pivots
+        m = [list(r) for r in mds]
+        for col in range(5):
+            piv = next(i for i in range(col, 5) if m[i][col] % p)
+            m[col], m[piv] = m[piv], m[col]
+            inv = pow(m[col][col], -1, p)
+            for i in range(col + 1, 5):
+                f = m[i][col] * inv % p
+                m[i] = [(a - f * b) % p for a, b in zip(m[i], m[col])]
+
+
+def test_poseidon_sponge_framing_and_merkle_path():
+    from oracle import poseidon as ps
+
+    p = ps.BLS_FR
+    # 4 inputs = RATE: one absorbing permutation + one padding-only permutation
+    st = ps.permute([(1 << 64), 1, 2, 3, 4])
+    st[1] = (st[1] + 1) % p
+    assert ps.hash_fix_len([1, 2, 3, 4]) == ps.permute(st)[1]
+    # 2 inputs: a single permutation with the padding 1 behind the inputs
+    assert ps.hash_fix_len([7, 9]) == ps.permute([(1 << 64), 7, 9, 1, 0])[1]
+    # Merkle path of leaf 5 in a 16-leaf tree recomputes the root (merkle_proof.rs:38-61)
+    leaves = [ps.hash_fix_len([i, i + 1]) for i in range(16)]
+    levels = ps.merkle_tree(leaves)
+    idx = 5
+    shape = [1 - ((idx >> lv) & 1) for lv in range(4)]
+    path = [levels[lv][(idx >> lv) ^ 1] for lv in range(4)]
+    assert ps.merkle_root(leaves[idx], shape, path) == levels[-1][0]
