@@ -181,6 +181,31 @@ int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, u
 int32_t zkmi_r1cs_export(const zkmi_r1cs* r, int32_t m, uint32_t* rowptr, uint32_t* col, uint8_t* val, uint64_t* nnz);
 int32_t zkmi_r1cs_is_satisfied(const zkmi_r1cs* r, const uint8_t* z);
 
+/* ---- Poseidon-5 ------------------------------------------ *
+ * T_WIDTH = 5, RATE = 4, R_F = 8, R_P = 56, S-box x^5
+ * (shielder/relations/src/lib.rs:17-26); hashing = PoseidonHasher::hash_fix_len_array
+ * (update_note.rs:100,131; update_account.rs:62; merkle_proof.rs:56): state
+ * [2^64,0,0,0,0], inputs added to state[1..], a 1 added behind the last input,
+ * an extra padding-only permutation when len % 4 == 0, output state[1].
+ * Constants are generated with the Grain LFSR procedure of the Poseidon paper
+ * (what halo2-base's OptimizedPoseidonSpec::new::<8,56,0>() runs; crate not in
+ * tree).  field: the scalar field of BLS12-381 (the prover's) or of BN254 (the
+ * field the reference's relations are written over). */
+#define ZKMI_FIELD_BLS12_381_FR 0
+#define ZKMI_FIELD_BN254_FR 1
+/* constants in canonical LE form: out_rc = 64 x 5 x 32 B (round-major), out_mds = 5 x 5 x 32 B (row-major) */
+int32_t zkmi_poseidon_spec(int32_t field, uint8_t* out_rc, uint8_t* out_mds);
+/* n_hashes independent hash_fix_len_array calls of `arity` (0..64) inputs each, on the device.
+ * in: n_hashes x arity x 32 B canonical LE (< modulus), out: n_hashes x 32 B. */
+int32_t zkmi_poseidon_hash_batch(zkmi_ctx* ctx, int32_t field, const uint8_t* in, uint64_t n_hashes, uint32_t arity,
+                                 uint8_t* out);
+int32_t zkmi_poseidon_hash_batch_dev(zkmi_ctx* ctx, int32_t field, const void* d_in, uint64_t n_hashes, uint32_t arity,
+                                     void* d_out);
+/* Binary Poseidon Merkle tree (node = hash_fix_len_array([left, right]), merkle_proof.rs:56):
+ * d_nodes holds 2^(log_leaves+1) - 1 elements of 32 B; the caller fills the first 2^log_leaves
+ * (the leaves); each level is appended behind the previous one, the root is the last element. */
+int32_t zkmi_poseidon_merkle_tree_dev(zkmi_ctx* ctx, int32_t field, void* d_nodes, uint32_t log_leaves);
+
 /* ---- rows a7, a10: Groth16 ------------------------------------------------ */
 /* Trusted setup with explicit toxic waste tau|alpha|beta|gamma|delta
  * (5 x 32 B), heavy part (fixed-base multiplications) on the device.  The

@@ -260,3 +260,16 @@ def test_fr_reduce(zk, pkg):
     with pytest.raises(pkg.ZkmiError) as e:
         zk.shielder_witness_from_input(8, inp)
     assert e.value.code == -2
+
+
+def test_poseidon_constants_match_oracle(zk):
+    """The library's Grain/Cauchy generator (host code in poseidon.hip) == oracle/poseidon.py for
+    both fields; the oracle in turn is pinned by published BN254 vectors (test_cpu_oracle.py)."""
+    from oracle import poseidon as ps
+
+    for field, name in ((0, "bls12_381_fr"), (1, "bn254_fr")):
+        rc, mds = zk.poseidon_spec(field)
+        orc, omds = ps.spec(name)
+        assert rc == [list(r) for r in orc]
+        assert mds == [list(r) for r in omds]
+    assert zk.poseidon_spec(1)[0][0][0] != zk.poseidon_spec(0)[0][0][0]

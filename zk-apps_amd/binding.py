@@ -225,6 +225,17 @@ class Zkmi:
         self._chk(self.lib.zkmi_shielder_witness(C.c_uint32(log_n), C.c_uint64(seed), out))
         return bytes(out)
 
+    # ---- Poseidon-5 ---------------------------------------
+    def poseidon_spec(self, field=0):
+        """(round constants [64][5], mds [5][5]) as ints, straight from the library's generator."""
+        rc = (C.c_uint8 * (32 * 64 * 5))()
+        mds = (C.c_uint8 * (32 * 25))()
+        self._chk(self.lib.zkmi_poseidon_spec(C.c_int32(field), rc, mds))
+        r, m = bytes(rc), bytes(mds)
+        ints = lambda raw, n: [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(n)]
+        rl, ml = ints(r, 320), ints(m, 25)
+        return [rl[5 * i : 5 * i + 5] for i in range(64)], [ml[5 * i : 5 * i + 5] for i in range(5)]
+
     def fr_reduce(self, b32):
         out = (C.c_uint8 * 32)()
         self._chk(self.lib.zkmi_fr_reduce(_buf(b32), out))
@@ -453,6 +464,19 @@ class Context:
         out = (C.c_uint8 * 192)()
         self._chk(self.lib.zkmi_msm_g2_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
         return bytes(out)
+
+    def poseidon_hash_batch(self, inputs, n_hashes, arity, field=0):
+        """n_hashes x arity canonical 32-byte inputs (bytes) -> n_hashes x 32 bytes, hashed on the GPU."""
+        assert len(inputs) == 32 * n_hashes * arity
+        out = (C.c_uint8 * (32 * max(1, n_hashes)))()
+        self._chk(self.lib.zkmi_poseidon_hash_batch(self.h, C.c_int32(field), _buf(inputs), C.c_uint64(n_hashes), C.c_uint32(arity), out))
+        return bytes(out)[: 32 * n_hashes]
+
+    def poseidon_hash_batch_dev(self, d_in, n_hashes, arity, d_out, field=0):
+        self._chk(self.lib.zkmi_poseidon_hash_batch_dev(self.h, C.c_int32(field), C.c_void_p(d_in), C.c_uint64(n_hashes), C.c_uint32(arity), C.c_void_p(d_out)))
+
+    def poseidon_merkle_tree_dev(self, d_nodes, log_leaves, field=0):
+        self._chk(self.lib.zkmi_poseidon_merkle_tree_dev(self.h, C.c_int32(field), C.c_void_p(d_nodes), C.c_uint32(log_leaves)))
 
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
         out = (C.c_uint8 * (96 * 64))()

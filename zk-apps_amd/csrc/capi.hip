@@ -109,6 +109,8 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   ctx->g2.release();
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
+  for (void* p : ctx->d_pos)
+    if (p) (void)hipFree(p);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
   if (ctx->stream_g2) (void)hipStreamDestroy(ctx->stream_g2);

@@ -26,6 +26,7 @@ struct zkmi_ctx {
   void* d_tmp = nullptr;  // staging for host-buffer entry points
   uint64_t d_tmp_cap = 0;
   void* d_work = nullptr;  // limb-form work buffer of the NTT entry points
+  void* d_pos[2] = {nullptr, nullptr};  // Poseidon constants per field (poseidon.hip)
   uint64_t d_work_cap = 0;
 
   zkmi::PhaseTimer* timer() { return prof.enabled ? &prof : nullptr; }

@@ -47,6 +47,26 @@ struct Fr28Params {
                                       0x26172ba, 0x6854f56, 0x3973f39, 0xbc66e55, 0x0000006};
   static constexpr int32_t R2[10] = {0xc31bba9, 0x3b3440e, 0xe045fb0, 0x8929657, 0x57c6e1a,
                                      0x2d645cf, 0x012ecf5, 0xea6a1c5, 0xc7b9d12, 0x0000003};
+  static constexpr uint32_t MOD32[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                        0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+  static constexpr int NUM_BITS = 255;
+};
+
+// BN254 scalar field (halo2curves::bn256::Fr, the field the reference's relations are written
+// over: shielder/Cargo.lock:454-478); used by the Poseidon kernels only.
+struct BnFr28Params {
+  static constexpr int NL = 10;
+  static constexpr int N32 = 8;
+  static constexpr uint32_t INV = 0xfffffffu;
+  static constexpr int32_t MOD[10] = {0x0000001, 0xe1f593f, 0x9709143, 0xe84879b, 0x85d2833,
+                                      0xb681815, 0x9b85045, 0xe131a02, 0x0644e72, 0x0000003};
+  static constexpr int32_t ONE[10] = {0xab5b8ba, 0xa771fc5, 0x1e556e4, 0x939ee8c, 0xdd60d0e,
+                                      0x105a695, 0x89f6e5c, 0x8c59c9e, 0x7359fa8, 0x0000000};
+  static constexpr int32_t R2[10] = {0xf4ec6b4, 0x9b2c977, 0x8aa70ff, 0x88742bb, 0xae1fcf6,
+                                     0xff538b3, 0xbf33da0, 0xa1d99a8, 0xa45a5a6, 0x0000000};
+  static constexpr uint32_t MOD32[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr int NUM_BITS = 254;
 };
 
 template <class P>
@@ -277,6 +297,7 @@ struct Fp28 {
 };
 
 using Fq28 = Fp28<Fq28Params>;
+using BnFr28 = Fp28<BnFr28Params>;
 using Fr28 = Fp28<Fr28Params>;  // scalar field: NTT / witness map (values may grow to ~2^21 r between products)
 
 // ---- Fq2 components with lazy reduction (overloads of field.hpp's generic forms) ----

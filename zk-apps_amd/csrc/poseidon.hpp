@@ -1,0 +1,111 @@
+// zkmi — Poseidon-5 (x^5) over a 255/254-bit scalar field in the 28-bit limb form.
+//
+// Parameters fixed by the reference's relations (shielder/relations/src/lib.rs:17-26):
+//   T_WIDTH = 5, RATE = 4, R_F = 8, R_P = 56; hashing call = PoseidonHasher::hash_fix_len_array
+//   (update_note.rs:100,131; update_account.rs:62; merkle_proof.rs:56).
+// The arithmetic itself is in crates that are not in the tree (halo2-base 0.4.1, pse-poseidon
+// 0.2.0); what is restated here is their published procedure: Grain-LFSR round
+// constants + Cauchy MDS (poseidon.hip), plain ARK -> S-box -> MDS rounds, and the sponge framing
+// [2^64, 0, 0, 0, 0] / "+1" padding / output state[1].
+//
+// One code path for host (witness generation of a single relation instance) and device (batched
+// hashing, Merkle trees): everything below is __host__ __device__.
+#pragma once
+#include "field28.hpp"
+
+namespace zkmi {
+
+constexpr int POS_T = 5, POS_RATE = 4, POS_RF = 8, POS_RP = 56, POS_ROUNDS = POS_RF + POS_RP;
+
+// Montgomery-form constants as they sit in HBM (13.8 KB; uniform addresses -> scalar loads)
+template <class F>
+struct PoseidonConsts {
+  F rc[POS_ROUNDS * POS_T];
+  F mds[POS_T * POS_T];  // row-major: new[i] = sum_j mds[5 i + j] * state[j]
+  F cap;                 // 2^64, the initial capacity element
+};
+
+// sum_j m[j] * s[j] with ONE Montgomery reduction: 50 partial products of < 2^56 per column
+// stay below 2^62 in the 64-bit accumulators (operands normalised, |v| < 4 p).
+template <class F>
+ZK_HD F pos_dot5(const F* __restrict__ m, const F* __restrict__ s) {
+  constexpr int NL = F::NL;
+  int64_t T[2 * NL];
+#pragma unroll
+  for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+#pragma unroll
+  for (int j = 0; j < POS_T; j++)
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+      for (int k = 0; k < NL; k++) T[i + k] += (int64_t)m[j].l[i] * s[j].l[k];
+  return F::reduce(T);
+}
+
+template <class F>
+ZK_HD F pos_pow5(const F& x) {
+  const F x2 = x.sqr_inline();
+  const F x4 = x2.sqr_inline();
+  return F::mul_inline(x4, x);
+}
+
+template <class F>
+ZK_HD void pos_round(F st[POS_T], const F* __restrict__ rc, const F* __restrict__ mds, bool full) {
+#pragma unroll
+  for (int i = 0; i < POS_T; i++) st[i] = st[i] + rc[i];
+  st[0] = pos_pow5(st[0]);
+  if (full) {
+#pragma unroll
+    for (int i = 1; i < POS_T; i++) st[i] = pos_pow5(st[i]);
+  }
+  F nx[POS_T];
+#pragma unroll
+  for (int i = 0; i < POS_T; i++) nx[i] = pos_dot5(mds + POS_T * i, st);
+#pragma unroll
+  for (int i = 0; i < POS_T; i++) st[i] = nx[i];
+}
+
+template <class F>
+ZK_HD void poseidon_permute(F st[POS_T], const PoseidonConsts<F>* __restrict__ c) {
+  int r = 0;
+#pragma unroll 1
+  for (; r < POS_RF / 2; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
+#pragma unroll 1
+  for (; r < POS_RF / 2 + POS_RP; r++) pos_round(st, c->rc + POS_T * r, c->mds, false);
+#pragma unroll 1
+  for (; r < POS_ROUNDS; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
+}
+
+// hash_fix_len_array over `len` canonical 32-byte little-endian inputs (8 words each)
+template <class F>
+ZK_HD F poseidon_hash_words(const uint32_t* __restrict__ in, uint32_t len, const PoseidonConsts<F>* __restrict__ c) {
+  F st[POS_T];
+  st[0] = c->cap;
+#pragma unroll
+  for (int i = 1; i < POS_T; i++) st[i] = F::zero();
+  uint32_t done = 0;
+  bool more = true;
+#pragma unroll 1
+  while (more) {
+    const uint32_t take = (len - done) < (uint32_t)POS_RATE ? (len - done) : (uint32_t)POS_RATE;
+#pragma unroll
+    for (int i = 0; i < POS_RATE; i++) {
+      if ((uint32_t)i < take) st[1 + i] = st[1 + i] + F::from_canonical(in + 8 * (done + i));
+      if ((uint32_t)i == take) st[1 + i] = st[1 + i] + F::one();  // padding behind the last input
+    }
+    done += take;
+    poseidon_permute(st, c);
+    // a full last chunk is followed by a padding-only permutation (take == 0 next time round)
+    more = (take == (uint32_t)POS_RATE);
+  }
+  return st[1];
+}
+
+// host: constants in canonical form (rc: 64 x 5 x 32 B, mds: 25 x 32 B) for field 0 = BLS12-381 Fr,
+// 1 = BN254 Fr; generated once per process
+const uint8_t* poseidon_rc_canonical(int field);
+const uint8_t* poseidon_mds_canonical(int field);
+const PoseidonConsts<Fr28>* poseidon_consts_bls();
+const PoseidonConsts<BnFr28>* poseidon_consts_bn();
+
+}  // namespace zkmi
