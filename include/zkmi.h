@@ -206,6 +206,35 @@ int32_t zkmi_poseidon_hash_batch_dev(zkmi_ctx* ctx, int32_t field, const void* d
  * (the leaves); each level is appended behind the previous one, the root is the last element. */
 int32_t zkmi_poseidon_merkle_tree_dev(zkmi_ctx* ctx, int32_t field, void* d_nodes, uint32_t log_leaves);
 
+/* ---- rows a1-a5 with real hashing: the update_note relation ---------------- *
+ * update_note_circuit (shielder/relations/src/relations/update_note.rs:106-149) with
+ * verify_note_circuit (:91-103), CircuitMerkleProof::verify (merkle_proof.rs:38-61)
+ * and update_account_circuit (update_account.rs:68-95) over the concrete account the
+ * mock defines (two (token, balance) slots, u128 balances; mocked_zk/src/account.rs),
+ * arithmetised as R1CS with Poseidon-5 and padded with the multiplication chain to
+ * constraints + publics = 2^log_n, variables = 2^log_n (log_n >= 14).
+ * Public inputs, in the order update_note.rs:121,127 fixes:
+ *   amount, token, user, new_note_hash, merkle_root, old_note.nullifier. */
+#define ZKMI_OP_DEPOSIT 0
+#define ZKMI_OP_WITHDRAW 1
+typedef struct {
+  zkmi_fr amount, token, user;   /* op_pub                                          */
+  zkmi_fr new_note[3];           /* zk_id, trapdoor, nullifier (account_hash derived) */
+  zkmi_fr old_note[3];           /* zk_id, trapdoor, nullifier                      */
+  uint8_t path_shape[10];        /* MerkleProof::path_shape                         */
+  zkmi_fr path[10];              /* MerkleProof::path                               */
+  zkmi_fr op_priv_user;          /* op_priv                                         */
+  zkmi_fr account[4];            /* old account: token_0, balance_0, token_1, balance_1 */
+} zkmi_note_update;
+int32_t zkmi_update_note_r1cs(uint32_t log_n, int32_t op_kind, zkmi_r1cs** out);
+/* Full assignment (2^log_n x 32 B) from the semantic inputs; the note/account hashes, the
+ * Merkle root and every S-box intermediate are computed here.  out_publics (optional)
+ * receives the 6 public inputs.  Returns ZKMI_ERR_ACCOUNT_UPDATE / ZKMI_ERR_OPERATION_COMBINE
+ * (the mock's ZkpError variants) when the update is impossible: the assignment is still
+ * written but does not satisfy the relation. */
+int32_t zkmi_update_note_witness(uint32_t log_n, int32_t op_kind, const zkmi_note_update* in, uint8_t* out_z,
+                                 uint8_t* out_publics);
+
 /* ---- rows a7, a10: Groth16 ------------------------------------------------ */
 /* Trusted setup with explicit toxic waste tau|alpha|beta|gamma|delta
  * (5 x 32 B), heavy part (fixed-base multiplications) on the device.  The

@@ -273,3 +273,87 @@ def test_poseidon_constants_match_oracle(zk):
         assert rc == [list(r) for r in orc]
         assert mds == [list(r) for r in omds]
     assert zk.poseidon_spec(1)[0][0][0] != zk.poseidon_spec(0)[0][0][0]
+
+
+def _note_update_case(zk, seed, op_kind, amount=250, balances=(1000, 77), slot=0):
+    """A valid update_note instance + the values the oracle's Poseidon gives for its hashes."""
+    from oracle import bls12_381 as ec
+    from oracle import poseidon as ps
+
+    rng = ec.SplitMix64(seed)
+    tok = [rng.fr(), rng.fr()]
+    bal = list(balances)
+    new_id, old_id, ot, on, nt, nn, user = (rng.fr() for _ in range(7))
+    old_acc = ps.hash_fix_len([tok[0], bal[0], tok[1], bal[1]])
+    old_note = ps.hash_fix_len([old_id, ot, on, old_acc])
+    shape = [rng.next() & 1 for _ in range(10)]
+    path = [rng.fr() for _ in range(10)]
+    root = ps.merkle_root(old_note, shape, path)
+    nb = list(bal)
+    nb[slot] += amount if op_kind == 0 else -amount
+    new_acc = ps.hash_fix_len([tok[0], nb[0], tok[1], nb[1]])
+    new_note = ps.hash_fix_len([new_id, nt, nn, new_acc])
+    inp = zk.note_update(amount, tok[slot], user, (new_id, nt, nn), (old_id, ot, on), shape, path, user,
+                         (tok[0], bal[0], tok[1], bal[1]))
+    publics = [amount, tok[slot], user, new_note, root, on]
+    return inp, publics
+
+
+def test_update_note_relation_hashes_match_oracle(zk):
+    """The Poseidon relation (update_note.rs:106-149 as R1CS): the witness generator's note hash and
+    Merkle root equal oracle/poseidon.py, the assignment satisfies the exported matrices under the
+    oracle's own R1CS evaluation, and tampering any public input breaks it."""
+    from oracle import groth16 as g16
+    from oracle.bls12_381 import R
+
+    lg = 14
+    for op_kind, slot in ((1, 0), (0, 1)):
+        r1 = zk.update_note_r1cs(lg, op_kind)
+        assert (r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n) == (1 << lg, 7, (1 << lg) - 7, lg)
+        inp, publics = _note_update_case(zk, 40 + op_kind, op_kind, slot=slot)
+        w, pub, rc = zk.update_note_witness(lg, op_kind, inp)
+        assert rc == 0 and pub == publics
+        assert w[32:224] == b"".join(v.to_bytes(32, "little") for v in publics)
+        assert r1.is_satisfied(w)
+        # independent evaluation by the oracle's R1CS class on the exported CSR
+        rows = []
+        for m in range(3):
+            rp, cl, vl = r1.export(m)
+            vals = [int.from_bytes(vl[32 * k : 32 * k + 32], "little") for k in range(len(cl))]
+            rows.append([[(cl[k], vals[k]) for k in range(rp[i], rp[i + 1])] for i in range(r1.n_constraints)])
+        z_int = [int.from_bytes(w[32 * i : 32 * i + 32], "little") for i in range(1 << lg)]
+        oracle_r1 = g16.R1CS(r1.n_vars, r1.n_pub, *rows)
+        assert oracle_r1.is_satisfied(z_int)
+        for k in range(1, 7):
+            bad = list(z_int)
+            bad[k] = (bad[k] + 1) % R
+            assert not oracle_r1.is_satisfied(bad), "public %d not bound" % k
+        r1.free()
+
+
+def test_update_note_relation_rejects_impossible_updates(zk):
+    """Account::update / Operation::combine failure modes of the mock (account.rs:37-82,
+    ops.rs:47-63) come back as the same error codes and as unsatisfied assignments."""
+    lg = 14
+    r1 = zk.update_note_r1cs(lg, 1)
+    base, _ = _note_update_case(zk, 7, 1)
+    import copy
+
+    def variant(**kw):
+        i = copy.deepcopy(base)
+        for name, v in kw.items():
+            import ctypes as C
+            C.memmove(getattr(i, name), int(v).to_bytes(32, "little"), 32)
+        return i
+
+    for inp, code in (
+        (variant(amount=1001), -6),          # checked_sub underflow
+        (variant(token=123456789), -6),      # token not in the account
+        (variant(op_priv_user=5), -7),       # users differ
+    ):
+        w, _, rc = zk.update_note_witness(lg, 1, inp, check=False)
+        assert rc == code
+        assert not r1.is_satisfied(w)
+    w, _, rc = zk.update_note_witness(lg, 1, variant(amount=1000))  # withdraw everything: fine
+    assert rc == 0 and r1.is_satisfied(w)
+    r1.free()

@@ -468,3 +468,45 @@ def test_poseidon_hash_large_batch_self_consistent(ctx, zk):
     for i in (0, 3, 12345, n - 1):
         a, b = (int.from_bytes(host_in[i, k].tobytes(), "little") for k in (0, 1))
         assert int.from_bytes(host_out[i].tobytes(), "little") == ps.hash_fix_len([a, b])
+
+
+def _wire_key(zk, pk, vk, toxic, r1):
+    """Proving key in wire format for the C++ oracle prover (as bench.py's cpu_baseline does)."""
+    n, N = r1.n_vars, 1 << r1.log_n
+    return {
+        "alpha_g1": vk[:96], "beta_g2": vk[96:288], "delta_g2": vk[480:672],
+        "beta_g1": zk.g1_mul(zk.g1_generator(), toxic[64:96]), "delta_g1": zk.g1_mul(zk.g1_generator(), toxic[128:160]),
+        "a_query": pk.export_query(0, 0, n), "b_g1_query": pk.export_query(1, 0, n),
+        "b_g2_query": pk.export_query(2, 0, n), "h_query": pk.export_query(3, 0, N - 1),
+        "l_query": pk.export_query(4, 0, n - r1.n_pub),
+    }
+
+
+def test_update_note_poseidon_relation_proof(ctx, zk):
+    """The reference's update_note relation with real Poseidon hashing (N = 2^14): the GPU proof
+    (a) verifies against publics computed independently by oracle/poseidon.py, (b) is byte-identical
+    to the C++ oracle prover's proof over the same key, (c) fails for any other public input."""
+    from oracle import cpp as ocpp
+    from test_cpu_host import _note_update_case
+
+    ocpp.build()
+    lg = 14
+    r1 = zk.update_note_r1cs(lg, 1)
+    rng = ec.SplitMix64(4242)
+    toxic = frs([rng.fr() for _ in range(5)])
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    inp, publics = _note_update_case(zk, 99, 1, amount=33, balances=(5, 40), slot=1)
+    wit, pub, rc = zk.update_note_witness(lg, 1, inp)
+    assert rc == 0 and pub == publics
+    r_, s_ = ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr())
+    proof = ctx.groth16_prove(pk, wit, r_, s_)
+    assert zk.groth16_verify(vk, frs(publics), proof) is True
+    for k in range(6):
+        bad = list(publics)
+        bad[k] = (bad[k] + 1) % R
+        assert zk.groth16_verify(vk, frs(bad), proof) is False
+    mats = [r1.export(m) for m in range(3)]
+    want = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, _wire_key(zk, pk, vk, toxic, r1), wit, r_, s_)
+    assert proof == want
+    pk.free()
+    r1.free()

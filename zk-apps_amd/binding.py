@@ -60,6 +60,17 @@ class OpPriv(C.Structure):
     _fields_ = [("user", Scalar)]
 
 
+class NoteUpdate(C.Structure):
+    """zkmi_note_update (include/zkmi.h): semantic inputs of the Poseidon update_note relation."""
+
+    _fields_ = [
+        ("amount", C.c_uint8 * 32), ("token", C.c_uint8 * 32), ("user", C.c_uint8 * 32),
+        ("new_note", (C.c_uint8 * 32) * 3), ("old_note", (C.c_uint8 * 32) * 3),
+        ("path_shape", C.c_uint8 * 10), ("path", (C.c_uint8 * 32) * 10),
+        ("op_priv_user", C.c_uint8 * 32), ("account", (C.c_uint8 * 32) * 4),
+    ]
+
+
 class UpdateNoteInput(C.Structure):
     """zkmi_update_note_input: semantic inputs of the withdraw-shaped relation (row a1)."""
 
@@ -235,6 +246,37 @@ class Zkmi:
         ints = lambda raw, n: [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(n)]
         rl, ml = ints(r, 320), ints(m, 25)
         return [rl[5 * i : 5 * i + 5] for i in range(64)], [ml[5 * i : 5 * i + 5] for i in range(5)]
+
+    # ---- update_note relation with real Poseidon hashing --------------------
+    def update_note_r1cs(self, log_n, op_kind):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_update_note_r1cs(C.c_uint32(log_n), C.c_int32(op_kind), C.byref(h)))
+        return R1cs(self, h)
+
+    def note_update(self, amount, token, user, new_note, old_note, path_shape, path, op_priv_user, account):
+        """Integers in, zkmi_note_update out (new_note / old_note = (zk_id, trapdoor, nullifier),
+        account = (token_0, balance_0, token_1, balance_1))."""
+        i = NoteUpdate()
+        put = lambda dst, v: C.memmove(dst, int(v).to_bytes(32, "little"), 32)
+        put(i.amount, amount), put(i.token, token), put(i.user, user), put(i.op_priv_user, op_priv_user)
+        for k in range(3):
+            put(i.new_note[k], new_note[k]), put(i.old_note[k], old_note[k])
+        for k in range(10):
+            i.path_shape[k] = int(path_shape[k])
+            put(i.path[k], path[k])
+        for k in range(4):
+            put(i.account[k], account[k])
+        return i
+
+    def update_note_witness(self, log_n, op_kind, inp, check=True):
+        """(z bytes, [6 public ints], status); raises on a non-zero status unless check=False."""
+        out = (C.c_uint8 * (32 << log_n))()
+        pub = (C.c_uint8 * (32 * 6))()
+        rc = self.lib.zkmi_update_note_witness(C.c_uint32(log_n), C.c_int32(op_kind), C.byref(inp), out, pub)
+        if check or rc in (-1, -2):
+            self._chk(rc)
+        p = bytes(pub)
+        return bytes(out), [int.from_bytes(p[32 * k : 32 * k + 32], "little") for k in range(6)], rc
 
     def fr_reduce(self, b32):
         out = (C.c_uint8 * 32)()

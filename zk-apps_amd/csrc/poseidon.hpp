@@ -54,12 +54,11 @@ ZK_HD void pos_round(F st[POS_T], const F* __restrict__ rc, const F* __restrict_
 #pragma unroll
   for (int i = 0; i < POS_T; i++) st[i] = st[i] + rc[i];
   st[0] = pos_pow5(st[0]);
+  // (these two loops stay rolled: the bodies are ~1-3 k instructions each)
   if (full) {
-#pragma unroll
     for (int i = 1; i < POS_T; i++) st[i] = pos_pow5(st[i]);
   }
   F nx[POS_T];
-#pragma unroll
   for (int i = 0; i < POS_T; i++) nx[i] = pos_dot5(mds + POS_T * i, st);
 #pragma unroll
   for (int i = 0; i < POS_T; i++) st[i] = nx[i];

@@ -1,0 +1,429 @@
+// zkmi — the reference's update_note relation as an R1CS with real Poseidon hashing (host code).
+// SURVEY.md §8a rows a1-a5, §8f-1.
+//
+// What is mirrored, statement by statement:
+//   UpdateNoteInput::new      shielder/relations/src/relations/update_note.rs:47-88   (load order)
+//   update_note_circuit       update_note.rs:106-149  (publics: op_pub || new_note_hash ||
+//                             merkle_root || old_note.nullifier; note hashes; Merkle proof;
+//                             Operation::combine; update_account_circuit)
+//   verify_note_circuit       update_note.rs:91-103
+//   CircuitMerkleProof::verify merkle_proof.rs:38-61  (is_zero, two selects, Poseidon 2 -> 1)
+//   update_account_circuit    update_account.rs:68-95 (old/new account hash checks around update)
+// The reference leaves Account / Operation generic (relations/src/account.rs, operation.rs); the
+// concrete instance used here is the one its mock defines: two (token, balance) slots, deposit /
+// withdraw of `amount` on the slot whose token equals op_pub.token, u128 balances, users of
+// op_pub and op_priv equal (mocked_zk/src/account.rs:37-82, ops.rs:47-63).
+//
+// The reference arithmetises with halo2 (PLONKish); the Groth16 path needs R1CS, so every gate
+// becomes rank-1 constraints here: x^5 = 3 products, is_zero = 2, select = 1, equality = 1,
+// 128-bit range = 129.  The relation proper has a few thousand constraints; the remainder up to
+// constraints + publics = 2^log_n is the multiplication chain SURVEY.md §8d prescribes
+// (s_{k+1} = s_k^2 + s_{k-1}, seeded from the loaded inputs).
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <utility>
+#include "ctx.hpp"
+#include "poseidon.hpp"
+#include "r1cs.hpp"
+
+namespace zkmi {
+namespace {
+
+constexpr int TREE_HEIGHT = 10;  // shielder/mocked_zk/src/lib.rs:16
+constexpr int BALANCE_BITS = 128;
+constexpr uint32_t N_PUB = 7;  // 1, amount, token, user, new_note_hash, merkle_root, old_nullifier
+
+struct Term {
+  uint32_t col;
+  Fr coef;
+};
+struct LC {
+  std::vector<Term> t;
+  Fr v = Fr::zero();
+};
+
+Fr fr_small(uint64_t x) {
+  Fr a = Fr::zero();
+  a.l[0] = (uint32_t)x;
+  a.l[1] = (uint32_t)(x >> 32);
+  return a.to_mont();
+}
+
+struct PoseidonFr {
+  Fr rc[POS_ROUNDS * POS_T], mds[POS_T * POS_T], cap;
+  PoseidonFr() {
+    const uint8_t* r = poseidon_rc_canonical(ZKMI_FIELD_BLS12_381_FR);
+    const uint8_t* m = poseidon_mds_canonical(ZKMI_FIELD_BLS12_381_FR);
+    for (int i = 0; i < POS_ROUNDS * POS_T; i++) fr_from_wire(r + 32 * i, &rc[i]);
+    for (int i = 0; i < POS_T * POS_T; i++) fr_from_wire(m + 32 * i, &mds[i]);
+    uint8_t c[32] = {0};
+    c[8] = 1;  // 2^64
+    fr_from_wire(c, &cap);
+  }
+};
+const PoseidonFr& pos_fr() {
+  static const PoseidonFr p;
+  return p;
+}
+
+class Builder {
+ public:
+  zkmi_r1cs* r;          // constraints are recorded when non-null
+  std::vector<Fr> z;     // assignment, z[0] = 1
+  explicit Builder(zkmi_r1cs* out) : r(out) {
+    z.push_back(Fr::one());
+    if (r)
+      for (int i = 0; i < 3; i++) r->m[i].rowptr.assign(1, 0u);
+  }
+  uint32_t n_constraints = 0;
+
+  LC var(const Fr& value) {
+    z.push_back(value);
+    LC l;
+    l.t.push_back({(uint32_t)z.size() - 1, Fr::one()});
+    l.v = value;
+    return l;
+  }
+  static LC constant(const Fr& c) {
+    LC l;
+    if (!c.is_zero()) l.t.push_back({0u, c});
+    l.v = c;
+    return l;
+  }
+  // canonical form: sorted by column, equal columns merged, zero coefficients dropped
+  static void compact(LC& a) {
+    std::sort(a.t.begin(), a.t.end(), [](const Term& x, const Term& y) { return x.col < y.col; });
+    size_t w = 0;
+    for (size_t i = 0; i < a.t.size();) {
+      Term acc = a.t[i];
+      size_t j = i + 1;
+      for (; j < a.t.size() && a.t[j].col == acc.col; j++) acc.coef = acc.coef + a.t[j].coef;
+      if (!acc.coef.is_zero()) a.t[w++] = acc;
+      i = j;
+    }
+    a.t.resize(w);
+  }
+  static void add_scaled(LC& dst, const LC& src, const Fr& k) {
+    for (const Term& t : src.t) dst.t.push_back({t.col, t.coef * k});
+    dst.v = dst.v + src.v * k;
+  }
+  static LC add(const LC& a, const LC& b) {
+    LC o = a;
+    add_scaled(o, b, Fr::one());
+    compact(o);
+    return o;
+  }
+  static LC sub(const LC& a, const LC& b) {
+    LC o = a;
+    add_scaled(o, b, Fr::one().neg());
+    compact(o);
+    return o;
+  }
+  void enforce(const LC& a, const LC& b, const LC& c) {
+    n_constraints++;
+    if (!r) return;
+    const LC* rows[3] = {&a, &b, &c};
+    for (int m = 0; m < 3; m++) {
+      for (const Term& t : rows[m]->t) {
+        r->m[m].col.push_back(t.col);
+        r->m[m].val.push_back(t.coef);
+      }
+      r->m[m].rowptr.push_back((uint32_t)r->m[m].col.size());
+    }
+  }
+  LC mul(const LC& a, const LC& b) {
+    LC o = var(a.v * b.v);
+    enforce(a, b, o);
+    return o;
+  }
+  void enforce_equal(const LC& a, const LC& b) { enforce(sub(a, b), constant(Fr::one()), LC()); }
+
+  // GateInstructions::is_zero: out = 1 iff x == 0   (x * inv = 1 - out, x * out = 0)
+  LC is_zero(const LC& x) {
+    const bool zero = x.v.is_zero();
+    LC inv = var(zero ? Fr::zero() : x.v.inv());
+    LC out = var(zero ? Fr::one() : Fr::zero());
+    enforce(x, inv, sub(constant(Fr::one()), out));
+    enforce(x, out, LC());
+    return out;
+  }
+  // GateInstructions::select(a, b, sel) = sel ? a : b
+  LC select(const LC& a, const LC& b, const LC& sel) {
+    LC t = mul(sel, sub(a, b));
+    return add(t, b);
+  }
+  // value < 2^bits: bit variables b_i (b_i * (b_i - 1) = 0) with sum b_i 2^i = x
+  bool range(const LC& x, int bits) {
+    uint8_t raw[32];
+    fr_to_wire(x.v, raw);
+    bool fits = true;
+    for (int i = bits; i < 256; i++)
+      if ((raw[i >> 3] >> (i & 7)) & 1) fits = false;
+    LC sum;
+    Fr pw = Fr::one();
+    for (int i = 0; i < bits; i++) {
+      LC b = var(((raw[i >> 3] >> (i & 7)) & 1) ? Fr::one() : Fr::zero());
+      enforce(b, sub(b, constant(Fr::one())), LC());
+      add_scaled(sum, b, pw);
+      pw = pw.dbl();
+    }
+    compact(sum);
+    enforce_equal(sum, x);
+    return fits;
+  }
+
+  LC pow5(const LC& x) {
+    LC x2 = mul(x, x);
+    LC x4 = mul(x2, x2);
+    return mul(x4, x);
+  }
+  void permute(LC st[POS_T]) {
+    const PoseidonFr& p = pos_fr();
+    for (int rd = 0; rd < POS_ROUNDS; rd++) {
+      const bool full = rd < POS_RF / 2 || rd >= POS_RF / 2 + POS_RP;
+      for (int i = 0; i < POS_T; i++) st[i] = add(st[i], constant(p.rc[POS_T * rd + i]));
+      st[0] = pow5(st[0]);
+      if (full)
+        for (int i = 1; i < POS_T; i++) st[i] = pow5(st[i]);
+      LC nx[POS_T];
+      for (int i = 0; i < POS_T; i++) {
+        for (int j = 0; j < POS_T; j++) add_scaled(nx[i], st[j], p.mds[POS_T * i + j]);
+        compact(nx[i]);
+      }
+      for (int i = 0; i < POS_T; i++) st[i] = std::move(nx[i]);
+    }
+  }
+  // PoseidonHasher::hash_fix_len_array
+  LC hash(const std::vector<LC>& in) {
+    LC st[POS_T];
+    st[0] = constant(pos_fr().cap);
+    size_t done = 0;
+    for (bool more = true; more;) {
+      const size_t take = std::min<size_t>(POS_RATE, in.size() - done);
+      for (size_t i = 0; i < take; i++) st[1 + i] = add(st[1 + i], in[done + i]);
+      if (take < (size_t)POS_RATE) st[1 + take] = add(st[1 + take], constant(Fr::one()));
+      done += take;
+      permute(st);
+      more = take == (size_t)POS_RATE;
+    }
+    return st[1];
+  }
+};
+
+// Builds constraints (when r != null) and the assignment for one instance.  Returns the status a
+// prover-side caller would see: the mock's ZkpError variants for an impossible update.
+int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, zkmi_r1cs* r, std::vector<Fr>* z_out) {
+  const uint32_t N = 1u << log_n;
+  Builder b(r);
+  auto load = [&](const zkmi_fr& f, bool* ok) {
+    Fr v;
+    if (!fr_from_wire(f.bytes, &v)) *ok = false;
+    return v;
+  };
+  bool ok = true;
+  // ---- UpdateNoteInput::new: publics first, then the witnesses in its load order ----
+  LC amount = b.var(load(in.amount, &ok)), token = b.var(load(in.token, &ok)), user = b.var(load(in.user, &ok));
+  LC new_note_hash = b.var(Fr::zero());  // value patched below (computed from the loaded fields)
+  LC merkle_root = b.var(Fr::zero());
+  LC old_nullifier = b.var(load(in.old_note[2], &ok));
+  LC new_id = b.var(load(in.new_note[0], &ok)), new_trap = b.var(load(in.new_note[1], &ok)),
+     new_null = b.var(load(in.new_note[2], &ok));
+  LC new_acc_hash = b.var(Fr::zero());
+  LC old_id = b.var(load(in.old_note[0], &ok)), old_trap = b.var(load(in.old_note[1], &ok));
+  LC old_acc_hash = b.var(Fr::zero());
+  LC shape[TREE_HEIGHT], path[TREE_HEIGHT];
+  for (int i = 0; i < TREE_HEIGHT; i++) {
+    if (in.path_shape[i] > 1) ok = false;
+    shape[i] = b.var(fr_small(in.path_shape[i]));
+  }
+  for (int i = 0; i < TREE_HEIGHT; i++) path[i] = b.var(load(in.path[i], &ok));
+  LC priv_user = b.var(load(in.op_priv_user, &ok));
+  LC acc[4];
+  for (int i = 0; i < 4; i++) acc[i] = b.var(load(in.account[i], &ok));
+  if (!ok) return ZKMI_ERR_NON_CANONICAL;
+  const uint32_t n_loaded = (uint32_t)b.z.size();
+
+  int32_t status = ZKMI_OK;
+  // ---- Account::update on the host (mocked_zk/src/account.rs:37-82) -> derived field values ----
+  Fr new_bal[2] = {acc[1].v, acc[3].v};
+  {
+    int hit = -1;
+    for (int s = 0; s < 2; s++)
+      if (acc[2 * s].v == token.v && hit < 0) hit = s;
+    if (hit < 0) status = ZKMI_ERR_ACCOUNT_UPDATE;
+    else new_bal[hit] = op_kind == ZKMI_OP_DEPOSIT ? acc[2 * hit + 1].v + amount.v : acc[2 * hit + 1].v - amount.v;
+    if (acc[0].v == acc[2].v) status = ZKMI_ERR_ACCOUNT_UPDATE;  // slots must hold distinct tokens
+  }
+  if (!(priv_user.v == user.v) && status == ZKMI_OK) status = ZKMI_ERR_OPERATION_COMBINE;
+
+  // ---- update_note_circuit ----
+  // patch the derived note fields before they are hashed: the circuit recomputes them
+  auto set_value = [&](LC& l, const Fr& v) {
+    l.v = v;
+    b.z[l.t[0].col] = v;
+  };
+  {
+    // a throw-away builder computes the hashes without touching the constraint system
+    Builder h(nullptr);
+    LC oa = h.hash({Builder::constant(acc[0].v), Builder::constant(acc[1].v), Builder::constant(acc[2].v),
+                    Builder::constant(acc[3].v)});
+    LC na = h.hash({Builder::constant(acc[0].v), Builder::constant(new_bal[0]), Builder::constant(acc[2].v),
+                    Builder::constant(new_bal[1])});
+    set_value(old_acc_hash, oa.v);
+    set_value(new_acc_hash, na.v);
+    LC nn = h.hash({Builder::constant(new_id.v), Builder::constant(new_trap.v), Builder::constant(new_null.v),
+                    Builder::constant(na.v)});
+    set_value(new_note_hash, nn.v);
+    LC cur = h.hash({Builder::constant(old_id.v), Builder::constant(old_trap.v), Builder::constant(old_nullifier.v),
+                     Builder::constant(oa.v)});
+    for (int i = 0; i < TREE_HEIGHT; i++) {
+      const bool sel = shape[i].v.is_zero();
+      LC left = Builder::constant(sel ? path[i].v : cur.v), right = Builder::constant(sel ? cur.v : path[i].v);
+      cur = h.hash({left, right});
+    }
+    set_value(merkle_root, cur.v);
+  }
+
+  // verify_note_circuit(new_note, new_note_hash)
+  b.enforce_equal(b.hash({new_id, new_trap, new_null, new_acc_hash}), new_note_hash);
+  // old_note_hash, Merkle proof up to merkle_root
+  LC cur = b.hash({old_id, old_trap, old_nullifier, old_acc_hash});
+  for (int i = 0; i < TREE_HEIGHT; i++) {
+    LC sel = b.is_zero(shape[i]);
+    LC left = b.select(path[i], cur, sel);
+    LC right = b.select(cur, path[i], sel);
+    cur = b.hash({left, right});
+  }
+  b.enforce_equal(cur, merkle_root);
+  // CircuitOperation::combine(op_priv, op_pub): same user
+  b.enforce_equal(priv_user, user);
+  // update_account_circuit: verify old account, update, verify new account
+  b.enforce_equal(b.hash({acc[0], acc[1], acc[2], acc[3]}), old_acc_hash);
+  LC m0 = b.is_zero(Builder::sub(acc[0], token)), m1 = b.is_zero(Builder::sub(acc[2], token));
+  b.enforce_equal(Builder::add(m0, m1), Builder::constant(Fr::one()));
+  LC d0 = b.mul(m0, amount), d1 = b.mul(m1, amount);
+  LC nb0 = op_kind == ZKMI_OP_DEPOSIT ? Builder::add(acc[1], d0) : Builder::sub(acc[1], d0);
+  LC nb1 = op_kind == ZKMI_OP_DEPOSIT ? Builder::add(acc[3], d1) : Builder::sub(acc[3], d1);
+  // checked_add / checked_sub on u128 (account.rs:46-49, 66-69)
+  const bool fit0 = b.range(nb0, BALANCE_BITS), fit1 = b.range(nb1, BALANCE_BITS);
+  if (!(fit0 && fit1) && status == ZKMI_OK) status = ZKMI_ERR_ACCOUNT_UPDATE;
+  b.enforce_equal(b.hash({acc[0], nb0, acc[2], nb1}), new_acc_hash);
+
+  // ---- padding chain up to constraints + publics = N, variables = N ----
+  const uint32_t c_real = b.n_constraints, v_real = (uint32_t)b.z.size();
+  if ((uint64_t)c_real + N_PUB + 8 > N || (uint64_t)v_real + 8 > N) return ZKMI_ERR_BAD_ARG;  // log_n too small
+  // K chain variables, n_re re-check rows (no new variable), n_free unconstrained variables
+  int64_t K = (int64_t)N - v_real;
+  int64_t n_re = (int64_t)N - N_PUB - c_real - K;
+  uint32_t n_free = 0;
+  if (n_re < 0) {
+    n_free = (uint32_t)(-n_re);
+    K -= n_free;
+    n_re = 0;
+  }
+  LC s_prev, s_cur;
+  {
+    const LC* pub[4] = {&amount, &token, &user, &old_nullifier};
+    for (int j = 0; j < 4; j++) Builder::add_scaled(s_prev, *pub[j], fr_small(j + 1));
+    Builder::compact(s_prev);
+    for (uint32_t col = N_PUB; col < n_loaded; col++) {
+      LC one_var;
+      one_var.t.push_back({col, Fr::one()});
+      one_var.v = b.z[col];
+      Builder::add_scaled(s_cur, one_var, fr_small(col - N_PUB + 1));
+    }
+    Builder::compact(s_cur);
+  }
+  const LC s_m1 = s_prev, s_0 = s_cur;
+  std::vector<uint32_t> chain_cols;
+  chain_cols.reserve((size_t)K);
+  for (int64_t k = 0; k < K; k++) {
+    // s_{k+1} = s_k^2 + s_{k-1}   <=>   s_k * s_k = s_{k+1} - s_{k-1}
+    LC nxt = b.var(s_cur.v.sqr() + s_prev.v);
+    if (r) b.enforce(s_cur, s_cur, Builder::sub(nxt, s_prev));
+    else b.n_constraints++;
+    chain_cols.push_back(nxt.t[0].col);
+    s_prev = std::move(s_cur);
+    s_cur = std::move(nxt);
+  }
+  // re-check rows: (2 s_k) * s_k = 2 s_{k+1} - 2 s_{k-1} over the first n_re chain steps
+  {
+    auto s_at = [&](int64_t k) -> LC {  // k in [-1, K]
+      if (k == -1) return s_m1;
+      if (k == 0) return s_0;
+      LC l;
+      l.t.push_back({chain_cols[(size_t)k - 1], Fr::one()});
+      l.v = b.z[chain_cols[(size_t)k - 1]];
+      return l;
+    };
+    const Fr two = fr_small(2);
+    for (int64_t k = 0; k < n_re; k++) {
+      const int64_t kk = K > 0 ? k % K : 0;
+      LC a, c;
+      Builder::add_scaled(a, s_at(kk), two);
+      Builder::compact(a);
+      if (K > 0) {
+        Builder::add_scaled(c, s_at(kk + 1), two);
+        Builder::add_scaled(c, s_at(kk - 1), two.neg());
+        Builder::compact(c);
+        b.enforce(a, s_at(kk), c);
+      } else {
+        b.enforce(LC(), LC(), LC());
+      }
+    }
+  }
+  for (uint32_t i = 0; i < n_free; i++) b.var(Fr::zero());
+
+  if (b.z.size() != N || b.n_constraints != N - N_PUB) return ZKMI_ERR_BAD_ARG;
+  if (r) {
+    r->n_vars = N;
+    r->n_pub = N_PUB;
+    r->n_constraints = b.n_constraints;
+    r1cs_finish_shape(r);
+  }
+  if (z_out) *z_out = std::move(b.z);
+  return status;
+}
+
+}  // namespace
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int32_t zkmi_update_note_r1cs(uint32_t log_n, int32_t op_kind, zkmi_r1cs** out) {
+  if (!out || log_n < 14 || log_n > 26 || (op_kind != ZKMI_OP_DEPOSIT && op_kind != ZKMI_OP_WITHDRAW))
+    return ZKMI_ERR_BAD_ARG;
+  *out = nullptr;
+  zkmi_r1cs* r = new (std::nothrow) zkmi_r1cs();
+  if (!r) return ZKMI_ERR_BAD_ARG;
+  // the shape does not depend on the values: synthesize over a fixed valid instance
+  zkmi_note_update in;
+  memset(&in, 0, sizeof(in));
+  in.account[2].bytes[0] = 1;  // distinct token ids 0 and 1
+  const int32_t rc = synthesize(log_n, op_kind, in, r, nullptr);
+  if (rc != ZKMI_OK) {
+    delete r;
+    return rc;
+  }
+  *out = r;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_update_note_witness(uint32_t log_n, int32_t op_kind, const zkmi_note_update* in, uint8_t* out_z,
+                                 uint8_t* out_publics) {
+  if (!in || log_n < 14 || log_n > 26 || (op_kind != ZKMI_OP_DEPOSIT && op_kind != ZKMI_OP_WITHDRAW))
+    return ZKMI_ERR_BAD_ARG;
+  std::vector<Fr> z;
+  const int32_t rc = synthesize(log_n, op_kind, *in, nullptr, &z);
+  if (rc == ZKMI_ERR_BAD_ARG || rc == ZKMI_ERR_NON_CANONICAL) return rc;
+  if (out_z)
+    for (size_t i = 0; i < z.size(); i++) fr_to_wire(z[i], out_z + 32 * i);
+  if (out_publics)
+    for (uint32_t i = 1; i < N_PUB; i++) fr_to_wire(z[i], out_publics + 32 * (i - 1));
+  return rc;  // ZKMI_OK, or the mock's error for an update the relation cannot satisfy
+}
+
+}  // extern "C"
