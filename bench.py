@@ -52,13 +52,34 @@ class SplitMix64:
                 return v.to_bytes(32, "little")
 
 
-def cpu_baseline(z, ctx, sample_log_n, full_log_n):
+def relation_and_witness(z, relation, log_n, seeds):
+    """(r1cs, [witness bytes per seed]).  "poseidon": the reference's update_note relation with real
+    Poseidon-5 hashing (withdraw), padded to 2^log_n; "chain": the hash-free stand-in of the first builds."""
+    if relation == "chain":
+        return z.shielder_r1cs(log_n), [z.shielder_witness(log_n, s) for s in seeds]
+    r1 = z.update_note_r1cs(log_n, 1)
+    wits = []
+    for s in seeds:
+        rng = SplitMix64(s)
+        f = lambda: int.from_bytes(rng.fr_bytes(), "little")
+        tok = (f(), f())
+        bal = (rng.next() >> 1, rng.next() >> 1)
+        amount = bal[0] >> 3
+        user = f()
+        inp = z.note_update(amount, tok[0], user, (f(), f(), f()), (f(), f(), f()), [rng.next() & 1 for _ in range(10)],
+                            [f() for _ in range(10)], user, (tok[0], bal[0], tok[1], bal[1]))
+        w, _, _ = z.update_note_witness(log_n, 1, inp)
+        wits.append(w)
+    return r1, wits
+
+
+def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
     """In-repo C++ oracle prover ("port") on the host cores, on a bounded sample:
     one full proof at 2^sample_log_n, scaled linearly in N to 2^full_log_n."""
     from oracle import cpp as ocpp  # the checker; only this leg may touch oracle/
 
     ocpp.build()
-    r1 = z.shielder_r1cs(sample_log_n)
+    r1, (wit,) = relation_and_witness(z, relation, sample_log_n, [0x5A4B0000])
     rng = SplitMix64(0x5A4B00C0)
     toxic = b"".join(rng.fr_bytes() for _ in range(5))
     pk, vk = ctx.groth16_setup(r1, toxic)
@@ -74,7 +95,6 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n):
         "b_g2_query": pk.export_query(2, 0, n), "h_query": pk.export_query(3, 0, N - 1),
         "l_query": pk.export_query(4, 0, n - r1.n_pub),
     }
-    wit = z.shielder_witness(sample_log_n, 0x5A4B0000)
     mats = [r1.export(m) for m in range(3)]
     r, s = rng.fr_bytes(), rng.fr_bytes()
     t0 = time.time()
@@ -133,6 +153,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
     ap.add_argument("--pmc-summary", default="profiles/r01/pmc_summary_bench_steps2_final.json")
     args = ap.parse_args()
 
@@ -156,13 +177,12 @@ def main():
 
     # --- one-time preparation (not timed): relation, trusted setup on the GPU --
     t0 = time.time()
-    r1 = z.shielder_r1cs(log_n)
+    r1, wits = relation_and_witness(z, args.relation, log_n, [0x5A4B0000 + 16 * rank + i for i in range(2)])
     rng = SplitMix64(0x5A4B0001)
     toxic = b"".join(rng.fr_bytes() for _ in range(5))
     pk, vk = ctx.groth16_setup(r1, toxic)
     setup_s = time.time() - t0
     # two witnesses per rank (distinct seeds per rank), resident in HBM
-    wits = [z.shielder_witness(log_n, 0x5A4B0000 + 16 * rank + i) for i in range(2)]
     d_wits = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
     rs = [(rng.fr_bytes(), rng.fr_bytes()) for _ in range(2)]
     torch.cuda.synchronize()
@@ -255,6 +275,8 @@ def main():
         "config": {
             "workload": "single withdraw-shaped Groth16 proof, N=2^%d (7 Fr NTTs, 4 G1 MSM + 1 G2 MSM of 2^%d-1 terms), 1 proof per step per GPU"
             % (log_n, log_n),
+            "relation": "update_note (withdraw) with Poseidon-5 hashing, chain-padded to N" if args.relation == "poseidon"
+            else "hash-free chain stand-in",
             "curve": "BLS12-381",
             "independent_proofs_per_rank": args.steps,
             "proofs_in_flight_per_gpu": 2,
@@ -265,7 +287,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n)
+        out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n, args.relation)
     if rank == 0:
         print(json.dumps(out), flush=True)
     pk.free()
