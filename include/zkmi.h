@@ -205,6 +205,9 @@ int32_t zkmi_poseidon_hash_batch_dev(zkmi_ctx* ctx, int32_t field, const void* d
  * d_nodes holds 2^(log_leaves+1) - 1 elements of 32 B; the caller fills the first 2^log_leaves
  * (the leaves); each level is appended behind the previous one, the root is the last element. */
 int32_t zkmi_poseidon_merkle_tree_dev(zkmi_ctx* ctx, int32_t field, void* d_nodes, uint32_t log_leaves);
+/* Host-executed self-test: the sparse partial-round form the kernels run equals the plain
+ * 64-round definition on `iters` random states; *out_mismatches must be 0. */
+int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
 
 /* ---- rows a1-a5 with real hashing: the update_note relation ---------------- *
  * update_note_circuit (shielder/relations/src/relations/update_note.rs:106-149) with

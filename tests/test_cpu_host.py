@@ -357,3 +357,14 @@ def test_update_note_relation_rejects_impossible_updates(zk):
     w, _, rc = zk.update_note_witness(lg, 1, variant(amount=1000))  # withdraw everything: fine
     assert rc == 0 and r1.is_satisfied(w)
     r1.free()
+
+
+def test_poseidon_sparse_form_equals_definition(zk):
+    """The kernels run the partial rounds in the sparse form (one scalar constant + a sparse matrix
+    per round); host execution of the same code must equal the plain 64-round definition."""
+    import ctypes as C
+
+    for field in (0, 1):
+        bad = C.c_uint32(1)
+        assert zk.lib.zkmi_selftest_poseidon(C.c_int32(field), C.c_uint64(11 + field), C.c_uint32(40), C.byref(bad)) == 0
+        assert bad.value == 0

@@ -11,7 +11,9 @@
 //   M[i][j] = 1 / (x_i + y_j).
 // oracle/poseidon.py restates the same procedure and pins it against published BN254 vectors.
 #include <string.h>
-#include <mutex>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include <vector>
 #include "ctx.hpp"
 #include "poseidon.hpp"
@@ -113,6 +115,90 @@ struct Spec {
       }
     uint32_t cap[8] = {0, 0, 1, 0, 0, 0, 0, 0};  // 2^64
     consts.cap = F::from_canonical(cap);
+    optimize();
+  }
+
+  // Sparse form of the partial rounds.  With S = x^5 on lane 0 only, round i is x -> M S(x + c_i).
+  //  (1) constants: lanes 1..4 of c_i pass through S unchanged, so M S(x + c_i) =
+  //      M S(x + c_i[0] e0) + M (0, c_i[1..4]); the second term joins the next round's constants.
+  //      Going forward leaves one scalar per round and a remainder for the following full round.
+  //  (2) matrices: A = [[a, v], [w, B]] factors as [[1, 0], [0, B]] * [[a, v], [B^-1 w, I]]; the
+  //      left factor fixes lane 0, commutes with S and with lane-0 constants, and is absorbed into
+  //      the next round's matrix M * [[1, 0], [0, B]].  The last left factor is applied once.
+  using F = Fp28<P>;
+  static void inv4(const F in[16], F out[16]) {
+    F a[4][8];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        a[i][j] = in[4 * i + j];
+        a[i][4 + j] = i == j ? F::one() : F::zero();
+      }
+    auto is0 = [](const F& x) {
+      uint32_t w[8];
+      x.to_canonical(w);
+      uint32_t acc = 0;
+      for (int k = 0; k < 8; k++) acc |= w[k];
+      return acc == 0;
+    };
+    for (int col = 0; col < 4; col++) {
+      int piv = col;
+      while (piv < 4 && is0(a[piv][col])) piv++;
+      if (piv == 4) abort();  // singular block: cannot happen for a Cauchy-derived chain in practice
+      for (int j = 0; j < 8; j++) std::swap(a[col][j], a[piv][j]);
+      const F pinv = a[col][col].inv();
+      for (int j = 0; j < 8; j++) a[col][j] = a[col][j] * pinv;
+      for (int i = 0; i < 4; i++) {
+        if (i == col) continue;
+        const F f = a[i][col];
+        for (int j = 0; j < 8; j++) a[i][j] = a[i][j] - f * a[col][j];
+      }
+    }
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) out[4 * i + j] = a[i][4 + j];
+  }
+  void optimize() {
+    const F* M = consts.mds;
+    const int first = POS_RF / 2;
+    F d[POS_T];
+    for (int j = 0; j < POS_T; j++) d[j] = consts.rc[POS_T * first + j];
+    for (int i = 0; i < POS_RP; i++) {
+      consts.pk[i] = d[0];
+      F push[POS_T];
+      for (int r = 0; r < POS_T; r++) {
+        F acc = F::zero();
+        for (int j = 1; j < POS_T; j++) acc = acc + M[POS_T * r + j] * d[j];
+        push[r] = acc;
+      }
+      for (int j = 0; j < POS_T; j++) d[j] = consts.rc[POS_T * (first + i + 1) + j] + push[j];
+    }
+    for (int j = 0; j < POS_T; j++) consts.rc_tail[j] = d[j];
+    F A[POS_T * POS_T];
+    for (int k = 0; k < POS_T * POS_T; k++) A[k] = M[k];
+    for (int i = 0; i < POS_RP; i++) {
+      F B[16], Binv[16];
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) B[4 * r + c] = A[POS_T * (r + 1) + (c + 1)];
+      inv4(B, Binv);
+      for (int j = 0; j < POS_T; j++) consts.prow[POS_T * i + j] = A[j];
+      for (int r = 0; r < 4; r++) {
+        F acc = F::zero();
+        for (int c = 0; c < 4; c++) acc = acc + Binv[4 * r + c] * A[POS_T * (c + 1)];
+        consts.pcol[4 * i + r] = acc;
+      }
+      if (i == POS_RP - 1)
+        for (int k = 0; k < 16; k++) consts.plast[k] = B[k];
+      // A <- M * [[1, 0], [0, B]]
+      F nA[POS_T * POS_T];
+      for (int r = 0; r < POS_T; r++) {
+        nA[POS_T * r] = M[POS_T * r];
+        for (int c = 0; c < 4; c++) {
+          F acc = F::zero();
+          for (int k = 0; k < 4; k++) acc = acc + M[POS_T * r + (k + 1)] * B[4 * k + c];
+          nA[POS_T * r + (c + 1)] = acc;
+        }
+      }
+      for (int k = 0; k < POS_T * POS_T; k++) A[k] = nA[k];
+    }
   }
 };
 
@@ -182,6 +268,49 @@ int32_t zkmi_poseidon_spec(int32_t field, uint8_t* out_rc, uint8_t* out_mds) {
   if (!field_ok(field)) return ZKMI_ERR_BAD_ARG;
   if (out_rc) memcpy(out_rc, poseidon_rc_canonical(field), 32 * POS_ROUNDS * POS_T);
   if (out_mds) memcpy(out_mds, poseidon_mds_canonical(field), 32 * POS_T * POS_T);
+  return ZKMI_OK;
+}
+
+// host self-test: sparse form == plain form of the permutation on random states
+int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
+  if (!field_ok(field) || !out_mismatches) return ZKMI_ERR_BAD_ARG;
+  uint32_t bad = 0;
+  uint64_t x = seed;
+  auto next = [&]() {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t v = x;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    return v ^ (v >> 31);
+  };
+  auto run = [&](auto* consts) {
+    using F = typename std::remove_const<typename std::remove_reference<decltype(consts->cap)>::type>::type;
+    for (uint32_t it = 0; it < iters; it++) {
+      F a[POS_T], b[POS_T];
+      for (int j = 0; j < POS_T; j++) {
+        uint32_t w[8];
+        for (int k = 0; k < 8; k += 2) {
+          const uint64_t v = next();
+          w[k] = (uint32_t)v;
+          w[k + 1] = (uint32_t)(v >> 32);
+        }
+        w[7] &= 0x0fffffffu;  // < 2^252 < modulus
+        if (it == 0) memset(w, 0, sizeof(w));
+        a[j] = b[j] = F::from_canonical(w);
+      }
+      poseidon_permute_plain(a, consts);
+      poseidon_permute(b, consts);
+      for (int j = 0; j < POS_T; j++) {
+        uint32_t wa[8], wb[8];
+        a[j].to_canonical(wa);
+        b[j].to_canonical(wb);
+        if (memcmp(wa, wb, 32) != 0) bad++;
+      }
+    }
+  };
+  if (field == ZKMI_FIELD_BLS12_381_FR) run(poseidon_consts_bls());
+  else run(poseidon_consts_bn());
+  *out_mismatches = bad;
   return ZKMI_OK;
 }
 

@@ -23,6 +23,15 @@ struct PoseidonConsts {
   F rc[POS_ROUNDS * POS_T];
   F mds[POS_T * POS_T];  // row-major: new[i] = sum_j mds[5 i + j] * state[j]
   F cap;                 // 2^64, the initial capacity element
+  // Equivalent form of the 56 partial rounds (Poseidon paper, appendix B; derived in poseidon.hip):
+  // one scalar constant per round on lane 0, a sparse matrix per round (first row + first column,
+  // identity elsewhere), one 4x4 block applied after the last partial round, and the leftover
+  // constant vector folded into the first full round that follows.
+  F pk[POS_RP];               // lane-0 constants
+  F prow[POS_RP * POS_T];     // new[0] = sum_j prow[j] * s[j]
+  F pcol[POS_RP * (POS_T - 1)];  // new[j+1] = s[j+1] + pcol[j] * s[0]
+  F plast[(POS_T - 1) * (POS_T - 1)];  // s[1..] <- plast * s[1..] after the partial rounds
+  F rc_tail[POS_T];           // constants of round R_F/2 + R_P including the folded remainder
 };
 
 // sum_j m[j] * s[j] with ONE Montgomery reduction: 50 partial products of < 2^56 per column
@@ -64,13 +73,59 @@ ZK_HD void pos_round(F st[POS_T], const F* __restrict__ rc, const F* __restrict_
   for (int i = 0; i < POS_T; i++) st[i] = nx[i];
 }
 
+// the definition: 64 x (add round constants, S-box, MDS)
+template <class F>
+ZK_HD void poseidon_permute_plain(F st[POS_T], const PoseidonConsts<F>* __restrict__ c) {
+  int r = 0;
+#pragma unroll 1
+  for (; r < POS_RF / 2; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
+#pragma unroll 1
+  for (; r < POS_RF / 2 + POS_RP; r++) pos_round(st, c->rc + POS_T * r, c->mds, false);
+#pragma unroll 1
+  for (; r < POS_ROUNDS; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
+}
+
+// s0 * k + t with one reduction of the product (k, s0, t normalised)
+template <class F>
+ZK_HD F pos_mul_add(const F& k, const F& s0, const F& t) {
+  return F::mul_inline(k, s0) + t;
+}
+
+// same permutation, partial rounds in the sparse form: 9 instead of 25 products per round
 template <class F>
 ZK_HD void poseidon_permute(F st[POS_T], const PoseidonConsts<F>* __restrict__ c) {
   int r = 0;
 #pragma unroll 1
   for (; r < POS_RF / 2; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
 #pragma unroll 1
-  for (; r < POS_RF / 2 + POS_RP; r++) pos_round(st, c->rc + POS_T * r, c->mds, false);
+  for (int i = 0; i < POS_RP; i++) {
+    st[0] = pos_pow5(st[0] + c->pk[i]);
+    const F n0 = pos_dot5(c->prow + POS_T * i, st);
+#pragma unroll
+    for (int j = 0; j < POS_T - 1; j++) st[j + 1] = pos_mul_add(c->pcol[(POS_T - 1) * i + j], st[0], st[j + 1]);
+    st[0] = n0;
+  }
+  {
+    F t[POS_T - 1];
+#pragma unroll
+    for (int i = 0; i < POS_T - 1; i++) {
+      constexpr int NL = F::NL;
+      int64_t T[2 * NL];
+#pragma unroll
+      for (int q = 0; q < 2 * NL; q++) T[q] = 0;
+#pragma unroll
+      for (int j = 0; j < POS_T - 1; j++)
+#pragma unroll
+        for (int a = 0; a < NL; a++)
+#pragma unroll
+          for (int b = 0; b < NL; b++) T[a + b] += (int64_t)c->plast[(POS_T - 1) * i + j].l[a] * st[j + 1].l[b];
+      t[i] = F::reduce(T);
+    }
+#pragma unroll
+    for (int i = 0; i < POS_T - 1; i++) st[i + 1] = t[i];
+  }
+  pos_round(st, c->rc_tail, c->mds, true);
+  r = POS_RF / 2 + POS_RP + 1;
 #pragma unroll 1
   for (; r < POS_ROUNDS; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
 }
