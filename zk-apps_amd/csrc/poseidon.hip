@@ -210,12 +210,13 @@ const Spec<P>& spec() {
 
 // ---- device ---------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void k_poseidon_hash(const uint32_t* __restrict__ in, uint64_t n, uint32_t arity,
+__global__ __launch_bounds__(256, 3) void k_poseidon_hash(const uint32_t* __restrict__ in, uint64_t n, uint32_t arity,
                                                        uint32_t* __restrict__ out,
                                                        const PoseidonConsts<F>* __restrict__ c) {
+  __shared__ int32_t tile[POS_LDS_WORDS];  // full-round state, one column per thread
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const F h = poseidon_hash_words<F>(in + 8ull * arity * i, arity, c);
+  const F h = poseidon_hash_words_lds<F>(in + 8ull * arity * i, arity, c, tile + threadIdx.x);
   uint32_t w[8];
   h.to_canonical(w);
   uint4* o = reinterpret_cast<uint4*>(out + 8ull * i);

@@ -73,6 +73,127 @@ ZK_HD void pos_round(F st[POS_T], const F* __restrict__ rc, const F* __restrict_
   for (int i = 0; i < POS_T; i++) st[i] = nx[i];
 }
 
+// ---- device form: the state lives in this thread's column of an LDS tile -------------------
+// Layout [element][limb][thread] (bank-conflict free), 5 x 10 words x 256 threads = 50 KB per block,
+// three blocks per CU.  Every loop over state elements stays rolled and loads its operand just in
+// time, so the register footprint is one accumulator set + two elements instead of the whole
+// state (the all-in-registers form needs 255 VGPRs or spills ~1.4 KB per lane to scratch).
+// No barrier anywhere: a thread only touches its own column.
+constexpr int POS_LDS_WORDS = POS_T * Fr28::NL * 256;
+#if defined(__HIPCC__)
+template <class F>
+__device__ __forceinline__ void pos_lds_store(int32_t* col, int elem, const F& v) {
+#pragma unroll
+  for (int k = 0; k < F::NL; k++) col[(elem * F::NL + k) * 256] = v.l[k];
+}
+template <class F>
+__device__ __forceinline__ F pos_lds_load(const int32_t* col, int elem) {
+  F v;
+#pragma unroll
+  for (int k = 0; k < F::NL; k++) v.l[k] = col[(elem * F::NL + k) * 256];
+  return v;
+}
+template <class F>
+__device__ __forceinline__ void pos_mac(int64_t* T, const F& a, const F& b) {
+#pragma unroll
+  for (int i = 0; i < F::NL; i++)
+#pragma unroll
+    for (int k = 0; k < F::NL; k++) T[i + k] += (int64_t)a.l[i] * b.l[k];
+}
+// sum_j row[j] * state[first + j], j < n, operands streamed from LDS
+template <class F>
+__device__ __forceinline__ F pos_dot_lds(const F* __restrict__ row, const int32_t* col, int first, int n) {
+  int64_t T[2 * F::NL];
+#pragma unroll
+  for (int i = 0; i < 2 * F::NL; i++) T[i] = 0;
+#pragma unroll 1
+  for (int j = 0; j < n; j++) pos_mac(T, row[j], pos_lds_load<F>(col, first + j));
+  return F::reduce(T);
+}
+template <class F>
+__device__ __forceinline__ void pos_round_full_lds(const F* __restrict__ rc, const F* __restrict__ mds, int32_t* col) {
+#pragma unroll 1
+  for (int i = 0; i < POS_T; i++) pos_lds_store(col, i, pos_pow5(pos_lds_load<F>(col, i) + rc[i]));
+  // the five outputs wait in registers (rotated into place) until the inputs are no longer needed
+  F nx[POS_T];
+#pragma unroll
+  for (int i = 0; i < POS_T; i++) nx[i] = F::zero();
+#pragma unroll 1
+  for (int i = 0; i < POS_T; i++) {
+    const F y = pos_dot_lds<F>(mds + POS_T * i, col, 0, POS_T);
+    nx[0] = nx[1];
+    nx[1] = nx[2];
+    nx[2] = nx[3];
+    nx[3] = nx[4];
+    nx[4] = y;
+  }
+#pragma unroll
+  for (int i = 0; i < POS_T; i++) pos_lds_store(col, i, nx[i]);
+}
+// the permutation on the LDS-resident state (sparse partial rounds, see PoseidonConsts)
+template <class F>
+__device__ __forceinline__ void poseidon_permute_lds(int32_t* col, const PoseidonConsts<F>* __restrict__ c) {
+  int r = 0;
+#pragma unroll 1
+  for (; r < POS_RF / 2; r++) pos_round_full_lds<F>(c->rc + POS_T * r, c->mds, col);
+#pragma unroll 1
+  for (int i = 0; i < POS_RP; i++) {
+    const F x0 = pos_pow5(pos_lds_load<F>(col, 0) + c->pk[i]);
+    int64_t T[2 * F::NL];
+#pragma unroll
+    for (int q = 0; q < 2 * F::NL; q++) T[q] = 0;
+    pos_mac(T, c->prow[POS_T * i], x0);
+#pragma unroll 1
+    for (int j = 1; j < POS_T; j++) pos_mac(T, c->prow[POS_T * i + j], pos_lds_load<F>(col, j));
+    const F n0 = F::reduce(T);
+#pragma unroll 1
+    for (int j = 1; j < POS_T; j++)
+      pos_lds_store(col, j, F::mul_inline(c->pcol[(POS_T - 1) * i + j - 1], x0) + pos_lds_load<F>(col, j));
+    pos_lds_store(col, 0, n0);
+  }
+  {
+    F t[POS_T - 1];
+#pragma unroll
+    for (int i = 0; i < POS_T - 1; i++) t[i] = F::zero();
+#pragma unroll 1
+    for (int i = 0; i < POS_T - 1; i++) {
+      const F y = pos_dot_lds<F>(c->plast + (POS_T - 1) * i, col, 1, POS_T - 1);
+      t[0] = t[1];
+      t[1] = t[2];
+      t[2] = t[3];
+      t[3] = y;
+    }
+#pragma unroll
+    for (int i = 0; i < POS_T - 1; i++) pos_lds_store(col, i + 1, t[i]);
+  }
+#pragma unroll 1
+  for (r = POS_RF / 2 + POS_RP; r < POS_ROUNDS; r++)
+    pos_round_full_lds<F>(r == POS_RF / 2 + POS_RP ? c->rc_tail : c->rc + POS_T * r, c->mds, col);
+}
+// hash_fix_len_array, device form
+template <class F>
+__device__ __forceinline__ F poseidon_hash_words_lds(const uint32_t* __restrict__ in, uint32_t len,
+                                                     const PoseidonConsts<F>* __restrict__ c, int32_t* col) {
+  pos_lds_store(col, 0, c->cap);
+#pragma unroll 1
+  for (int i = 1; i < POS_T; i++) pos_lds_store(col, i, F::zero());
+  uint32_t done = 0;
+  bool more = true;
+#pragma unroll 1
+  while (more) {
+    const uint32_t take = (len - done) < (uint32_t)POS_RATE ? (len - done) : (uint32_t)POS_RATE;
+#pragma unroll 1
+    for (uint32_t i = 0; i < take; i++)
+      pos_lds_store(col, 1 + i, pos_lds_load<F>(col, 1 + i) + F::from_canonical(in + 8 * (done + i)));
+    if (take < (uint32_t)POS_RATE) pos_lds_store(col, 1 + take, pos_lds_load<F>(col, 1 + take) + F::one());
+    done += take;
+    poseidon_permute_lds<F>(col, c);
+    more = (take == (uint32_t)POS_RATE);
+  }
+  return pos_lds_load<F>(col, 1);
+}
+#endif
+
 // the definition: 64 x (add round constants, S-box, MDS)
 template <class F>
 ZK_HD void poseidon_permute_plain(F st[POS_T], const PoseidonConsts<F>* __restrict__ c) {
@@ -92,6 +213,8 @@ ZK_HD F pos_mul_add(const F& k, const F& s0, const F& t) {
 }
 
 // same permutation, partial rounds in the sparse form: 9 instead of 25 products per round
+// (register-array form: host witness generation and the host self-test; the kernels run
+// poseidon_permute_lds, the same sequence on an LDS-resident state)
 template <class F>
 ZK_HD void poseidon_permute(F st[POS_T], const PoseidonConsts<F>* __restrict__ c) {
   int r = 0;
@@ -106,28 +229,36 @@ ZK_HD void poseidon_permute(F st[POS_T], const PoseidonConsts<F>* __restrict__ c
     st[0] = n0;
   }
   {
+    // s[1..4] <- plast * s[1..4]; rolled, results rotated into place (constant indices only)
     F t[POS_T - 1];
 #pragma unroll
+    for (int i = 0; i < POS_T - 1; i++) t[i] = F::zero();
+#pragma unroll 1
     for (int i = 0; i < POS_T - 1; i++) {
       constexpr int NL = F::NL;
       int64_t T[2 * NL];
 #pragma unroll
       for (int q = 0; q < 2 * NL; q++) T[q] = 0;
+      const F* __restrict__ row = c->plast + (POS_T - 1) * i;
 #pragma unroll
       for (int j = 0; j < POS_T - 1; j++)
 #pragma unroll
         for (int a = 0; a < NL; a++)
 #pragma unroll
-          for (int b = 0; b < NL; b++) T[a + b] += (int64_t)c->plast[(POS_T - 1) * i + j].l[a] * st[j + 1].l[b];
-      t[i] = F::reduce(T);
+          for (int b = 0; b < NL; b++) T[a + b] += (int64_t)row[j].l[a] * st[j + 1].l[b];
+      const F y = F::reduce(T);
+      t[0] = t[1];
+      t[1] = t[2];
+      t[2] = t[3];
+      t[3] = y;
     }
 #pragma unroll
     for (int i = 0; i < POS_T - 1; i++) st[i + 1] = t[i];
   }
-  pos_round(st, c->rc_tail, c->mds, true);
-  r = POS_RF / 2 + POS_RP + 1;
+  // second half: the first of its rounds uses the constants with the folded remainder
 #pragma unroll 1
-  for (; r < POS_ROUNDS; r++) pos_round(st, c->rc + POS_T * r, c->mds, true);
+  for (r = POS_RF / 2 + POS_RP; r < POS_ROUNDS; r++)
+    pos_round(st, r == POS_RF / 2 + POS_RP ? c->rc_tail : c->rc + POS_T * r, c->mds, true);
 }
 
 // hash_fix_len_array over `len` canonical 32-byte little-endian inputs (8 words each)
