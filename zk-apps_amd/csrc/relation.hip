@@ -335,41 +335,54 @@ int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, 
     }
     Builder::compact(s_cur);
   }
-  const LC s_m1 = s_prev, s_0 = s_cur;
-  std::vector<uint32_t> chain_cols;
-  chain_cols.reserve((size_t)K);
-  for (int64_t k = 0; k < K; k++) {
-    // s_{k+1} = s_k^2 + s_{k-1}   <=>   s_k * s_k = s_{k+1} - s_{k-1}
-    LC nxt = b.var(s_cur.v.sqr() + s_prev.v);
-    if (r) b.enforce(s_cur, s_cur, Builder::sub(nxt, s_prev));
-    else b.n_constraints++;
-    chain_cols.push_back(nxt.t[0].col);
-    s_prev = std::move(s_cur);
-    s_cur = std::move(nxt);
-  }
-  // re-check rows: (2 s_k) * s_k = 2 s_{k+1} - 2 s_{k-1} over the first n_re chain steps
-  {
-    auto s_at = [&](int64_t k) -> LC {  // k in [-1, K]
-      if (k == -1) return s_m1;
-      if (k == 0) return s_0;
-      LC l;
-      l.t.push_back({chain_cols[(size_t)k - 1], Fr::one()});
-      l.v = b.z[chain_cols[(size_t)k - 1]];
-      return l;
-    };
-    const Fr two = fr_small(2);
-    for (int64_t k = 0; k < n_re; k++) {
-      const int64_t kk = K > 0 ? k % K : 0;
-      LC a, c;
-      Builder::add_scaled(a, s_at(kk), two);
-      Builder::compact(a);
-      if (K > 0) {
-        Builder::add_scaled(c, s_at(kk + 1), two);
-        Builder::add_scaled(c, s_at(kk - 1), two.neg());
-        Builder::compact(c);
-        b.enforce(a, s_at(kk), c);
-      } else {
-        b.enforce(LC(), LC(), LC());
+  if (!r) {
+    // assignment only: the chain is a tight value loop (1 squaring + 1 addition per variable)
+    b.z.reserve(N);
+    Fr sp = s_prev.v, sc = s_cur.v;
+    for (int64_t k = 0; k < K; k++) {
+      const Fr nx = sc.sqr() + sp;
+      b.z.push_back(nx);
+      sp = sc;
+      sc = nx;
+    }
+    b.n_constraints += (uint32_t)(K + n_re);
+  } else {
+    const LC s_m1 = s_prev, s_0 = s_cur;
+    std::vector<uint32_t> chain_cols;
+    chain_cols.reserve((size_t)K);
+    for (int64_t k = 0; k < K; k++) {
+      // s_{k+1} = s_k^2 + s_{k-1}   <=>   s_k * s_k = s_{k+1} - s_{k-1}
+      LC nxt = b.var(s_cur.v.sqr() + s_prev.v);
+      if (r) b.enforce(s_cur, s_cur, Builder::sub(nxt, s_prev));
+      else b.n_constraints++;
+      chain_cols.push_back(nxt.t[0].col);
+      s_prev = std::move(s_cur);
+      s_cur = std::move(nxt);
+    }
+    // re-check rows: (2 s_k) * s_k = 2 s_{k+1} - 2 s_{k-1} over the first n_re chain steps
+    {
+      auto s_at = [&](int64_t k) -> LC {  // k in [-1, K]
+        if (k == -1) return s_m1;
+        if (k == 0) return s_0;
+        LC l;
+        l.t.push_back({chain_cols[(size_t)k - 1], Fr::one()});
+        l.v = b.z[chain_cols[(size_t)k - 1]];
+        return l;
+      };
+      const Fr two = fr_small(2);
+      for (int64_t k = 0; k < n_re; k++) {
+        const int64_t kk = K > 0 ? k % K : 0;
+        LC a, c;
+        Builder::add_scaled(a, s_at(kk), two);
+        Builder::compact(a);
+        if (K > 0) {
+          Builder::add_scaled(c, s_at(kk + 1), two);
+          Builder::add_scaled(c, s_at(kk - 1), two.neg());
+          Builder::compact(c);
+          b.enforce(a, s_at(kk), c);
+        } else {
+          b.enforce(LC(), LC(), LC());
+        }
       }
     }
   }
