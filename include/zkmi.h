@@ -238,6 +238,16 @@ int32_t zkmi_update_note_r1cs(uint32_t log_n, int32_t op_kind, zkmi_r1cs** out);
 int32_t zkmi_update_note_witness(uint32_t log_n, int32_t op_kind, const zkmi_note_update* in, uint8_t* out_z,
                                  uint8_t* out_publics);
 
+/* SURVEY.md 8f-1 "witness generation on device": n instances at once, one GPU thread per
+ * instance walking the same statement sequence (value-only).  `in` = host array of n inputs,
+ * d_z_out[i] = device buffer of 2^log_n x 32 B for instance i (ready for zkmi_groth16_prove_dev /
+ * _prove_batch_dev), out_status[i] = ZKMI_OK or the mock's error code for that instance. */
+int32_t zkmi_update_note_witness_batch_dev(zkmi_ctx* ctx, uint32_t log_n, int32_t op_kind, const zkmi_note_update* in,
+                                           uint32_t n, void* const* d_z_out, int32_t* out_status);
+/* the same device code executed on the host for one instance (test hook: must equal
+ * zkmi_update_note_witness byte for byte) */
+int32_t zkmi_update_note_witness_values_host(uint32_t log_n, int32_t op_kind, const zkmi_note_update* in, uint8_t* out_z);
+
 /* ---- rows a7, a10: Groth16 ------------------------------------------------ */
 /* Trusted setup with explicit toxic waste tau|alpha|beta|gamma|delta
  * (5 x 32 B), heavy part (fixed-base multiplications) on the device.  The

@@ -368,3 +368,26 @@ def test_poseidon_sparse_form_equals_definition(zk):
         bad = C.c_uint32(1)
         assert zk.lib.zkmi_selftest_poseidon(C.c_int32(field), C.c_uint64(11 + field), C.c_uint32(40), C.byref(bad)) == 0
         assert bad.value == 0
+
+
+def test_update_note_value_synthesis_equals_constraint_builder(zk):
+    """The value-only synthesis the GPU runs (relation_values.hpp, executed on the host here) yields
+    the same assignment, byte for byte, as the constraint builder — valid and impossible updates."""
+    import copy
+    import ctypes as C
+
+    lg = 14
+    for op_kind, slot in ((1, 0), (1, 1), (0, 1)):
+        inp, _ = _note_update_case(zk, 300 + 2 * op_kind + slot, op_kind, amount=50, slot=slot)
+        w, _, rc = zk.update_note_witness(lg, op_kind, inp)
+        wv, rcv = zk.update_note_witness_values_host(lg, op_kind, inp)
+        assert rc == rcv == 0
+        assert wv == w
+    base, _ = _note_update_case(zk, 8, 1)
+    for field, value, code in (("amount", 1001, -6), ("token", 99, -6), ("op_priv_user", 5, -7)):
+        i = copy.deepcopy(base)
+        C.memmove(getattr(i, field), int(value).to_bytes(32, "little"), 32)
+        w, _, rc = zk.update_note_witness(lg, 1, i, check=False)
+        wv, rcv = zk.update_note_witness_values_host(lg, 1, i)
+        assert rc == rcv == code
+        assert wv == w

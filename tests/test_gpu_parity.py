@@ -510,3 +510,44 @@ def test_update_note_poseidon_relation_proof(ctx, zk):
     assert proof == want
     pk.free()
     r1.free()
+
+
+def test_update_note_witness_batch_on_device(ctx, zk):
+    """assignments of a batch generated by one GPU thread per instance equal the host
+    generator byte for byte (valid and impossible updates, both operation kinds), and feed the
+    pipelined batch prover straight from HBM."""
+    import copy
+    import ctypes as C
+    import torch
+    from test_cpu_host import _note_update_case
+
+    lg = 14
+    n = 1 << lg
+    cases = [_note_update_case(zk, 700 + i, 1, amount=10 + i, slot=i & 1) for i in range(6)]
+    inputs = [c[0] for c in cases]
+    bad = copy.deepcopy(inputs[0])
+    C.memmove(bad.amount, (10**6).to_bytes(32, "little"), 32)  # underflow
+    inputs.append(bad)
+    bufs = [torch.zeros(32 * n, dtype=torch.uint8, device="cuda") for _ in inputs]
+    torch.cuda.synchronize()
+    status = ctx.update_note_witness_batch_dev(lg, 1, inputs, [b.data_ptr() for b in bufs])
+    assert status == [0] * 6 + [-6]
+    for inp, buf in zip(inputs, bufs):
+        w, _, _ = zk.update_note_witness(lg, 1, inp, check=False)
+        assert bytes(buf.cpu().numpy().tobytes()) == w
+    # deposits use the same kernel with the other sign
+    dep, dep_pub = _note_update_case(zk, 31, 0, amount=5, slot=0)
+    dbuf = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    assert ctx.update_note_witness_batch_dev(lg, 0, [dep], [dbuf.data_ptr()]) == [0]
+    assert bytes(dbuf.cpu().numpy().tobytes()) == zk.update_note_witness(lg, 0, dep)[0]
+    # device-generated witnesses -> batch prover, no host copy of the assignment
+    r1 = zk.update_note_r1cs(lg, 1)
+    rng = ec.SplitMix64(8080)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(6)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(6)]
+    proofs = ctx.groth16_prove_batch_dev(pk, [b.data_ptr() for b in bufs[:6]], rs, ss)
+    for (_, publics), pf in zip(cases, proofs):
+        assert zk.groth16_verify(vk, frs(publics), pf) is True
+    pk.free()
+    r1.free()

@@ -278,6 +278,14 @@ class Zkmi:
         p = bytes(pub)
         return bytes(out), [int.from_bytes(p[32 * k : 32 * k + 32], "little") for k in range(6)], rc
 
+    def update_note_witness_values_host(self, log_n, op_kind, inp):
+        """The device code path (value-only synthesis) executed on the host; test hook."""
+        out = (C.c_uint8 * (32 << log_n))()
+        rc = self.lib.zkmi_update_note_witness_values_host(C.c_uint32(log_n), C.c_int32(op_kind), C.byref(inp), out)
+        if rc in (-1, -2):
+            self._chk(rc)
+        return bytes(out), rc
+
     def fr_reduce(self, b32):
         out = (C.c_uint8 * 32)()
         self._chk(self.lib.zkmi_fr_reduce(_buf(b32), out))
@@ -506,6 +514,17 @@ class Context:
         out = (C.c_uint8 * 192)()
         self._chk(self.lib.zkmi_msm_g2_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
         return bytes(out)
+
+    def update_note_witness_batch_dev(self, log_n, op_kind, inputs, d_ptrs):
+        """Assignments of len(inputs) instances generated on the GPU into the device buffers d_ptrs
+        (each 2^log_n x 32 B); returns the per-instance status codes."""
+        n = len(inputs)
+        assert n == len(d_ptrs)
+        arr = (NoteUpdate * max(1, n))(*inputs)
+        ptrs = (C.c_void_p * max(1, n))(*[int(p) for p in d_ptrs])
+        st = (C.c_int32 * max(1, n))()
+        self._chk(self.lib.zkmi_update_note_witness_batch_dev(self.h, C.c_uint32(log_n), C.c_int32(op_kind), arr, C.c_uint32(n), ptrs, st))
+        return list(st)[:n]
 
     def poseidon_hash_batch(self, inputs, n_hashes, arity, field=0):
         """n_hashes x arity canonical 32-byte inputs (bytes) -> n_hashes x 32 bytes, hashed on the GPU."""

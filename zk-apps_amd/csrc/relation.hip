@@ -26,6 +26,7 @@
 #include "ctx.hpp"
 #include "poseidon.hpp"
 #include "r1cs.hpp"
+#include "relation_values.hpp"
 
 namespace zkmi {
 namespace {
@@ -213,7 +214,13 @@ class Builder {
 
 // Builds constraints (when r != null) and the assignment for one instance.  Returns the status a
 // prover-side caller would see: the mock's ZkpError variants for an impossible update.
-int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, zkmi_r1cs* r, std::vector<Fr>* z_out) {
+struct ChainShape {
+  uint64_t K = 0;       // chain variables
+  uint32_t n_free = 0;  // unconstrained zero variables behind the chain
+};
+
+int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, zkmi_r1cs* r, std::vector<Fr>* z_out,
+                   ChainShape* shape_out = nullptr) {
   const uint32_t N = 1u << log_n;
   Builder b(r);
   auto load = [&](const zkmi_fr& f, bool* ok) {
@@ -322,6 +329,11 @@ int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, 
     K -= n_free;
     n_re = 0;
   }
+  if (shape_out) {
+    shape_out->K = (uint64_t)K;
+    shape_out->n_free = n_free;
+    return ZKMI_OK;  // shape query: the relation proper has been walked, the padding is not needed
+  }
   LC s_prev, s_cur;
   {
     const LC* pub[4] = {&amount, &token, &user, &old_nullifier};
@@ -399,6 +411,25 @@ int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, 
   return status;
 }
 
+// K / n_free of the padding for (log_n, op_kind): walk the relation proper once on a fixed instance
+int32_t chain_shape(uint32_t log_n, int32_t op_kind, ChainShape* out) {
+  zkmi_note_update in;
+  memset(&in, 0, sizeof(in));
+  in.account[2].bytes[0] = 1;
+  return synthesize(log_n, op_kind, in, nullptr, nullptr, out);
+}
+
+// one thread = one instance (the statement sequence is sequential; a batch supplies the parallelism)
+__global__ __launch_bounds__(64) void k_update_note_values(const zkmi_note_update* __restrict__ in, uint32_t n,
+                                                          int32_t op_kind, uint64_t K, uint32_t n_free,
+                                                          const PoseidonConsts<Fr28>* __restrict__ c,
+                                                          uint32_t* const* __restrict__ z_out,
+                                                          int32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  status[i] = rv_update_note(in[i], op_kind, K, n_free, c, z_out[i]);
+}
+
 }  // namespace
 }  // namespace zkmi
 
@@ -437,6 +468,55 @@ int32_t zkmi_update_note_witness(uint32_t log_n, int32_t op_kind, const zkmi_not
   if (out_publics)
     for (uint32_t i = 1; i < N_PUB; i++) fr_to_wire(z[i], out_publics + 32 * (i - 1));
   return rc;  // ZKMI_OK, or the mock's error for an update the relation cannot satisfy
+}
+
+// The device code path (relation_values.hpp) executed on the host for ONE instance: used by the
+// CPU tests to pin it against the constraint builder above.
+int32_t zkmi_update_note_witness_values_host(uint32_t log_n, int32_t op_kind, const zkmi_note_update* in, uint8_t* out_z) {
+  if (!in || !out_z || log_n < 14 || log_n > 26 || (op_kind != ZKMI_OP_DEPOSIT && op_kind != ZKMI_OP_WITHDRAW))
+    return ZKMI_ERR_BAD_ARG;
+  ChainShape sh;
+  int32_t rc = chain_shape(log_n, op_kind, &sh);
+  if (rc != ZKMI_OK) return rc;
+  std::vector<uint32_t> z((size_t)8 << log_n);
+  rc = rv_update_note(*in, op_kind, sh.K, sh.n_free, poseidon_consts_bls(), z.data());
+  memcpy(out_z, z.data(), (size_t)32 << log_n);
+  return rc;
+}
+
+// Batch of n instances on the device: inputs are host structs, d_z_out[i] are device buffers of
+// 2^log_n x 32 B; out_status[i] receives ZKMI_OK or the mock's error code per instance.
+int32_t zkmi_update_note_witness_batch_dev(zkmi_ctx* ctx, uint32_t log_n, int32_t op_kind, const zkmi_note_update* in,
+                                           uint32_t n, void* const* d_z_out, int32_t* out_status) {
+  ZK_ENTER(ctx);
+  if (log_n < 14 || log_n > 26 || (op_kind != ZKMI_OP_DEPOSIT && op_kind != ZKMI_OP_WITHDRAW) ||
+      (n && (!in || !d_z_out || !out_status)))
+    return ZKMI_ERR_BAD_ARG;
+  if (n == 0) return ZKMI_OK;
+  ChainShape sh;
+  const int32_t rc = chain_shape(log_n, op_kind, &sh);
+  if (rc != ZKMI_OK) return rc;
+  if (!ctx->d_pos[ZKMI_FIELD_BLS12_381_FR]) {
+    ZK_HIP(ctx, hipMalloc(&ctx->d_pos[ZKMI_FIELD_BLS12_381_FR], sizeof(PoseidonConsts<Fr28>)));
+    ZK_HIP(ctx, hipMemcpy(ctx->d_pos[ZKMI_FIELD_BLS12_381_FR], poseidon_consts_bls(), sizeof(PoseidonConsts<Fr28>),
+                          hipMemcpyHostToDevice));
+  }
+  const size_t in_bytes = sizeof(zkmi_note_update) * (size_t)n, ptr_bytes = sizeof(void*) * (size_t)n;
+  const size_t off_ptr = (in_bytes + 255) & ~(size_t)255, off_st = (off_ptr + ptr_bytes + 255) & ~(size_t)255;
+  ZK_HIP(ctx, ctx->staging(off_st + sizeof(int32_t) * (size_t)n));
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_tmp);
+  ZK_HIP(ctx, hipMemcpyAsync(d, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(d + off_ptr, d_z_out, ptr_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->timer()) ctx->timer()->begin(PH_WITNESS, ctx->stream);
+  hipLaunchKernelGGL(k_update_note_values, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     reinterpret_cast<const zkmi_note_update*>(d), n, op_kind, sh.K, sh.n_free,
+                     static_cast<const PoseidonConsts<Fr28>*>(ctx->d_pos[ZKMI_FIELD_BLS12_381_FR]),
+                     reinterpret_cast<uint32_t* const*>(d + off_ptr), reinterpret_cast<int32_t*>(d + off_st));
+  if (ctx->timer()) ctx->timer()->end(PH_WITNESS, ctx->stream);
+  ZK_HIP(ctx, hipGetLastError());
+  ZK_HIP(ctx, hipMemcpyAsync(out_status, d + off_st, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
 }
 
 }  // extern "C"
