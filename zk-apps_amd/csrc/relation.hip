@@ -21,6 +21,7 @@
 // (s_{k+1} = s_k^2 + s_{k-1}, seeded from the loaded inputs).
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <utility>
 #include "ctx.hpp"
@@ -413,10 +414,30 @@ int32_t synthesize(uint32_t log_n, int32_t op_kind, const zkmi_note_update& in, 
 
 // K / n_free of the padding for (log_n, op_kind): walk the relation proper once on a fixed instance
 int32_t chain_shape(uint32_t log_n, int32_t op_kind, ChainShape* out) {
+  // K = 2^log_n - (variables of the relation proper), the same walk for every log_n: cache per kind
+  static std::mutex mu;
+  static bool known[2] = {false, false};
+  static uint64_t v_real[2];
+  static uint32_t n_free[2];
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (known[op_kind]) {
+      out->n_free = n_free[op_kind];
+      out->K = (1ull << log_n) - v_real[op_kind] - n_free[op_kind];
+      return ZKMI_OK;
+    }
+  }
   zkmi_note_update in;
   memset(&in, 0, sizeof(in));
   in.account[2].bytes[0] = 1;
-  return synthesize(log_n, op_kind, in, nullptr, nullptr, out);
+  const int32_t rc = synthesize(log_n, op_kind, in, nullptr, nullptr, out);
+  if (rc == ZKMI_OK) {
+    std::lock_guard<std::mutex> g(mu);
+    n_free[op_kind] = out->n_free;
+    v_real[op_kind] = (1ull << log_n) - out->K - out->n_free;
+    known[op_kind] = true;
+  }
+  return rc;
 }
 
 // one thread = one instance (the statement sequence is sequential; a batch supplies the parallelism)
