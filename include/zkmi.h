@@ -181,6 +181,18 @@ int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, u
 int32_t zkmi_r1cs_export(const zkmi_r1cs* r, int32_t m, uint32_t* rowptr, uint32_t* col, uint8_t* val, uint64_t* nnz);
 int32_t zkmi_r1cs_is_satisfied(const zkmi_r1cs* r, const uint8_t* z);
 
+/* ---- the contract's SHA-256 Merkle tree, batched ------------ *
+ * compute_hash / combine_merkle_hash = SHA-256(first.bytes || second.bytes)
+ * (shielder/contract/merkle.rs:24-28, shielder/mocked_zk/src/lib.rs:24-28).
+ * in: n_hashes x 2 x 32 B, out: n_hashes x 32 B. */
+int32_t zkmi_sha256_pairs(zkmi_ctx* ctx, const uint8_t* in, uint64_t n_hashes, uint8_t* out);
+int32_t zkmi_sha256_pairs_dev(zkmi_ctx* ctx, const void* d_in, uint64_t n_hashes, void* d_out);
+/* MerkleTree<DEPTH> after its first n_filled add_leaf calls (merkle.rs:48-81): d_nodes holds
+ * 2^(log_leaves+1) - 1 elements of 32 B, leaves first, then each level, root last; the caller
+ * writes the first n_filled leaves.  A node no inserted leaf has touched does not exist in the
+ * contract's mapping and reads as Scalar 0 (not as a hash of zeros) - reproduced here. */
+int32_t zkmi_sha256_merkle_tree_dev(zkmi_ctx* ctx, void* d_nodes, uint32_t log_leaves, uint64_t n_filled);
+
 /* ---- Poseidon-5 ------------------------------------------ *
  * T_WIDTH = 5, RATE = 4, R_F = 8, R_P = 56, S-box x^5
  * (shielder/relations/src/lib.rs:17-26); hashing = PoseidonHasher::hash_fix_len_array

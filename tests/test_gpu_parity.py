@@ -551,3 +551,63 @@ def test_update_note_witness_batch_on_device(ctx, zk):
         assert zk.groth16_verify(vk, frs(publics), pf) is True
     pk.free()
     r1.free()
+
+
+# ---- the contract's SHA-256 Merkle tree (pinned by the reference's own test) ----
+
+
+def _contract_tree(depth, leaves):
+    """MerkleTree::add_leaf replayed with hashlib (contract/merkle.rs:48-81): nodes[] keyed like the
+    contract (root = 1, leaf i = 2^depth + i), missing nodes read as zero; returns the node map."""
+    import hashlib
+
+    size = 1 << depth
+    nodes = {}
+    for i, leaf in enumerate(leaves):
+        idx = size + i
+        nodes[idx] = leaf
+        idx //= 2
+        while idx > 0:
+            left, right = nodes.get(2 * idx, bytes(32)), nodes.get(2 * idx + 1, bytes(32))
+            nodes[idx] = hashlib.sha256(left + right).digest()
+            idx //= 2
+    return nodes
+
+
+def test_sha256_pairs_match_hashlib(ctx):
+    import hashlib
+    import random
+
+    rnd = random.Random(9)
+    n = 1000
+    raw = rnd.randbytes(64 * n)
+    want = b"".join(hashlib.sha256(raw[64 * i : 64 * i + 64]).digest() for i in range(n))
+    assert ctx.sha256_pairs(raw, n) == want
+    assert ctx.sha256_pairs(b"", 0) == b""
+
+
+def test_sha256_merkle_tree_matches_contract_semantics(ctx):
+    """Device tree == the reference's own pinned value (merkle.rs:115-132, two leaves, depth 10) and ==
+    add_leaf replayed leaf by leaf for partially filled trees (untouched nodes read as zero)."""
+    import torch
+
+    depth = 10
+    size = 1 << depth
+    two = [(1).to_bytes(32, "little"), (2).to_bytes(32, "little")]
+    for leaves in (two, [i.to_bytes(32, "little") for i in range(10)], [bytes([i % 251] * 32) for i in range(size)], []):
+        buf = torch.full((2 * size - 1, 32), 0xEE, dtype=torch.uint8, device="cuda")  # stale contents must not leak
+        if leaves:
+            buf[: len(leaves)] = torch.frombuffer(bytearray(b"".join(leaves)), dtype=torch.uint8).view(-1, 32).cuda()
+        torch.cuda.synchronize()
+        ctx.sha256_merkle_tree_dev(buf.data_ptr(), depth, len(leaves))
+        got = bytes(buf.cpu().numpy().tobytes())
+        nodes = _contract_tree(depth, leaves)
+        off, width, level = 0, size, depth
+        while width >= 1:
+            for j in range(width):
+                assert got[32 * (off + j) : 32 * (off + j + 1)] == nodes.get((1 << level) + j, bytes(32)), (level, j)
+            off += width
+            width //= 2
+            level -= 1
+        if leaves is two:
+            assert got[-32:].hex() == golden("mock_boundary.json")["merkle_root_two_leaves"]

@@ -526,6 +526,18 @@ class Context:
         self._chk(self.lib.zkmi_update_note_witness_batch_dev(self.h, C.c_uint32(log_n), C.c_int32(op_kind), arr, C.c_uint32(n), ptrs, st))
         return list(st)[:n]
 
+    def sha256_pairs(self, inputs, n_hashes):
+        assert len(inputs) == 64 * n_hashes
+        out = (C.c_uint8 * (32 * max(1, n_hashes)))()
+        self._chk(self.lib.zkmi_sha256_pairs(self.h, _buf(inputs), C.c_uint64(n_hashes), out))
+        return bytes(out)[: 32 * n_hashes]
+
+    def sha256_pairs_dev(self, d_in, n_hashes, d_out):
+        self._chk(self.lib.zkmi_sha256_pairs_dev(self.h, C.c_void_p(d_in), C.c_uint64(n_hashes), C.c_void_p(d_out)))
+
+    def sha256_merkle_tree_dev(self, d_nodes, log_leaves, n_filled):
+        self._chk(self.lib.zkmi_sha256_merkle_tree_dev(self.h, C.c_void_p(d_nodes), C.c_uint32(log_leaves), C.c_uint64(n_filled)))
+
     def poseidon_hash_batch(self, inputs, n_hashes, arity, field=0):
         """n_hashes x arity canonical 32-byte inputs (bytes) -> n_hashes x 32 bytes, hashed on the GPU."""
         assert len(inputs) == 32 * n_hashes * arity
