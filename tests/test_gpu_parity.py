@@ -611,3 +611,36 @@ def test_sha256_merkle_tree_matches_contract_semantics(ctx):
             level -= 1
         if leaves is two:
             assert got[-32:].hex() == golden("mock_boundary.json")["merkle_root_two_leaves"]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_degenerate_bases_and_scalars(ctx, group):
+    """Exceptional cases of the bucket additions, forced into the same buckets by equal scalars:
+    P + P (doubling path), P + (-P) (cancellation to infinity, then restart), points at infinity
+    among the bases, scalars 0, 1, r - 1; in the light-bucket kernel (n = 9), across the heavy-bucket
+    kernels (the pattern repeated 400 times) and through the signed-digit borrow (r - 1)."""
+    F, G = (ec.Fq, ec.G1) if group == 1 else (ec.Fq2, ec.G2)
+    mul = ec.g1_mul if group == 1 else ec.g2_mul
+    to_b = ec.g1_to_bytes if group == 1 else ec.g2_to_bytes
+    width = 96 if group == 1 else 192
+    neg = lambda p: ec.pt_neg(F, p)
+    P2, P3 = mul(2), mul(3)
+    pts = [G, G, neg(G), G, None, P2, neg(P2), P3, P3]
+    k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890AB % R
+    for reps, scalars in (
+        (1, [k] * 9),
+        (1, [k, k, k, R - 1, 5, 0, 1, R - 1, R - 1]),
+        (400, [k] * 9),
+    ):
+        bases = pts * reps
+        sc = scalars * reps
+        want = None
+        for s, p in zip(scalars, pts):
+            if p is not None and s:
+                want = ec.pt_add(F, want, ec.pt_mul(F, p, s))
+        want = ec.pt_mul(F, want, reps) if want is not None else None
+        raw_b = b"".join(to_b(p) if p is not None else bytes(width) for p in bases)
+        b = ctx.bases_g1(raw_b) if group == 1 else ctx.bases_g2(raw_b)
+        got = (ctx.msm_g1 if group == 1 else ctx.msm_g2)(frs(sc), b)
+        assert got == (to_b(want) if want is not None else bytes(width)), (reps, scalars[:3])
+        b.free()
