@@ -1,0 +1,48 @@
+"""Summarise rocprofv3 --pmc passes (counter_collection.csv files) into one JSON: per kernel, the
+average counter value per dispatch.  Usage: python scripts/pmc_summary.py OUT.json DIR [DIR ...]
+(each DIR is the -d directory of one rocprofv3 --pmc pass)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    name = name.replace("zkmi::", "").replace("(anonymous namespace)::", "")
+    name = re.sub(r"Fp28<(\w+)28Params\s*>", r"\g<1>28", name)
+    name = re.sub(r"Fq2T<Fq28\s*>", "Fq2_28", name)
+    return name.strip()
+
+
+def main():
+    out_path, dirs = sys.argv[1], sys.argv[2:]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for path in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+            # one row per (dispatch, counter); a counter may appear once per dimension instance: sum those
+            per_dispatch = collections.defaultdict(float)
+            names = {}
+            for r in csv.DictReader(open(path)):
+                key = (r["Dispatch_Id"], r["Counter_Name"])
+                per_dispatch[key] += float(r["Counter_Value"])
+                names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+            for (disp, counter), v in per_dispatch.items():
+                agg[names[disp]][counter].append(v)
+    rows = []
+    for kernel, counters in agg.items():
+        row = {"kernel": kernel}
+        for c, vals in sorted(counters.items()):
+            row[c + "_avg_per_dispatch"] = sum(vals) / len(vals)
+            row[c + "_dispatches"] = len(vals)
+        rows.append(row)
+    rows.sort(key=lambda r: -r.get("SQ_INSTS_VALU_avg_per_dispatch", 0) * r.get("SQ_INSTS_VALU_dispatches", 0))
+    json.dump(rows, open(out_path, "w"), indent=1)
+    print("wrote", out_path, len(rows), "kernels")
+
+
+if __name__ == "__main__":
+    main()
