@@ -27,6 +27,7 @@
 //                 segsum over {t : bit j of t set}
 //   host: window_w = P[w][0] + SEG * sum_j 2^j P[w][1+j];  result = sum_w 2^(c w) window_w
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include <vector>
 #include "curve.hpp"
@@ -58,9 +59,6 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
-#ifndef ZK_ACCUM_PREFETCH
-#define ZK_ACCUM_PREFETCH false  // measured: prefetching the next point costs 28 VGPRs and gains nothing
-#endif
 // G1 (14-limb coordinates): 248 VGPRs -> 2 waves per SIMD.  G2 needs ~330 registers
 // (accumulator 112 + point 56 + columns 56 + temporaries) and runs at 1 wave per SIMD with
 // cheap AGPR spills; forcing 2 waves sends 350+ values to scratch and is 2x slower.
@@ -68,7 +66,7 @@ template <class F>
 struct AccumWaves {
   static constexpr int value = (sizeof(F) <= 64) ? 2 : 1;  // measured: forcing 3 for G1 spills around the rare-path calls and is 25 % slower
 };
-template <class F, bool PREFETCH>
+template <class F>
 __global__ void __launch_bounds__(256, AccumWaves<F>::value)
 k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
         const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
@@ -81,27 +79,69 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
   if (cnt > heavy_thr) return;  // k_accum_heavy owns it
   const uint32_t beg = begin[b], end = beg + cnt;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  if (PREFETCH) {
-    // software pipeline: the next point's gather is in flight during this mixed addition
-    uint32_t vn = cnt ? sorted[beg] : 0u;
-    Affine<F> pn = load_vec(bases + (vn & 0x7fffffffu));
-    for (uint32_t j = beg; j < end; j++) {
-      const uint32_t v = vn;
-      Affine<F> p = pn;
-      if (j + 1 < end) {
-        vn = sorted[j + 1];
-        pn = load_vec(bases + (vn & 0x7fffffffu));
-      }
-      if (v >> 31) p.y = p.y.neg();
-      acc.madd(p);
+  // (prefetching the next point into registers costs 28 VGPRs and gains nothing; the G1 path of
+  // the prover prefetches through LDS instead: k_accum_g1_glds below)
+  for (uint32_t j = beg; j < end; j++) {
+    const uint32_t v = sorted[j];
+    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+    if (v >> 31) p.y = p.y.neg();
+    acc.madd(p);
+  }
+  store_vec(buckets + b, acc);
+}
+
+// G1 accumulation with the gather of the NEXT point in flight during the current mixed addition,
+// at no register cost: the 112-byte table entry is fetched by seven direct-to-LDS loads
+// (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform LDS base + 16 B x lane),
+// into one of two LDS buffers.  Order inside an iteration: wait -> read point j from LDS -> issue the
+// loads of point j+1 and of index j+2 -> mixed addition (no memory operation inside it).
+// LDS: 2 buffers x 256 threads x 112 B = 56 KB per block, two blocks per CU (VGPR-limited anyway).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256, 2)
+k_accum_g1_glds(const Affine<Fq28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+                const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
+                const uint32_t* __restrict__ sorted, XYZZ<Fq28>* __restrict__ buckets, uint32_t total_buckets,
+                uint32_t heavy_thr) {
+  constexpr int CHUNKS = sizeof(Affine<Fq28>) / 16;  // 7
+  __shared__ uint4 tile[2][4][CHUNKS][64];            // [buffer][wave][chunk][lane]
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (t >= total_buckets) return;
+  const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
+  const uint32_t beg = begin[b], end = beg + cnt;
+  XYZZ<Fq28> acc = XYZZ<Fq28>::infinity();
+  auto fetch = [&](uint32_t v, int buf) {
+    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[buf][wave][q][0], 16, 0, 0);
+  };
+  uint32_t v_cur = 0, v_next = 0;
+  if (cnt) {
+    v_cur = sorted[beg];
+    fetch(v_cur, 0);
+    if (cnt > 1) v_next = sorted[beg + 1];
+  }
+  int buf = 0;
+  for (uint32_t j = beg; j < end; j++) {
+    // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
+    Affine<Fq28> p;
+    uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) d[q] = tile[buf][wave][q][lane];
+    const uint32_t v = v_cur;
+    if (j + 1 < end) {
+      fetch(v_next, buf ^ 1);
+      v_cur = v_next;
+      if (j + 2 < end) v_next = sorted[j + 2];
     }
-  } else {
-    for (uint32_t j = beg; j < end; j++) {
-      const uint32_t v = sorted[j];
-      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
-      if (v >> 31) p.y = p.y.neg();
-      acc.madd(p);
-    }
+    buf ^= 1;
+    if (v >> 31) p.y = p.y.neg();
+    acc.madd(p);
   }
   store_vec(buckets + b, acc);
 }
@@ -404,8 +444,15 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     hipLaunchKernelGGL(k_accum_g2_split<0>, dim3((2 * tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
                        sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   } else {
-    hipLaunchKernelGGL((k_accum<F, ZK_ACCUM_PREFETCH>), dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,
-                       sort.count, sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+    // default: LDS-prefetching kernel (3.62 -> 3.43 ms on the 2^20 windowed MSM); ZKMI_ACCUM_GLDS=0 selects
+    // the plain gather kernel for A/B runs
+    static const bool glds = !(getenv("ZKMI_ACCUM_GLDS") && getenv("ZKMI_ACCUM_GLDS")[0] == '0');
+    if (glds)
+      hipLaunchKernelGGL(k_accum_g1_glds<0>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+    else
+      hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,
+                         sort.count, sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
