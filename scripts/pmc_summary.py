@@ -11,8 +11,8 @@ import sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "").replace("zkmi::", "")
     name = name.split("(")[0]
-    name = name.replace("zkmi::", "").replace("(anonymous namespace)::", "")
     name = re.sub(r"Fp28<(\w+)28Params\s*>", r"\g<1>28", name)
     name = re.sub(r"Fq2T<Fq28\s*>", "Fq2_28", name)
     return name.strip()
