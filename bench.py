@@ -230,7 +230,7 @@ def main():
     ms_tot, launches = phases[dom]
     avg_ms = ms_tot / max(1, launches)
     achieved = kernels[dom]["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    kname = "k_accum_g1_glds<0>" if dom == "msm_accum_g1" else "k_accum_g2_split<0>"
+    kname = "k_accum_g1_glds<Fq28 >" if dom == "msm_accum_g1" else "k_accum_g2_split<0>"
     traffic, traffic_note = pmc_traffic(args.pmc_summary, kname)
     roofline = {
         "kernel": kname,

@@ -181,6 +181,28 @@ int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, u
 int32_t zkmi_r1cs_export(const zkmi_r1cs* r, int32_t m, uint32_t* rowptr, uint32_t* col, uint8_t* val, uint64_t* nnz);
 int32_t zkmi_r1cs_is_satisfied(const zkmi_r1cs* r, const uint8_t* z);
 
+/* ---- BN254 (halo2curves::bn256) MSM / NTT, KZG-commit-shaped driver ------ *
+ * The reference's relations are halo2 circuits over bn256 (shielder/Cargo.toml:26,
+ * shielder/Cargo.lock:436-492); a halo2/KZG prover's hot loops are best_fft and best_multiexp
+ * (crates not in tree).  Same kernels as above over the 254-bit fields.
+ * Fr / Fq: 32-byte LE canonical; G1 affine: x || y (64 B), all-zero = infinity;
+ * curve y^2 = x^3 + 3, generator (1, 2); NTT root = 7^((r-1)/2^28) (bn256::Fr::ROOT_OF_UNITY),
+ * coset shift 7 (bn256::Fr::MULTIPLICATIVE_GENERATOR). */
+typedef struct zkmi_bn_bases zkmi_bn_bases;
+int32_t zkmi_bn254_bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bn_bases** out);
+/* P_i = [1 + i * 0xC0FFEE] G, generated in HBM (tests / timing) */
+int32_t zkmi_bn254_bases_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bn_bases** out);
+int32_t zkmi_bn254_bases_read(zkmi_ctx* ctx, const zkmi_bn_bases* b, uint64_t first, uint64_t count, uint8_t* out);
+int32_t zkmi_bn254_bases_free(zkmi_bn_bases* b);
+int32_t zkmi_bn254_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bn_bases* bases, uint8_t out_affine[64]);
+int32_t zkmi_bn254_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_bases* bases, uint8_t out_affine[64]);
+int32_t zkmi_bn254_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset);
+int32_t zkmi_bn254_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inverse, int32_t coset);
+/* KZG commitment from evaluations: coefficients = iNTT(evaluations) (written back to d_evals),
+ * commitment = MSM(srs, coefficients); srs holds at least 2^log_n points [tau^i] G. */
+int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, const zkmi_bn_bases* srs,
+                                  uint8_t out_commitment[64]);
+
 /* ---- the contract's SHA-256 Merkle tree, batched ------------ *
  * compute_hash / combine_merkle_hash = SHA-256(first.bytes || second.bytes)
  * (shielder/contract/merkle.rs:24-28, shielder/mocked_zk/src/lib.rs:24-28).

@@ -175,3 +175,23 @@ def test_poseidon_sponge_framing_and_merkle_path():
     shape = [1 - ((idx >> lv) & 1) for lv in range(4)]
     path = [levels[lv][(idx >> lv) ^ 1] for lv in range(4)]
     assert ps.merkle_root(leaves[idx], shape, path) == levels[-1][0]
+
+
+# ---- BN254 ------------------------------------------------------------------
+
+
+def test_bn254_constants_and_definitions():
+    from oracle import bn254 as bn
+
+    assert bn.on_curve(bn.G1) and bn.pt_mul(bn.G1, bn.R) is None
+    assert pow(2, bn.P - 1, bn.P) == 1 and pow(2, bn.R - 1, bn.R) == 1
+    # halo2curves bn256::Fr::ROOT_OF_UNITY = 7^((r-1)/2^28), primitive of order 2^28
+    assert pow(bn.FR_GENERATOR, (bn.R - 1) >> 28, bn.R) == bn.FR_ROOT_2_28
+    assert pow(bn.FR_ROOT_2_28, 1 << 27, bn.R) == bn.R - 1
+    rng = ec.SplitMix64(3)
+    a = [rng.next() * rng.next() % bn.R for _ in range(32)]
+    assert bn.ntt(a) == bn.dft_naive(a)
+    assert bn.ntt(a, inverse=True) == bn.dft_naive(a, inverse=True)
+    assert bn.ntt(bn.ntt(a, coset=True), inverse=True, coset=True) == a
+    pts = bn.synthetic_bases(5)
+    assert pts[3] == bn.pt_mul(bn.G1, 1 + 3 * 0xC0FFEE) and all(bn.on_curve(p) for p in pts)

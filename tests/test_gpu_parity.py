@@ -644,3 +644,114 @@ def test_msm_degenerate_bases_and_scalars(ctx, group):
         got = (ctx.msm_g1 if group == 1 else ctx.msm_g2)(frs(sc), b)
         assert got == (to_b(want) if want is not None else bytes(width)), (reps, scalars[:3])
         b.free()
+
+
+# ---- BN254 MSM / NTT / KZG commit ---------------------------------------------
+
+
+def _bn_frs(vals):
+    return b"".join(int(v).to_bytes(32, "little") for v in vals)
+
+
+def test_bn254_ntt_matches_oracle(ctx):
+    from oracle import bn254 as bn
+
+    for lg in (0, 1, 4, 9, 11, 13):
+        rng = ec.SplitMix64(50 + lg)
+        a = [rng.next() * rng.next() * rng.next() * rng.next() % bn.R for _ in range(1 << lg)]
+        a[0] = bn.R - 1
+        raw = _bn_frs(a)
+        assert ctx.bn254_ntt(raw, lg) == _bn_frs(bn.ntt(a))
+        assert ctx.bn254_ntt(raw, lg, inverse=True) == _bn_frs(bn.ntt(a, inverse=True))
+        assert ctx.bn254_ntt(raw, lg, coset=True) == _bn_frs(bn.ntt(a, coset=True))
+        assert ctx.bn254_ntt(raw, lg, inverse=True, coset=True) == _bn_frs(bn.ntt(a, inverse=True, coset=True))
+    with pytest.raises(Exception):
+        ctx.bn254_ntt(bn.R.to_bytes(32, "little") * 2, 1)
+
+
+def test_bn254_ntt_large_round_trip(ctx):
+    import torch
+
+    lg = 20
+    n = 1 << lg
+    g = torch.Generator(device="cuda").manual_seed(20)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x1F
+    x = raw.clone()
+    torch.cuda.synchronize()
+    ctx.bn254_ntt_dev(x.data_ptr(), lg)
+    assert not torch.equal(x, raw)
+    ctx.bn254_ntt_dev(x.data_ptr(), lg, inverse=True)
+    assert torch.equal(x, raw)
+    ctx.bn254_ntt_dev(x.data_ptr(), lg, coset=True)
+    ctx.bn254_ntt_dev(x.data_ptr(), lg, inverse=True, coset=True)
+    assert torch.equal(x, raw)
+
+
+def test_bn254_msm_matches_oracle(ctx):
+    """Seeded MSM vs double-and-add; edge scalars; infinity / repeated / opposite bases; on-curve check."""
+    from oracle import bn254 as bn
+
+    rng = ec.SplitMix64(254)
+    n = 300
+    pts = bn.synthetic_bases(n)
+    b = ctx.bn254_bases_synthetic(n)
+    assert b.read(0, 4) == b"".join(bn.g1_to_bytes(p) for p in pts[:4])
+    assert b.read(n - 1, 1) == bn.g1_to_bytes(pts[-1])
+    sc = [rng.next() * rng.next() * rng.next() * rng.next() % bn.R for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, bn.R - 1
+    assert ctx.bn254_msm_g1(_bn_frs(sc), b) == bn.g1_to_bytes(bn.msm_naive(sc, pts))
+    assert ctx.bn254_msm_g1(b"", b) == bytes(64)
+    b.free()
+    g, g2 = bn.G1, bn.pt_mul(bn.G1, 2)
+    odd = [g, g, bn.pt_neg(g), None, g2, bn.pt_neg(g2), g2, g]
+    k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890AB % bn.R
+    for reps, scalars in ((1, [k] * 8), (300, [k] * 8), (1, [k, bn.R - 1, 5, 7, 0, 1, bn.R - 1, k])):
+        bb = ctx.bn254_bases(b"".join(bn.g1_to_bytes(p) for p in odd * reps))
+        want = bn.pt_mul(bn.msm_naive(scalars, odd), reps)
+        assert ctx.bn254_msm_g1(_bn_frs(scalars * reps), bb) == bn.g1_to_bytes(want)
+        bb.free()
+    with pytest.raises(Exception):
+        ctx.bn254_bases((1).to_bytes(32, "little") + (3).to_bytes(32, "little"))  # (1, 3) is not on the curve
+
+
+def test_bn254_msm_full_size_closed_form(ctx):
+    """n = 2^20 on the synthetic bases: sum s_i [1 + i c] G = [sum s_i + c sum i s_i] G."""
+    import torch
+    from oracle import bn254 as bn
+
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(99)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x1F
+    idx = torch.arange(n, dtype=torch.int64, device="cuda")
+    s0 = raw.to(torch.int64).sum(dim=0).cpu().tolist()
+    s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0).cpu().tolist()
+    tot = sum(v << (8 * k) for k, v in enumerate(s0))
+    wtot = sum(v << (8 * k) for k, v in enumerate(s1))
+    b = ctx.bn254_bases_synthetic(n)
+    got = ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b)
+    assert got == bn.g1_to_bytes(bn.pt_mul(bn.G1, (tot + 0xC0FFEE * wtot) % bn.R))
+    b.free()
+
+
+def test_bn254_kzg_commit(ctx):
+    """commit(evaluations) = MSM(SRS, iNTT(evaluations)) = [p(tau)] G for an SRS [tau^i] G."""
+    import torch
+    from oracle import bn254 as bn
+
+    lg = 8
+    n = 1 << lg
+    tau = 0xDEADBEEFCAFEF00D1234567 % bn.R
+    srs = [bn.pt_mul(bn.G1, pow(tau, i, bn.R)) for i in range(n)]
+    rng = ec.SplitMix64(88)
+    coeffs = [rng.next() * rng.next() * rng.next() * rng.next() % bn.R for _ in range(n)]
+    evals = bn.ntt(coeffs)
+    b = ctx.bn254_bases(b"".join(bn.g1_to_bytes(p) for p in srs))
+    d = torch.frombuffer(bytearray(_bn_frs(evals)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    got = ctx.bn254_kzg_commit_dev(d.data_ptr(), lg, b)
+    p_tau = sum(c * pow(tau, i, bn.R) for i, c in enumerate(coeffs)) % bn.R
+    assert got == bn.g1_to_bytes(bn.pt_mul(bn.G1, p_tau))
+    assert bytes(d.cpu().numpy().tobytes()) == _bn_frs(coeffs)  # the coefficients are left in place
+    b.free()

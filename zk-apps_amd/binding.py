@@ -526,6 +526,40 @@ class Context:
         self._chk(self.lib.zkmi_update_note_witness_batch_dev(self.h, C.c_uint32(log_n), C.c_int32(op_kind), arr, C.c_uint32(n), ptrs, st))
         return list(st)[:n]
 
+    # ---- BN254 MSM / NTT / KZG commit -----------------------
+    def bn254_bases(self, affine, check=True):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bn254_bases_load(self.h, _buf(affine), C.c_uint64(len(affine) // 64), C.c_int32(check), C.byref(h)))
+        return BnBases(self, h, len(affine) // 64)
+
+    def bn254_bases_synthetic(self, n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bn254_bases_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        return BnBases(self, h, n)
+
+    def bn254_msm_g1(self, scalars, bases):
+        out = (C.c_uint8 * 64)()
+        self._chk(self.lib.zkmi_bn254_msm_g1(self.h, _buf(scalars), C.c_uint64(len(scalars) // 32), bases.h, out))
+        return bytes(out)
+
+    def bn254_msm_g1_dev(self, dptr, n, bases):
+        out = (C.c_uint8 * 64)()
+        self._chk(self.lib.zkmi_bn254_msm_g1_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
+    def bn254_ntt(self, data, log_n, inverse=False, coset=False):
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        self._chk(self.lib.zkmi_bn254_ntt_fr(self.h, buf, C.c_uint32(log_n), C.c_int32(inverse), C.c_int32(coset)))
+        return bytes(buf)
+
+    def bn254_ntt_dev(self, dptr, log_n, inverse=False, coset=False):
+        self._chk(self.lib.zkmi_bn254_ntt_fr_dev(self.h, C.c_void_p(dptr), C.c_uint32(log_n), C.c_int32(inverse), C.c_int32(coset)))
+
+    def bn254_kzg_commit_dev(self, d_evals, log_n, srs):
+        out = (C.c_uint8 * 64)()
+        self._chk(self.lib.zkmi_bn254_kzg_commit_dev(self.h, C.c_void_p(d_evals), C.c_uint32(log_n), srs.h, out))
+        return bytes(out)
+
     def sha256_pairs(self, inputs, n_hashes):
         assert len(inputs) == 64 * n_hashes
         out = (C.c_uint8 * (32 * max(1, n_hashes)))()
@@ -600,6 +634,21 @@ class Context:
         out = (C.c_uint8 * (32 << pk.r1cs.log_n))()
         self._chk(self.lib.zkmi_groth16_witness_map(self.h, pk.h, _buf(z), out))
         return bytes(out)
+
+
+class BnBases:
+    def __init__(self, ctx, h, n):
+        self.ctx, self.h, self.n = ctx, h, n
+
+    def read(self, first, count):
+        out = (C.c_uint8 * (64 * max(1, count)))()
+        self.ctx._chk(self.ctx.lib.zkmi_bn254_bases_read(self.ctx.h, self.h, C.c_uint64(first), C.c_uint64(count), out))
+        return bytes(out)[: 64 * count]
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zkmi_bn254_bases_free(self.h)
+            self.h = None
 
 
 class Bases:

@@ -1,0 +1,247 @@
+// zkmi — BN254 (alt_bn128) instantiation of the MSM and NTT kernels and a KZG-commit-shaped
+// driver.
+//
+// BN254 is the curve of the reference's actual proving stack: its relations are halo2 circuits over
+// halo2curves::bn256 (shielder/Cargo.toml:26, shielder/Cargo.lock:436-492); a halo2/KZG prover
+// spends its time in exactly two primitives, which the reference reaches only through crates that
+// are not in the tree:
+//   halo2_proofs::arithmetic::best_fft        -> radix-2 NTT over bn256::Fr (two-adicity 28,
+//                                                ROOT_OF_UNITY = 7^((r-1)/2^28))
+//   halo2_proofs::arithmetic::best_multiexp   -> G1 MSM (y^2 = x^3 + 3, generator (1, 2))
+//   ParamsKZG::commit_lagrange                -> commitment = MSM(SRS in Lagrange basis, evaluations);
+//                                                commit(coefficients) = MSM(SRS, iNTT(evaluations))
+// The kernels are the same templates as the BLS12-381 ones (msm_impl.hpp over Fp28<BnFq28Params>,
+// ntt.hip over Fp28<BnFr28Params>): 10 limbs instead of 14, and the bucket accumulation fits
+// 166 VGPRs = 3 waves per SIMD instead of 2.
+// Wire formats: Fr / Fq = 32-byte little-endian canonical integers; G1 affine = x || y (64 B),
+// all-zero = the point at infinity.
+#include <string.h>
+#include <new>
+#include <vector>
+#include "ctx.hpp"
+
+using namespace zkmi;
+
+struct zkmi_bn_bases {
+  zkmi_ctx* ctx;
+  Affine<BnFq28>* d28 = nullptr;  // device MSM representation (10 limbs, R = 2^280)
+  uint64_t n = 0;
+};
+
+namespace {
+
+bool words_lt(const uint32_t w[8], const uint32_t mod[8]) {
+  for (int i = 7; i >= 0; i--)
+    if (w[i] != mod[i]) return w[i] < mod[i];
+  return false;
+}
+bool all_zero(const uint8_t* b, size_t n) {
+  uint8_t acc = 0;
+  for (size_t i = 0; i < n; i++) acc |= b[i];
+  return acc == 0;
+}
+BnFq28 small(uint32_t v) {
+  uint32_t w[8] = {v, 0, 0, 0, 0, 0, 0, 0};
+  return BnFq28::from_canonical(w);
+}
+bool bn_from_wire(const uint8_t* b, Affine<BnFq28>* out, bool check) {
+  if (all_zero(b, 64)) {
+    *out = Affine<BnFq28>::infinity();
+    return true;
+  }
+  uint32_t x[8], y[8];
+  memcpy(x, b, 32);
+  memcpy(y, b + 32, 32);
+  if (!words_lt(x, BnFq28Params::MOD32) || !words_lt(y, BnFq28Params::MOD32)) return false;
+  out->x = BnFq28::from_canonical(x);
+  out->y = BnFq28::from_canonical(y);
+  if (!check) return true;
+  const BnFq28 lhs = out->y.sqr(), rhs = out->x.sqr() * out->x + small(3);
+  return (lhs - rhs).is_zero();  // difference of two products: within is_zero's exact range
+}
+void bn_to_wire(const Affine<BnFq28>& p, uint8_t* b) {
+  uint32_t x[8], y[8];
+  p.x.to_canonical(x);
+  p.y.to_canonical(y);
+  memcpy(b, x, 32);
+  memcpy(b + 32, y, 32);  // infinity = (0, 0) -> all zero
+}
+
+// P_i = [1 + i * 0xC0FFEE] G, G = (1, 2): distinct points manufactured in HBM for tests / timing
+__global__ void __launch_bounds__(64) k_bn_synth(Affine<BnFq28>* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0}, two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+  const Affine<BnFq28> g = {BnFq28::from_canonical(one), BnFq28::from_canonical(two)};
+  const uint64_t s = 1ull + i * 0xC0FFEEull;
+  const uint32_t k[2] = {(uint32_t)s, (uint32_t)(s >> 32)};
+  const XYZZ<BnFq28> r = scalar_mul(XYZZ<BnFq28>::from_affine(g), k, 2);
+  const Affine<BnFq28> a = r.to_affine();
+  uint4* d = reinterpret_cast<uint4*>(out + i);
+  const uint4* sgm = reinterpret_cast<const uint4*>(&a);
+#pragma unroll
+  for (unsigned q = 0; q < sizeof(a) / 16; q++) d[q] = sgm[q];
+}
+
+bool scalars_canonical(const uint8_t* s, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t w[8];
+    memcpy(w, s + 32 * i, 32);
+    if (!words_lt(w, BnFr28Params::MOD32)) return false;
+  }
+  return true;
+}
+
+hipError_t work_buffer(zkmi_ctx* ctx, uint64_t bytes) {
+  if (ctx->d_work_cap >= bytes) return hipSuccess;
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
+  ctx->d_work = nullptr;
+  ctx->d_work_cap = 0;
+  hipError_t e = hipMalloc(&ctx->d_work, bytes);
+  if (e == hipSuccess) ctx->d_work_cap = bytes;
+  return e;
+}
+
+int32_t msm_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_bases* bases, uint8_t out[64]) {
+  ZK_HIP(ctx, ctx->sort.reserve(n));
+  ZK_HIP(ctx, ctx->g1_bn.reserve(n));
+  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g1_bn.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1,
+                                    PH_MSM_REDUCE_G1));
+  XYZZ<BnFq> res;
+  ZK_HIP(ctx, ctx->g1_bn.finish_host(&res));
+  const Affine<BnFq> a = res.to_affine();
+  const Affine<BnFq28> a28 = {fq28_from_fq(a.x), fq28_from_fq(a.y)};
+  bn_to_wire(a28, out);
+  return ZKMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t zkmi_bn254_bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bn_bases** out) {
+  ZK_ENTER(ctx);
+  if (!out || (n && !affine) || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  *out = nullptr;
+  std::vector<Affine<BnFq28>> h(n);
+  for (uint64_t i = 0; i < n; i++)
+    if (!bn_from_wire(affine + 64 * i, &h[i], check != 0))
+      return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 base point not canonical / not on curve");
+  zkmi_bn_bases* b = new (std::nothrow) zkmi_bn_bases();
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  b->ctx = ctx;
+  b->n = n;
+  hipError_t e = hipMalloc(&b->d28, sizeof(Affine<BnFq28>) * (n ? n : 1));
+  if (e == hipSuccess && n) e = hipMemcpy(b->d28, h.data(), sizeof(Affine<BnFq28>) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (b->d28) (void)hipFree(b->d28);
+    delete b;
+    return ctx->hip_fail(e, "bn254 bases upload");
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bn254_bases_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bn_bases** out) {
+  ZK_ENTER(ctx);
+  if (!out || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  zkmi_bn_bases* b = new (std::nothrow) zkmi_bn_bases();
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  b->ctx = ctx;
+  b->n = n;
+  hipError_t e = hipMalloc(&b->d28, sizeof(Affine<BnFq28>) * (n ? n : 1));
+  if (e == hipSuccess && n) {
+    hipLaunchKernelGGL(k_bn_synth, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, b->d28, n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e != hipSuccess) {
+    if (b->d28) (void)hipFree(b->d28);
+    delete b;
+    return ctx->hip_fail(e, "bn254 synthetic bases");
+  }
+  *out = b;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bn254_bases_read(zkmi_ctx* ctx, const zkmi_bn_bases* b, uint64_t first, uint64_t count, uint8_t* out) {
+  ZK_ENTER(ctx);
+  if (!b || !out || first + count > b->n) return ZKMI_ERR_BAD_ARG;
+  std::vector<Affine<BnFq28>> h(count);
+  if (count) ZK_HIP(ctx, hipMemcpy(h.data(), b->d28 + first, sizeof(Affine<BnFq28>) * count, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++) bn_to_wire(h[i], out + 64 * i);
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bn254_bases_free(zkmi_bn_bases* b) {
+  if (!b) return ZKMI_ERR_BAD_ARG;
+  if (b->d28) (void)hipFree(b->d28);
+  delete b;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bn254_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_bases* bases,
+                              uint8_t out_affine[64]) {
+  ZK_ENTER(ctx);
+  if (!bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  return msm_dev(ctx, d_scalars, n, bases, out_affine);
+}
+
+int32_t zkmi_bn254_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bn_bases* bases,
+                          uint8_t out_affine[64]) {
+  ZK_ENTER(ctx);
+  if (!bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!scalars_canonical(scalars, n)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 scalar >= r");
+  ZK_HIP(ctx, ctx->staging(n * 32 + 32));
+  if (n) ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return msm_dev(ctx, ctx->d_tmp, n, bases, out_affine);
+}
+
+int32_t zkmi_bn254_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  ZK_ENTER(ctx);
+  if (!d_data || log_n > 26) return ZKMI_ERR_BAD_ARG;
+  hipError_t e;
+  NttDomainBn* dom = ctx->domain_bn((int)log_n, &e);
+  if (!dom) return ctx->hip_fail(e, "bn254 ntt domain init");
+  const uint32_t n = 1u << log_n;
+  ZK_HIP(ctx, work_buffer(ctx, (uint64_t)n * sizeof(BnFr28)));
+  BnFr28* work = static_cast<BnFr28*>(ctx->d_work);
+  ZK_HIP(ctx, ntt_from_canonical(static_cast<const uint32_t*>(d_data), work, n, ctx->stream));
+  PhaseTimer* t = ctx->timer();
+  if (t) t->begin(PH_NTT, ctx->stream);
+  e = dom->transform(work, inverse != 0, coset != 0, ctx->stream);
+  if (t) t->end(PH_NTT, ctx->stream);
+  if (e != hipSuccess) return ctx->hip_fail(e, "bn254 ntt transform");
+  ZK_HIP(ctx, ntt_to_canonical(work, static_cast<uint32_t*>(d_data), n, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+int32_t zkmi_bn254_ntt_fr(zkmi_ctx* ctx, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  ZK_ENTER(ctx);
+  if (!data || log_n > 26) return ZKMI_ERR_BAD_ARG;
+  const uint64_t n = 1ull << log_n;
+  if (!scalars_canonical(data, n)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 ntt input >= r");
+  ZK_HIP(ctx, ctx->staging(n * 32));
+  ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  const int32_t rc = zkmi_bn254_ntt_fr_dev(ctx, ctx->d_tmp, log_n, inverse, coset);
+  if (rc != ZKMI_OK) return rc;
+  ZK_HIP(ctx, hipMemcpyAsync(data, ctx->d_tmp, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+// Commitment to the polynomial given by its 2^log_n evaluations over the radix-2 domain, against an SRS
+// in the monomial basis: coefficients = iNTT(evaluations) (left in d_evals, canonical form), commitment =
+// MSM(srs, coefficients).  d_evals is overwritten with the coefficients.
+int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, const zkmi_bn_bases* srs,
+                                  uint8_t out_commitment[64]) {
+  ZK_ENTER(ctx);
+  if (!d_evals || !srs || !out_commitment || log_n > 26 || srs->n < (1ull << log_n)) return ZKMI_ERR_BAD_ARG;
+  const int32_t rc = zkmi_bn254_ntt_fr_dev(ctx, d_evals, log_n, 1, 0);
+  if (rc != ZKMI_OK) return rc;
+  return msm_dev(ctx, d_evals, 1ull << log_n, srs, out_commitment);
+}
+
+}  // extern "C"

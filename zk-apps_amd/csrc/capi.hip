@@ -104,9 +104,11 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamSynchronize(ctx->stream_aux);
   ctx->domains.clear();
+  ctx->domains_bn.clear();
   ctx->sort.release();
   ctx->g1.release();
   ctx->g2.release();
+  ctx->g1_bn.release();
   if (ctx->d_tmp) (void)hipFree(ctx->d_tmp);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   for (void* p : ctx->d_pos)

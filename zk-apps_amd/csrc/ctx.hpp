@@ -23,6 +23,8 @@ struct zkmi_ctx {
   zkmi::MsmSort sort;
   zkmi::MsmEngine<zkmi::Fq28> g1;
   zkmi::MsmEngine<zkmi::Fq2_28> g2;
+  zkmi::MsmEngine<zkmi::BnFq28> g1_bn;  // BN254 G1 (bn254.hip)
+  std::map<int, std::unique_ptr<zkmi::NttDomainBn>> domains_bn;
   void* d_tmp = nullptr;  // staging for host-buffer entry points
   uint64_t d_tmp_cap = 0;
   void* d_work = nullptr;  // limb-form work buffer of the NTT entry points
@@ -46,6 +48,19 @@ struct zkmi_ctx {
     hipError_t e = hipMalloc(&d_tmp, bytes);
     if (e == hipSuccess) d_tmp_cap = bytes;
     return e;
+  }
+  zkmi::NttDomainBn* domain_bn(int log_n, hipError_t* e) {
+    auto it = domains_bn.find(log_n);
+    if (it != domains_bn.end()) {
+      *e = hipSuccess;
+      return it->second.get();
+    }
+    auto d = std::make_unique<zkmi::NttDomainBn>();
+    *e = d->init(log_n, stream);
+    if (*e != hipSuccess) return nullptr;
+    auto* p = d.get();
+    domains_bn[log_n] = std::move(d);
+    return p;
   }
   zkmi::NttDomain* domain(int log_n, hipError_t* e) {
     auto it = domains.find(log_n);

@@ -45,6 +45,31 @@ struct FqParams {
                                       0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
 };
 
+// BN254 (alt_bn128): the curve of the reference's own proving stack (halo2curves::bn256,
+// shielder/Cargo.lock:454-478).  Used by the KZG-commit-shaped MSM / NTT driver.
+struct BnFqParams {
+  static constexpr int N = 8;
+  static constexpr uint32_t INV = 0xe4866389u;
+  static constexpr uint64_t INV64 = 0x87d20782e4866389ull;
+  static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                      0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+};
+struct BnFrParams {
+  static constexpr int N = 8;
+  static constexpr uint32_t INV = 0xefffffffu;
+  static constexpr uint64_t INV64 = 0xc2e1f593efffffffull;
+  static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                      0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+};
+
 template <class P>
 struct Fp {
   static constexpr int N = P::N;
@@ -287,6 +312,8 @@ struct Fp {
 
 using Fr = Fp<FrParams>;
 using Fq = Fp<FqParams>;
+using BnFq = Fp<BnFqParams>;
+using BnFr = Fp<BnFrParams>;
 
 // Fq2 product/square components; the device limb representation overloads these
 // (field28.hpp) to sum partial products in the column accumulators and pay one

@@ -297,6 +297,21 @@ struct Fp28 {
 };
 
 using Fq28 = Fp28<Fq28Params>;
+struct BnFq28Params {
+  static constexpr int NL = 10;
+  static constexpr int N32 = 8;
+  static constexpr uint32_t INV = 0x4866389u;
+  static constexpr int32_t MOD[10] = {0x87cfd47, 0x208c16d, 0x1ca8d3c, 0x6a91687, 0x85d9781,
+                                      0xb681815, 0x9b85045, 0xe131a02, 0x0644e72, 0x0000003};
+  static constexpr int32_t ONE[10] = {0xa0e0d96, 0x6a56a28, 0x56d8f97, 0x1e6c92b, 0xee608fc,
+                                      0x10581c8, 0x89f6e5c, 0x8c59c9e, 0x7359fa8, 0x0000000};
+  static constexpr int32_t R2[10] = {0x4693c46, 0xbb888f3, 0xe2ac0dd, 0x1c4bb9b, 0x3d9e1b9,
+                                     0xc1a7aec, 0x2c83580, 0x3cb4fa2, 0x95e2ea9, 0x0000000};
+  static constexpr uint32_t MOD32[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr int NUM_BITS = 254;
+};
+using BnFq28 = Fp28<BnFq28Params>;
 using BnFr28 = Fp28<BnFr28Params>;
 using Fr28 = Fp28<Fr28Params>;  // scalar field: NTT / witness map (values may grow to ~2^21 r between products)
 
@@ -344,17 +359,21 @@ using Fq2_28 = Fq2T<Fq28>;
 // ---- XYZZ building blocks (overloads of curve.hpp's generic forms) ------------
 // Fq28: differences that only feed products skip the carry sweep (limbs < 2^29,
 // 14 products of < 2^59 stay below 2^63 together with the reduction's share).
-ZK_HD Fq28 f_sub_lazy(const Fq28& a, const Fq28& b) { return a.sub_lazy(b); }
-ZK_HD Fq28 f_x3(const Fq28& rr, const Fq28& ppp, const Fq28& q) {
-  Fq28 r;
+// (templates on the parameter set: the BLS12-381 and the BN254 base fields share them)
+template <class P>
+ZK_HD Fp28<P> f_sub_lazy(const Fp28<P>& a, const Fp28<P>& b) { return a.sub_lazy(b); }
+template <class P>
+ZK_HD Fp28<P> f_x3(const Fp28<P>& rr, const Fp28<P>& ppp, const Fp28<P>& q) {
+  Fp28<P> r;
 #pragma unroll
-  for (int i = 0; i < Fq28::NL; i++) r.l[i] = rr.l[i] - ppp.l[i] - 2 * q.l[i];
+  for (int i = 0; i < P::NL; i++) r.l[i] = rr.l[i] - ppp.l[i] - 2 * q.l[i];
   r.carry();
   return r;
 }
 // a b - c d under one reduction (a, b may be lazy differences; c, d normalised)
-ZK_HD Fq28 f_mul_sub_mul(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
-  constexpr int NL = Fq28::NL;
+template <class P>
+ZK_HD Fp28<P> f_mul_sub_mul(const Fp28<P>& a, const Fp28<P>& b, const Fp28<P>& c, const Fp28<P>& d) {
+  constexpr int NL = P::NL;
   int64_t T[2 * NL];
 #pragma unroll
   for (int i = 0; i < 2 * NL; i++) T[i] = 0;
@@ -364,7 +383,7 @@ ZK_HD Fq28 f_mul_sub_mul(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28
 #pragma unroll
     for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.l[i] * b.l[j] + (int64_t)nc * d.l[j];
   }
-  return Fq28::reduce(T);
+  return Fp28<P>::reduce(T);
 }
 // Fq2 over the limbs: operands stay normalised (a component already sums two
 // products), but a b - c d needs only one reduction per component (4 x 14 products
@@ -511,6 +530,19 @@ ZK_HD Fq fq_from_fq28(const Fq28& a) {
   Fq c;
   a.to_canonical(c.l);
   return c.to_mont();
+}
+ZK_HD BnFq28 fq28_from_fq(const BnFq& a) {
+  BnFq c = a.from_mont();
+  return BnFq28::from_canonical(c.l);
+}
+ZK_HD BnFq fq_from_fq28(const BnFq28& a) {
+  BnFq c;
+  a.to_canonical(c.l);
+  return c.to_mont();
+}
+ZK_HD BnFr28 fr28_from_fr(const BnFr& a) {
+  BnFr c = a.from_mont();
+  return BnFr28::from_canonical(c.l);
 }
 ZK_HD Fq2_28 fq28_from_fq(const Fq2& a) { return {fq28_from_fq(a.c0), fq28_from_fq(a.c1)}; }
 ZK_HD Fq2 fq_from_fq28(const Fq2_28& a) { return {fq_from_fq28(a.c0), fq_from_fq28(a.c1)}; }

@@ -83,6 +83,7 @@ struct MsmSort {
 template <class F> struct HostFieldOf;
 template <> struct HostFieldOf<Fq28> { using type = Fq; };
 template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
+template <> struct HostFieldOf<BnFq28> { using type = BnFq; };
 
 template <class F>
 struct MsmEngine {
@@ -130,9 +131,11 @@ hipError_t msm_build_table(const Affine<F>* d_bases, uint64_t n, const MsmPlan& 
 
 extern template struct MsmEngine<Fq28>;
 extern template struct MsmEngine<Fq2_28>;
+extern template struct MsmEngine<BnFq28>;
 extern template hipError_t msm_build_table<Fq28>(const Affine<Fq28>*, uint64_t, const MsmPlan&, Affine<Fq28>**, hipStream_t);
 extern template hipError_t msm_build_table<Fq2_28>(const Affine<Fq2_28>*, uint64_t, const MsmPlan&, Affine<Fq2_28>**, hipStream_t);
 extern template hipError_t bases_convert<Fq28>(const Affine<Fq>*, Affine<Fq28>*, uint64_t, hipStream_t);
 extern template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
+extern template hipError_t bases_convert<BnFq28>(const Affine<BnFq>*, Affine<BnFq28>*, uint64_t, hipStream_t);
 
 }  // namespace zkmi

@@ -91,20 +91,20 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
 }
 
 // G1 accumulation with the gather of the NEXT point in flight during the current mixed addition,
-// at no register cost: the 112-byte table entry is fetched by seven direct-to-LDS loads
+// at no register cost: the 112-byte (BLS12-381) or 80-byte (BN254) table entry is fetched by seven direct-to-LDS loads
 // (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform LDS base + 16 B x lane),
 // into one of two LDS buffers.  Order inside an iteration: wait -> read point j from LDS -> issue the
 // loads of point j+1 and of index j+2 -> mixed addition (no memory operation inside it).
 // LDS: 2 buffers x 256 threads x 112 B = 56 KB per block, two blocks per CU (VGPR-limited anyway).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-template <int UNUSED = 0>
-__global__ void __launch_bounds__(256, 2)
-k_accum_g1_glds(const Affine<Fq28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+template <class F>
+__global__ void __launch_bounds__(256, AccumWaves<F>::value)
+k_accum_g1_glds(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
                 const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
-                const uint32_t* __restrict__ sorted, XYZZ<Fq28>* __restrict__ buckets, uint32_t total_buckets,
+                const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
                 uint32_t heavy_thr) {
-  constexpr int CHUNKS = sizeof(Affine<Fq28>) / 16;  // 7
+  constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
   __shared__ uint4 tile[2][4][CHUNKS][64];            // [buffer][wave][chunk][lane]
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -113,7 +113,7 @@ k_accum_g1_glds(const Affine<Fq28>* __restrict__ bases, const uint32_t* __restri
   const uint32_t cnt = count[b];
   if (cnt > heavy_thr) return;  // k_accum_heavy owns it
   const uint32_t beg = begin[b], end = beg + cnt;
-  XYZZ<Fq28> acc = XYZZ<Fq28>::infinity();
+  XYZZ<F> acc = XYZZ<F>::infinity();
   auto fetch = [&](uint32_t v, int buf) {
     const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
 #pragma unroll
@@ -129,7 +129,7 @@ k_accum_g1_glds(const Affine<Fq28>* __restrict__ bases, const uint32_t* __restri
   int buf = 0;
   for (uint32_t j = beg; j < end; j++) {
     // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
-    Affine<Fq28> p;
+    Affine<F> p;
     uint4* d = reinterpret_cast<uint4*>(&p);
 #pragma unroll
     for (int q = 0; q < CHUNKS; q++) d[q] = tile[buf][wave][q][lane];
@@ -448,7 +448,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     // the plain gather kernel for A/B runs
     static const bool glds = !(getenv("ZKMI_ACCUM_GLDS") && getenv("ZKMI_ACCUM_GLDS")[0] == '0');
     if (glds)
-      hipLaunchKernelGGL(k_accum_g1_glds<0>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
+      hipLaunchKernelGGL(k_accum_g1_glds<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
                          sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
     else
       hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,

@@ -38,7 +38,8 @@ __device__ __forceinline__ void st_words8(uint32_t* p, const uint32_t* w) {
   q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-__global__ void k_bitrev_copy(const Fr28* __restrict__ in, Fr28* __restrict__ out, int log_n) {
+template <class F>
+__global__ void k_bitrev_copy(const F* __restrict__ in, F* __restrict__ out, int log_n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
   const uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0u;
@@ -54,14 +55,14 @@ __global__ void k_bitrev_copy(const Fr28* __restrict__ in, Fr28* __restrict__ ou
 // per butterfly.  Without LOCAL_TW (three passes, N > 2^20) twiddles are gathered per butterfly.
 // post (optional): every output is multiplied by post[position].  canon_out (optional):
 // outputs are written as canonical 32-byte integers instead of limbs (H MSM digits).
-template <bool DIF, bool LOCAL_TW, int THREADS>
+template <class F, bool DIF, bool LOCAL_TW, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int t0, int S, int Q,
-           const Fr28* __restrict__ post, uint32_t* __restrict__ canon_out) {
+k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
+           const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  Fr28* tile = reinterpret_cast<Fr28*>(lds_raw);
+  F* tile = reinterpret_cast<F*>(lds_raw);
   const uint32_t tile_n = 1u << (S + Q);
-  Fr28* ctw = tile + tile_n;  // LOCAL_TW: w_{2^S}^k, k < 2^(S-1)
+  F* ctw = tile + tile_n;  // LOCAL_TW: w_{2^S}^k, k < 2^(S-1)
   const uint32_t blk = blockIdx.x;
   // tile element L -> global index g:
   //   t0 == 0 : g = blk * tile_n + L
@@ -76,18 +77,18 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
     return (hi << (t0 + S)) | (e << t0) | (mid << Q) | c;
   };
   // w^(column * rev_S(row)) for the element at tile position L of a strided pass
-  auto twist = [&](uint32_t L) -> Fr28 {
+  auto twist = [&](uint32_t L) -> F {
     const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
     const uint32_t col = (mid << Q) | c;
     const uint32_t ex = col * (__brev(e) >> (32 - S));
     const uint32_t halfn = 1u << (log_n - 1);
-    Fr28 f = ld28(tw + (ex & (halfn - 1u)));
+    F f = ld28(tw + (ex & (halfn - 1u)));
     return (ex & halfn) ? f.neg() : f;
   };
   if (LOCAL_TW)
     for (uint32_t k = threadIdx.x; k < (1u << (S - 1)); k += THREADS) ctw[k] = ld28(tw + ((size_t)k << (log_n - S)));
   for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
-    Fr28 v = ld28(data + gindex(L));
+    F v = ld28(data + gindex(L));
     if (LOCAL_TW && !DIF && t0 > 0) v = v * twist(L);
     tile[L] = v;
   }
@@ -103,20 +104,20 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
       const uint32_t lo = b & (dist - 1u);
       const uint32_t L0 = ((b >> dist_log) << (dist_log + 1)) | lo;
       const uint32_t L1 = L0 | dist;
-      Fr28 w;
+      F w;
       if (LOCAL_TW) {
         w = ctw[(lo >> qeff) << (S - 1 - u)];
       } else {
         const uint32_t j = gindex(L0) & ((1u << t) - 1u);
         w = ld28(tw + ((size_t)j << (log_n - 1 - t)));
       }
-      const Fr28 x = tile[L0];
+      const F x = tile[L0];
       if (DIF) {
-        const Fr28 y = tile[L1];
+        const F y = tile[L1];
         tile[L0] = x + y;
         tile[L1] = x.sub_lazy(y) * w;
       } else {
-        const Fr28 y = tile[L1] * w;
+        const F y = tile[L1] * w;
         tile[L0] = x + y;
         tile[L1] = x - y;
       }
@@ -126,7 +127,7 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
 
   for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
     const uint32_t g = gindex(L);
-    Fr28 v = tile[L];
+    F v = tile[L];
     if (LOCAL_TW && DIF && t0 > 0) v = v * twist(L);
     if (post) v = v * ld28(post + g);
     if (canon_out) {
@@ -139,24 +140,27 @@ k_ntt_pass(Fr28* __restrict__ data, const Fr28* __restrict__ tw, int log_n, int 
   }
 }
 
+template <class F>
 __global__ void __launch_bounds__(256)
-k_mul_table(Fr28* __restrict__ a, const Fr28* __restrict__ b, uint32_t n) {
+k_mul_table(F* __restrict__ a, const F* __restrict__ b, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) st28(a + i, ld28(a + i) * ld28(b + i));
 }
 
+template <class F>
 __global__ void __launch_bounds__(256)
-k_scale(Fr28* __restrict__ a, Fr28 s, uint32_t n) {
+k_scale(F* __restrict__ a, F s, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) st28(a + i, ld28(a + i) * s);
 }
 
 // out[i] = first * base^i, i < n: thread t starts at base^(16 t) by square-and-multiply
+template <class F>
 __global__ void __launch_bounds__(256)
-k_power_table(Fr28* __restrict__ out, Fr28 base, Fr28 first, uint32_t n) {
+k_power_table(F* __restrict__ out, F base, F first, uint32_t n) {
   const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
   if (i0 >= n) return;
-  Fr28 v = first, sq = base;
+  F v = first, sq = base;
   for (uint32_t e = i0; e; e >>= 1) {
     if (e & 1u) v = v * sq;
     sq = sq * sq;
@@ -168,16 +172,18 @@ k_power_table(Fr28* __restrict__ out, Fr28 base, Fr28 first, uint32_t n) {
 }
 
 // canonical 32-byte integers <-> limbs (Montgomery R = 2^280)
+template <class F>
 __global__ void __launch_bounds__(256)
-k_from_canonical(const uint32_t* __restrict__ in, Fr28* __restrict__ out, uint32_t n) {
+k_from_canonical(const uint32_t* __restrict__ in, F* __restrict__ out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t w[8];
   ld_words8(in + (size_t)i * 8, w);
-  st28(out + i, Fr28::from_canonical(w));
+  st28(out + i, F::from_canonical(w));
 }
+template <class F>
 __global__ void __launch_bounds__(256)
-k_to_canonical(const Fr28* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+k_to_canonical(const F* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t w[8];
@@ -201,58 +207,75 @@ Fr fr_root_of_unity(int log_n) {
   return w;
 }
 
-static Fr host_fr_from_u64(uint64_t v) {
-  Fr a = Fr::zero();
+NttField<Fr28>::Host NttField<Fr28>::root_max() { return fr_root_of_unity(32); }
+NttField<BnFr28>::Host NttField<BnFr28>::root_max() {
+  // halo2curves bn256::Fr::ROOT_OF_UNITY = 7^((r-1)/2^28)
+  static const uint32_t ROOT_2_28[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du,
+                                        0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
+  BnFr w;
+  for (int i = 0; i < 8; i++) w.l[i] = ROOT_2_28[i];
+  return w.to_mont();
+}
+
+template <class H>
+static H host_from_u64(uint64_t v) {
+  H a = H::zero();
   a.l[0] = (uint32_t)v;
   a.l[1] = (uint32_t)(v >> 32);
   return a.to_mont();
 }
-static Fr28 to28(const Fr& a) {
-  Fr c = a.from_mont();
-  return Fr28::from_canonical(c.l);
+template <class F, class H>
+static F to28(const H& a) {
+  H c = a.from_mont();
+  return F::from_canonical(c.l);
 }
 
-NttDomain::~NttDomain() {
-  Fr28* ptrs[] = {tw_fwd, tw_inv, coset_fwd, coset_inv_n, rev_coset_n, rev_coset_inv_n, n_inv, scratch};
-  for (Fr28* p : ptrs)
+template <class F>
+NttDomainT<F>::~NttDomainT() {
+  F* ptrs[] = {tw_fwd, tw_inv, coset_fwd, coset_inv_n, rev_coset_n, rev_coset_inv_n, n_inv, scratch};
+  for (F* p : ptrs)
     if (p) (void)hipFree(p);
 }
 
-hipError_t NttDomain::init(int log_n_, hipStream_t stream) {
+template <class F>
+hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
+  using H = typename NttField<F>::Host;
+  if (log_n_ > NttField<F>::TWO_ADICITY) return hipErrorInvalidValue;
   log_n = log_n_;
   const uint32_t n = 1u << log_n;
   const uint32_t half = n > 1 ? n / 2 : 1;
   hipError_t e;
-  Fr28** alloc_n[] = {&coset_fwd, &coset_inv_n, &rev_coset_n, &rev_coset_inv_n, &scratch};
-  if ((e = hipMalloc(&tw_fwd, sizeof(Fr28) * half)) != hipSuccess) return e;
-  if ((e = hipMalloc(&tw_inv, sizeof(Fr28) * half)) != hipSuccess) return e;
-  if ((e = hipMalloc(&n_inv, sizeof(Fr28))) != hipSuccess) return e;
-  for (Fr28** p : alloc_n)
-    if ((e = hipMalloc(p, sizeof(Fr28) * n)) != hipSuccess) return e;
-  const Fr w = fr_root_of_unity(log_n);
-  const Fr g = host_fr_from_u64(7);
-  const Fr ninv = host_fr_from_u64(n).inv();
-  const Fr28 one28 = Fr28::one(), ninv28 = to28(ninv);
+  F** alloc_n[] = {&coset_fwd, &coset_inv_n, &rev_coset_n, &rev_coset_inv_n, &scratch};
+  if ((e = hipMalloc(&tw_fwd, sizeof(F) * half)) != hipSuccess) return e;
+  if ((e = hipMalloc(&tw_inv, sizeof(F) * half)) != hipSuccess) return e;
+  if ((e = hipMalloc(&n_inv, sizeof(F))) != hipSuccess) return e;
+  for (F** p : alloc_n)
+    if ((e = hipMalloc(p, sizeof(F) * n)) != hipSuccess) return e;
+  H w = NttField<F>::root_max();
+  for (int i = NttField<F>::TWO_ADICITY; i > log_n; i--) w = w.sqr();
+  const H g = host_from_u64<H>(7);
+  const H ninv = host_from_u64<H>(n).inv();
+  const F one28 = F::one(), ninv28 = to28<F, H>(ninv);
   n_inv_host = ninv28;
   const int T = 256;
   auto blocks = [&](uint32_t cnt) { return (cnt + 16 * T - 1) / (16 * T); };
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_fwd, to28(w), one28, half);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(half)), dim3(T), 0, stream, tw_inv, to28(w.inv()), one28, half);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_fwd, to28(g), one28, n);
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, coset_inv_n, to28(g.inv()), ninv28, n);
+  hipLaunchKernelGGL(k_power_table<F>, dim3(blocks(half)), dim3(T), 0, stream, tw_fwd, to28<F, H>(w), one28, half);
+  hipLaunchKernelGGL(k_power_table<F>, dim3(blocks(half)), dim3(T), 0, stream, tw_inv, to28<F, H>(w.inv()), one28, half);
+  hipLaunchKernelGGL(k_power_table<F>, dim3(blocks(n)), dim3(T), 0, stream, coset_fwd, to28<F, H>(g), one28, n);
+  hipLaunchKernelGGL(k_power_table<F>, dim3(blocks(n)), dim3(T), 0, stream, coset_inv_n, to28<F, H>(g.inv()), ninv28, n);
   // position-indexed tables for bit-reversed coefficient order: entry p <- index rev(p)
-  hipLaunchKernelGGL(k_power_table, dim3(blocks(n)), dim3(T), 0, stream, scratch, to28(g), ninv28, n);
-  hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, scratch, rev_coset_n, log_n);
-  hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, coset_inv_n, rev_coset_inv_n, log_n);
-  if ((e = hipMemcpyAsync(n_inv, &ninv28, sizeof(Fr28), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_power_table<F>, dim3(blocks(n)), dim3(T), 0, stream, scratch, to28<F, H>(g), ninv28, n);
+  hipLaunchKernelGGL(k_bitrev_copy<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, scratch, rev_coset_n, log_n);
+  hipLaunchKernelGGL(k_bitrev_copy<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, coset_inv_n, rev_coset_inv_n, log_n);
+  if ((e = hipMemcpyAsync(n_inv, &ninv28, sizeof(F), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   return hipGetLastError();
 }
 
 // stages [0, log_n) split into passes of <= 10 stages; pass k of a DIT transform
 // covers the low stages first, of a DIF transform the high stages first
-template <bool DIF>
-static hipError_t run_passes(Fr28* buf, const Fr28* tw, int log_n, const Fr28* post, uint32_t* canon_out,
+template <class F, bool DIF>
+static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
                              hipStream_t stream) {
   const uint32_t n = 1u << log_n;
   struct Pass {
@@ -274,90 +297,109 @@ static hipError_t run_passes(Fr28* buf, const Fr28* tw, int log_n, const Fr28* p
     const bool last = (k == np - 1);
     const uint32_t tile_n = 1u << (p.S + p.Q);
     const uint32_t nblk = n / tile_n;
-    const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(Fr28);
-    const Fr28* pp = last ? post : nullptr;
+    const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(F);
+    const F* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
     if (tile_n >= 1024) {
       if (local_tw)
-        hipLaunchKernelGGL((k_ntt_pass<DIF, true, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
                            p.Q, pp, co);
       else
-        hipLaunchKernelGGL((k_ntt_pass<DIF, false, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
                            p.S, p.Q, pp, co);
     } else if (local_tw) {
-      hipLaunchKernelGGL((k_ntt_pass<DIF, true, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     } else {
-      hipLaunchKernelGGL((k_ntt_pass<DIF, false, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     }
   }
   return hipGetLastError();
 }
 
-hipError_t NttDomain::inverse_to_rev(Fr28* d, const Fr28* post_table, uint32_t* canon_out, hipStream_t st) {
+template <class F>
+hipError_t NttDomainT<F>::inverse_to_rev(F* d, const F* post_table, uint32_t* canon_out, hipStream_t st) {
   if (log_n == 0) {
     // single element: only the post factor / output format applies
-    if (post_table) hipLaunchKernelGGL(k_mul_table, dim3(1), dim3(256), 0, st, d, post_table, 1u);
-    if (canon_out) hipLaunchKernelGGL(k_to_canonical, dim3(1), dim3(256), 0, st, d, canon_out, 1u);
+    if (post_table) hipLaunchKernelGGL(k_mul_table<F>, dim3(1), dim3(256), 0, st, d, post_table, 1u);
+    if (canon_out) hipLaunchKernelGGL(k_to_canonical<F>, dim3(1), dim3(256), 0, st, d, canon_out, 1u);
     return hipGetLastError();
   }
-  return run_passes<true>(d, tw_inv, log_n, post_table, canon_out, st);
+  return run_passes<F, true>(d, tw_inv, log_n, post_table, canon_out, st);
 }
 
-hipError_t NttDomain::forward_from_rev(Fr28* d, hipStream_t st) {
+template <class F>
+hipError_t NttDomainT<F>::forward_from_rev(F* d, hipStream_t st) {
   if (log_n == 0) return hipSuccess;
-  return run_passes<false>(d, tw_fwd, log_n, nullptr, nullptr, st);
+  return run_passes<F, false>(d, tw_fwd, log_n, nullptr, nullptr, st);
 }
 
 // natural order in and out (public entry point)
-hipError_t NttDomain::transform(Fr28* d_data, bool inverse, bool coset, hipStream_t stream) {
+template <class F>
+hipError_t NttDomainT<F>::transform(F* d_data, bool inverse, bool coset, hipStream_t stream) {
   const uint32_t n = 1u << log_n;
   const int T = 256;
   if (coset && !inverse)
-    hipLaunchKernelGGL(k_mul_table, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_fwd, n);
+    hipLaunchKernelGGL(k_mul_table<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_fwd, n);
   if (log_n > 0) {
-    hipLaunchKernelGGL(k_bitrev_copy, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, scratch, log_n);
-    hipError_t e = run_passes<false>(scratch, inverse ? tw_inv : tw_fwd, log_n, nullptr, nullptr, stream);
+    hipLaunchKernelGGL(k_bitrev_copy<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, scratch, log_n);
+    hipError_t e = run_passes<F, false>(scratch, inverse ? tw_inv : tw_fwd, log_n, nullptr, nullptr, stream);
     if (e != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(d_data, scratch, sizeof(Fr28) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_data, scratch, sizeof(F) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
   }
   if (inverse) {
     if (coset) {
-      hipLaunchKernelGGL(k_mul_table, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_inv_n, n);
+      hipLaunchKernelGGL(k_mul_table<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, coset_inv_n, n);
     } else {
-      hipLaunchKernelGGL(k_scale, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, n_inv_host, n);
+      hipLaunchKernelGGL(k_scale<F>, dim3((n + T - 1) / T), dim3(T), 0, stream, d_data, n_inv_host, n);
     }
   }
   return hipGetLastError();
 }
 
-hipError_t ntt_from_canonical(const uint32_t* d_in, Fr28* d_out, uint32_t n, hipStream_t s) {
+template <class F>
+hipError_t ntt_from_canonical(const uint32_t* d_in, F* d_out, uint32_t n, hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_from_canonical, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  hipLaunchKernelGGL(k_from_canonical<F>, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
   return hipGetLastError();
 }
-hipError_t ntt_to_canonical(const Fr28* d_in, uint32_t* d_out, uint32_t n, hipStream_t s) {
+template <class F>
+hipError_t ntt_to_canonical(const F* d_in, uint32_t* d_out, uint32_t n, hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_to_canonical, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  hipLaunchKernelGGL(k_to_canonical<F>, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
   return hipGetLastError();
 }
-hipError_t ntt_mul_table(Fr28* d, const Fr28* table, uint32_t n, hipStream_t s) {
+template <class F>
+hipError_t ntt_mul_table(F* d, const F* table, uint32_t n, hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_mul_table, dim3((n + 255) / 256), dim3(256), 0, s, d, table, n);
+  hipLaunchKernelGGL(k_mul_table<F>, dim3((n + 255) / 256), dim3(256), 0, s, d, table, n);
   return hipGetLastError();
 }
 
 hipError_t ntt_enable_big_lds() {
-  const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass<true, true, 1024>),
-                       reinterpret_cast<const void*>(k_ntt_pass<false, true, 1024>),
-                       reinterpret_cast<const void*>(k_ntt_pass<true, false, 1024>),
-                       reinterpret_cast<const void*>(k_ntt_pass<false, false, 1024>)};
+  const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, false, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, false, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, false, false, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, true, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, false, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, false, 1024>)};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
+
+template struct NttDomainT<Fr28>;
+template struct NttDomainT<BnFr28>;
+template hipError_t ntt_from_canonical<Fr28>(const uint32_t*, Fr28*, uint32_t, hipStream_t);
+template hipError_t ntt_to_canonical<Fr28>(const Fr28*, uint32_t*, uint32_t, hipStream_t);
+template hipError_t ntt_mul_table<Fr28>(Fr28*, const Fr28*, uint32_t, hipStream_t);
+template hipError_t ntt_from_canonical<BnFr28>(const uint32_t*, BnFr28*, uint32_t, hipStream_t);
+template hipError_t ntt_to_canonical<BnFr28>(const BnFr28*, uint32_t*, uint32_t, hipStream_t);
+template hipError_t ntt_mul_table<BnFr28>(BnFr28*, const BnFr28*, uint32_t, hipStream_t);
 
 }  // namespace zkmi
