@@ -119,7 +119,7 @@ class Zkmi:
     """Loads libzkmi.so.  Fails loudly if it is missing (no fallback path)."""
 
     def __init__(self, path=None):
-        path = path or lib_path()
+        path = path or os.environ.get("ZKMI_LIB") or lib_path()
         if not os.path.exists(path):
             raise ZkmiError(-4, f"{path} not built; run __graft_entry__.build()")
         self.lib = C.CDLL(path)
