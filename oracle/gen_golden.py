@@ -8,6 +8,11 @@ What pins what:
                         mocked_zk / contract boundary (scalar.rs:36-54,
                         mocked_zk/src/tests.rs:27-35, contract/merkle.rs:115-132),
                         recomputed with hashlib;
+  * poseidon.json       Poseidon-5 constants digest, permutation / hash / Merkle vectors for
+                        BLS12-381 Fr and BN254 Fr, plus the published BN254 known answers the
+                        generator is pinned by (circomlib), and the update_note relation's
+                        public values for one seeded instance;
+  * bn254.json          BN254 G1 MSM / Fr NTT / KZG-commit vectors (halo2curves constants);
   * ntt_small.json, msm_small.json, groth16_n128.json, pairing.json
                         oracle outputs on seeded inputs (parity unpinned against the
                         reference, which has no such code; pinned by the O(N^2)
@@ -207,8 +212,85 @@ def groth16_n128():
     )
 
 
+def poseidon_vectors():
+    from . import poseidon as ps
+
+    out = {"published_bn254": {
+        "rc0_t2_8_56": hex(ps.spec("bn254_fr", 2, 8, 56)[0][0][0]),
+        "rc0_t3_8_57": hex(ps.spec("bn254_fr", 3, 8, 57)[0][0][0]),
+        "permute_0_1_2_t3_8_57": hex(ps.permute([0, 1, 2], "bn254_fr", 8, 57)[0]),
+        "permute_0_1_2_3_4_t5_8_60": hex(ps.permute([0, 1, 2, 3, 4], "bn254_fr", 8, 60)[0]),
+    }}
+    for field in ("bls12_381_fr", "bn254_fr"):
+        p, _ = ps.FIELDS[field]
+        rc, mds = ps.spec(field)
+        flat = b"".join(v.to_bytes(32, "little") for row in rc for v in row) + b"".join(
+            v.to_bytes(32, "little") for row in mds for v in row)
+        rng = ec.SplitMix64(0x905E1D00 + len(field))
+        cases = []
+        for arity in (0, 1, 2, 3, 4, 5, 8):
+            vals = [rng.next() * rng.next() * rng.next() * rng.next() % p for _ in range(arity)]
+            cases.append({"inputs": [hex(v) for v in vals], "hash": hex(ps.hash_fix_len(vals, field))})
+        leaves = [ps.hash_fix_len([i], field) for i in range(8)]
+        out[field] = {
+            "constants_sha256": hashlib.sha256(flat).hexdigest(),
+            "rc_first": hex(rc[0][0]), "rc_last": hex(rc[-1][-1]), "mds_00": hex(mds[0][0]), "mds_44": hex(mds[4][4]),
+            "permute_0_1_2_3_4": [hex(v) for v in ps.permute([0, 1, 2, 3, 4], field)],
+            "hashes": cases,
+            "merkle_8_leaves_root": hex(ps.merkle_tree(leaves, field)[-1][0]),
+        }
+    # one update_note instance (withdraw): inputs and the public values the relation exposes
+    rng = ec.SplitMix64(0x0DA7E)
+    tok = [rng.fr(), rng.fr()]
+    bal = [1000, 77]
+    new_id, old_id, ot, on, nt_, nn, user = (rng.fr() for _ in range(7))
+    shape = [rng.next() & 1 for _ in range(10)]
+    path = [rng.fr() for _ in range(10)]
+    amount = 250
+    old_acc = ps.hash_fix_len([tok[0], bal[0], tok[1], bal[1]])
+    root = ps.merkle_root(ps.hash_fix_len([old_id, ot, on, old_acc]), shape, path)
+    new_acc = ps.hash_fix_len([tok[0], bal[0] - amount, tok[1], bal[1]])
+    out["update_note_withdraw"] = {
+        "amount": amount, "token": hex(tok[0]), "user": hex(user),
+        "new_note": [hex(new_id), hex(nt_), hex(nn)], "old_note": [hex(old_id), hex(ot), hex(on)],
+        "path_shape": shape, "path": [hex(v) for v in path],
+        "account": [hex(tok[0]), hex(bal[0]), hex(tok[1]), hex(bal[1])],
+        "publics": [hex(v) for v in (amount, tok[0], user, ps.hash_fix_len([new_id, nt_, nn, new_acc]), root, on)],
+    }
+    dump("poseidon.json", out)
+
+
+def bn254_vectors():
+    from . import bn254 as bn
+
+    rng = ec.SplitMix64(0xB254)
+    rnd = lambda: rng.next() * rng.next() * rng.next() * rng.next() % bn.R
+    n = 64
+    pts = bn.synthetic_bases(n)
+    sc = [rnd() for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, bn.R - 1
+    a = [rnd() for _ in range(32)]
+    frs = lambda v: b"".join(int(x).to_bytes(32, "little") for x in v).hex()
+    tau = 0xDEADBEEFCAFEF00D1234567 % bn.R
+    coeffs = [rnd() for _ in range(16)]
+    dump("bn254.json", {
+        "p": hex(bn.P), "r": hex(bn.R), "root_2_28": hex(bn.FR_ROOT_2_28),
+        "synthetic_first4": [bn.g1_to_bytes(p).hex() for p in pts[:4]],
+        "msm": {"scalars": frs(sc), "bases": b"".join(bn.g1_to_bytes(p) for p in pts).hex(),
+                "expected": bn.g1_to_bytes(bn.msm_naive(sc, pts)).hex()},
+        "ntt": {"log_n": 5, "input": frs(a), "forward": frs(bn.ntt(a)), "inverse": frs(bn.ntt(a, inverse=True)),
+                "coset_forward": frs(bn.ntt(a, coset=True)), "coset_inverse": frs(bn.ntt(a, inverse=True, coset=True))},
+        "kzg": {"log_n": 4, "tau": hex(tau),
+                "srs": b"".join(bn.g1_to_bytes(bn.pt_mul(bn.G1, pow(tau, i, bn.R))) for i in range(16)).hex(),
+                "evaluations": frs(bn.ntt(coeffs)), "coefficients": frs(coeffs),
+                "commitment": bn.g1_to_bytes(bn.pt_mul(bn.G1, sum(c * pow(tau, i, bn.R) for i, c in enumerate(coeffs)) % bn.R)).hex()},
+    })
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    poseidon_vectors()
+    bn254_vectors()
     constants()
     mock_boundary()
     ntt_small()

@@ -391,3 +391,24 @@ def test_update_note_value_synthesis_equals_constraint_builder(zk):
         wv, rcv = zk.update_note_witness_values_host(lg, 1, i)
         assert rc == rcv == code
         assert wv == w
+
+
+def test_update_note_witness_matches_golden_publics(zk):
+    """The seeded update_note instance of tests/golden/poseidon.json: the library's witness generator
+    (host code) returns exactly the committed public inputs (note hash and Merkle root = Poseidon-5)."""
+    from conftest import golden
+
+    g = golden("poseidon.json")["update_note_withdraw"]
+    i = lambda v: int(v, 16) if isinstance(v, str) else int(v)
+    inp = zk.note_update(g["amount"], i(g["token"]), i(g["user"]), [i(v) for v in g["new_note"]], [i(v) for v in g["old_note"]],
+                         g["path_shape"], [i(v) for v in g["path"]], i(g["user"]), [i(v) for v in g["account"]])
+    _, pub, rc = zk.update_note_witness(14, 1, inp)
+    assert rc == 0 and [hex(v) for v in pub] == g["publics"]
+    rc_first = zk.poseidon_spec(0)[0][0][0]
+    assert hex(rc_first) == golden("poseidon.json")["bls12_381_fr"]["rc_first"]
+    import hashlib
+
+    for field, name in ((0, "bls12_381_fr"), (1, "bn254_fr")):
+        rc_, mds = zk.poseidon_spec(field)
+        flat = b"".join(v.to_bytes(32, "little") for row in rc_ for v in row) + b"".join(v.to_bytes(32, "little") for row in mds for v in row)
+        assert hashlib.sha256(flat).hexdigest() == golden("poseidon.json")[name]["constants_sha256"]

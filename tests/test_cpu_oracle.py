@@ -195,3 +195,25 @@ def test_bn254_constants_and_definitions():
     assert bn.ntt(bn.ntt(a, coset=True), inverse=True, coset=True) == a
     pts = bn.synthetic_bases(5)
     assert pts[3] == bn.pt_mul(bn.G1, 1 + 3 * 0xC0FFEE) and all(bn.on_curve(p) for p in pts)
+
+
+def test_poseidon_and_bn254_golden_fixtures_reproduce():
+    """tests/golden/poseidon.json and bn254.json (python -m oracle.gen_golden) are what the oracle
+    computes today; the published BN254 Poseidon values in the fixture are the literal known answers."""
+    from oracle import bn254 as bn
+    from oracle import poseidon as ps
+
+    g = golden("poseidon.json")
+    pub = g["published_bn254"]
+    assert pub["rc0_t2_8_56"] == "0x9c46e9ec68e9bd4fe1faaba294cba38a71aa177534cdd1b6c7dc0dbd0abd7a7"
+    assert pub["permute_0_1_2_3_4_t5_8_60"] == "0x299c867db6c1fdd79dcefa40e4510b9837e60ebb1ce0663dbaa525df65250465"
+    for field in ("bls12_381_fr", "bn254_fr"):
+        f = g[field]
+        assert [hex(v) for v in ps.permute([0, 1, 2, 3, 4], field)] == f["permute_0_1_2_3_4"]
+        for c in f["hashes"]:
+            assert hex(ps.hash_fix_len([int(v, 16) for v in c["inputs"]], field)) == c["hash"]
+    b = golden("bn254.json")
+    sc = [int.from_bytes(H(b["msm"]["scalars"])[i : i + 32], "little") for i in range(0, 64 * 32, 32)]
+    assert bn.g1_to_bytes(bn.msm_naive(sc, bn.synthetic_bases(64))).hex() == b["msm"]["expected"]
+    a = [int.from_bytes(H(b["ntt"]["input"])[i : i + 32], "little") for i in range(0, 32 * 32, 32)]
+    assert b"".join(v.to_bytes(32, "little") for v in bn.ntt(a)).hex() == b["ntt"]["forward"]

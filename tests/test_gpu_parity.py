@@ -755,3 +755,33 @@ def test_bn254_kzg_commit(ctx):
     assert got == bn.g1_to_bytes(bn.pt_mul(bn.G1, p_tau))
     assert bytes(d.cpu().numpy().tobytes()) == _bn_frs(coeffs)  # the coefficients are left in place
     b.free()
+
+
+def test_poseidon_and_bn254_golden_fixtures_on_gpu(ctx, zk):
+    """HIP path vs the committed fixtures (tests/golden/poseidon.json, bn254.json)."""
+    g = golden("poseidon.json")
+    for field, name in ((0, "bls12_381_fr"), (1, "bn254_fr")):
+        for c in g[name]["hashes"]:
+            vals = [int(v, 16) for v in c["inputs"]]
+            got = ctx.poseidon_hash_batch(b"".join(v.to_bytes(32, "little") for v in vals), 1, len(vals), field)
+            assert hex(int.from_bytes(got, "little")) == c["hash"]
+    b = golden("bn254.json")
+    bases = ctx.bn254_bases(H(b["msm"]["bases"]))
+    assert bases.read(0, 4) == b"".join(H(x) for x in b["synthetic_first4"])
+    assert ctx.bn254_msm_g1(H(b["msm"]["scalars"]), bases).hex() == b["msm"]["expected"]
+    bases.free()
+    n = b["ntt"]
+    x = H(n["input"])
+    assert ctx.bn254_ntt(x, n["log_n"]).hex() == n["forward"]
+    assert ctx.bn254_ntt(x, n["log_n"], inverse=True).hex() == n["inverse"]
+    assert ctx.bn254_ntt(x, n["log_n"], coset=True).hex() == n["coset_forward"]
+    assert ctx.bn254_ntt(x, n["log_n"], inverse=True, coset=True).hex() == n["coset_inverse"]
+    import torch
+
+    k = b["kzg"]
+    srs = ctx.bn254_bases(H(k["srs"]))
+    d = torch.frombuffer(bytearray(H(k["evaluations"])), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert ctx.bn254_kzg_commit_dev(d.data_ptr(), k["log_n"], srs).hex() == k["commitment"]
+    assert bytes(d.cpu().numpy().tobytes()).hex() == k["coefficients"]
+    srs.free()
