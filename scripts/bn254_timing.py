@@ -22,6 +22,11 @@ for it in range(3):
     ctx.prof_reset()
     t = time.time(); ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b); dt = time.time() - t
     print(f"bn254 msm_g1 2^{lg}: wall {dt*1e3:.2f} ms", {k: round(ctx.prof_get(k)[0], 3) for k in ("msm_sort", "msm_accum_g1", "msm_reduce_g1")})
+b.prepare()
+for it in range(3):
+    ctx.prof_reset()
+    t = time.time(); ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b); dt = time.time() - t
+    print(f"bn254 msm_g1 2^{lg} (prepared SRS): wall {dt*1e3:.2f} ms", {k: round(ctx.prof_get(k)[0], 3) for k in ("msm_sort", "msm_accum_g1", "msm_reduce_g1")})
 x = raw.clone()
 for it in range(3):
     ctx.prof_reset()

@@ -785,3 +785,36 @@ def test_poseidon_and_bn254_golden_fixtures_on_gpu(ctx, zk):
     assert ctx.bn254_kzg_commit_dev(d.data_ptr(), k["log_n"], srs).hex() == k["commitment"]
     assert bytes(d.cpu().numpy().tobytes()).hex() == k["coefficients"]
     srs.free()
+
+
+def test_bn254_prepared_srs_matches_plain_msm(ctx):
+    """zkmi_bn254_srs_prepare (fixed-base table, shared buckets) gives the same MSM / commitment as the
+    windowed schedule, for small, odd and large lengths and for edge scalars."""
+    import torch
+    from oracle import bn254 as bn
+
+    rng = ec.SplitMix64(1313)
+    for n in (1, 16, 77, 1000, 5000):
+        sc = [rng.next() * rng.next() * rng.next() * rng.next() % bn.R for _ in range(n)]
+        sc[0] = bn.R - 1
+        if n > 2:
+            sc[1], sc[2] = 0, 1
+        b = ctx.bn254_bases_synthetic(n)
+        plain = ctx.bn254_msm_g1(_bn_frs(sc), b)
+        b.prepare()
+        assert ctx.bn254_msm_g1(_bn_frs(sc), b) == plain
+        if n <= 77:
+            assert plain == bn.g1_to_bytes(bn.msm_naive(sc, bn.synthetic_bases(n)))
+        # a shorter MSM over prepared bases falls back to the windowed schedule
+        if n > 16:
+            assert ctx.bn254_msm_g1(_bn_frs(sc[:16]), b) == bn.g1_to_bytes(bn.msm_naive(sc[:16], bn.synthetic_bases(16)))
+        b.free()
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(7)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x1F
+    b = ctx.bn254_bases_synthetic(n)
+    plain = ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b)
+    b.prepare()
+    assert ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b) == plain
+    b.free()

@@ -640,6 +640,11 @@ class BnBases:
     def __init__(self, ctx, h, n):
         self.ctx, self.h, self.n = ctx, h, n
 
+    def prepare(self):
+        """Fixed-base table for repeated commitments against this SRS (zkmi_bn254_srs_prepare)."""
+        self.ctx._chk(self.ctx.lib.zkmi_bn254_srs_prepare(self.ctx.h, self.h))
+        return self
+
     def read(self, first, count):
         out = (C.c_uint8 * (64 * max(1, count)))()
         self.ctx._chk(self.ctx.lib.zkmi_bn254_bases_read(self.ctx.h, self.h, C.c_uint64(first), C.c_uint64(count), out))

@@ -25,6 +25,7 @@ using namespace zkmi;
 struct zkmi_bn_bases {
   zkmi_ctx* ctx;
   Affine<BnFq28>* d28 = nullptr;  // device MSM representation (10 limbs, R = 2^280)
+  Affine<BnFq28>* tab = nullptr;  // optional: 2^(c w) * P_i for every digit position w (zkmi_bn254_srs_prepare)
   uint64_t n = 0;
 };
 
@@ -103,11 +104,18 @@ hipError_t work_buffer(zkmi_ctx* ctx, uint64_t bytes) {
 }
 
 int32_t msm_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_bases* bases, uint8_t out[64]) {
-  ZK_HIP(ctx, ctx->sort.reserve(n));
-  ZK_HIP(ctx, ctx->g1_bn.reserve(n));
-  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g1_bn.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1,
-                                    PH_MSM_REDUCE_G1));
+  // a prepared SRS (fixed bases, full length): every digit of a scalar goes to ONE set of buckets through
+  // the table of 2^(c w) multiples -- 13 insertions per scalar instead of 16, 16 partition sums instead of
+  // a Horner walk over the windows (the prover's shared-bucket schedule)
+  const bool shared = bases->tab != nullptr && n == bases->n && n > 0;
+  ZK_HIP(ctx, ctx->sort.reserve(n, shared));
+  ZK_HIP(ctx, ctx->g1_bn.reserve(n, shared));
+  if (shared)
+    ZK_HIP(ctx, ctx->sort.run_shared(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  else
+    ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g1_bn.run_device(ctx->sort, shared ? bases->tab : bases->d28, ctx->stream, ctx->stream_aux,
+                                    ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   XYZZ<BnFq> res;
   ZK_HIP(ctx, ctx->g1_bn.finish_host(&res));
   const Affine<BnFq> a = res.to_affine();
@@ -174,9 +182,27 @@ int32_t zkmi_bn254_bases_read(zkmi_ctx* ctx, const zkmi_bn_bases* b, uint64_t fi
   return ZKMI_OK;
 }
 
+// Fixed-base preparation of an SRS: table[w * n + i] = 2^(c w) * P_i (13 x n points at n = 2^20, 1.1 GB).
+// MSMs / commitments of exactly n terms over these bases then run the shared-bucket schedule.
+int32_t zkmi_bn254_srs_prepare(zkmi_ctx* ctx, zkmi_bn_bases* b) {
+  ZK_ENTER(ctx);
+  if (!b || b->n == 0) return ZKMI_ERR_BAD_ARG;
+  if (b->tab) return ZKMI_OK;
+  const MsmPlan plan = msm_make_plan_shared(b->n);
+  hipError_t e = msm_build_table<BnFq28>(b->d28, b->n, plan, &b->tab, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (b->tab) (void)hipFree(b->tab);
+    b->tab = nullptr;
+    return ctx->hip_fail(e, "bn254 srs table");
+  }
+  return ZKMI_OK;
+}
+
 int32_t zkmi_bn254_bases_free(zkmi_bn_bases* b) {
   if (!b) return ZKMI_ERR_BAD_ARG;
   if (b->d28) (void)hipFree(b->d28);
+  if (b->tab) (void)hipFree(b->tab);
   delete b;
   return ZKMI_OK;
 }

@@ -134,6 +134,7 @@ extern template struct MsmEngine<Fq2_28>;
 extern template struct MsmEngine<BnFq28>;
 extern template hipError_t msm_build_table<Fq28>(const Affine<Fq28>*, uint64_t, const MsmPlan&, Affine<Fq28>**, hipStream_t);
 extern template hipError_t msm_build_table<Fq2_28>(const Affine<Fq2_28>*, uint64_t, const MsmPlan&, Affine<Fq2_28>**, hipStream_t);
+extern template hipError_t msm_build_table<BnFq28>(const Affine<BnFq28>*, uint64_t, const MsmPlan&, Affine<BnFq28>**, hipStream_t);
 extern template hipError_t bases_convert<Fq28>(const Affine<Fq>*, Affine<Fq28>*, uint64_t, hipStream_t);
 extern template hipError_t bases_convert<Fq2_28>(const Affine<Fq2>*, Affine<Fq2_28>*, uint64_t, hipStream_t);
 extern template hipError_t bases_convert<BnFq28>(const Affine<BnFq>*, Affine<BnFq28>*, uint64_t, hipStream_t);
