@@ -818,3 +818,61 @@ def test_bn254_prepared_srs_matches_plain_msm(ctx):
     b.prepare()
     assert ctx.bn254_msm_g1_dev(raw.data_ptr(), n, b) == plain
     b.free()
+
+
+def test_msm_random_sizes_vs_cpp_oracle(ctx):
+    """A sweep over irregular lengths (1 ... 40 000, powers of two and their neighbours included) of G1
+    and G2 MSMs against the C++ oracle on the same seeded inputs; every plan boundary of the window /
+    chunk selection is crossed somewhere in the sweep."""
+    import random
+
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    rnd = random.Random(2718)
+    sizes = [1, 2, 3, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4097] + [rnd.randrange(5, 40000) for _ in range(8)]
+    nmax = max(sizes)
+    b1 = ctx.bases_g1_synthetic(nmax)
+    raw_b1 = b1.read(0, nmax)
+    for n in sizes:
+        sc = bytearray(rnd.randbytes(32 * n))
+        for i in range(31, 32 * n, 32):
+            sc[i] &= 0x3F
+        sc = bytes(sc)
+        assert ctx.msm_g1(sc, b1) == ocpp.msm_g1(sc, raw_b1[: 96 * n]), n
+    b1.free()
+    g2_sizes = [1, 2, 65, 257, 1025, rnd.randrange(1500, 6000)]
+    nmax2 = max(g2_sizes)
+    b2 = ctx.bases_g2_synthetic(nmax2)
+    raw_b2 = b2.read(0, nmax2)
+    for n in g2_sizes:
+        sc = bytearray(rnd.randbytes(32 * n))
+        for i in range(31, 32 * n, 32):
+            sc[i] &= 0x3F
+        sc = bytes(sc)
+        assert ctx.msm_g2(sc, b2) == ocpp.msm_g2(sc, raw_b2[: 192 * n]), n
+    b2.free()
+
+
+def test_ntt_every_size_round_trip_and_definition(ctx):
+    """Every domain size 2^0 ... 2^22: inverse(forward(x)) == x and coset round trip on device; sizes
+    up to 2^10 also against the C++ oracle."""
+    import torch
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    g = torch.Generator(device="cuda").manual_seed(314)
+    for lg in range(0, 23):
+        n = 1 << lg
+        raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        raw[:, 31] &= 0x3F
+        x = raw.clone()
+        torch.cuda.synchronize()
+        ctx.ntt_dev(x.data_ptr(), lg)
+        if lg <= 10:
+            assert bytes(x.cpu().numpy().tobytes()) == ocpp.ntt(bytes(raw.cpu().numpy().tobytes()), lg), lg
+        ctx.ntt_dev(x.data_ptr(), lg, inverse=True)
+        assert torch.equal(x, raw), lg
+        ctx.ntt_dev(x.data_ptr(), lg, coset=True)
+        ctx.ntt_dev(x.data_ptr(), lg, inverse=True, coset=True)
+        assert torch.equal(x, raw), lg
