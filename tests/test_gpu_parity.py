@@ -876,3 +876,21 @@ def test_ntt_every_size_round_trip_and_definition(ctx):
         ctx.ntt_dev(x.data_ptr(), lg, coset=True)
         ctx.ntt_dev(x.data_ptr(), lg, inverse=True, coset=True)
         assert torch.equal(x, raw), lg
+
+
+@pytest.mark.parametrize("lg", [7, 8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 21])
+def test_groth16_every_domain_size_verifies(ctx, zk, lg):
+    """Setup + prove + pairing-verify at every domain size between the golden 2^7 and 2^21: crosses the
+    one/two/three-pass NTT plans and every shared-bucket digit width (c = log2 n clamped to 6..22)."""
+    r1 = zk.shielder_r1cs(lg)
+    z = zk.shielder_witness(lg, 900 + lg)
+    rng = ec.SplitMix64(70 + lg)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
+    publics = z[32 : 32 * r1.n_pub]
+    assert zk.groth16_verify(vk, publics, proof) is True
+    bad = bytearray(publics)
+    bad[33] ^= 1
+    assert zk.groth16_verify(vk, bytes(bad), proof) is False
+    pk.free()
+    r1.free()
