@@ -10,8 +10,8 @@
 #define CHAINS 8
 #define UNROLL 16
 
-enum Op { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, ADD_U32, ADD_CO_PAIR, ADD3_U32, MAD_U64_DEP, FMA_F32, LSHL_ADD, OP_COUNT };
-static const char* NAMES[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_fma_f64", "v_add_u32", "v_add_co+v_addc_co", "v_add3_u32", "v_mad_u64_u32(dep chain)", "v_fma_f32", "v_lshl_add_u32"};
+enum Op { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, ADD_U32, ADD_CO_PAIR, ADD3_U32, MAD_U64_DEP, FMA_F32, LSHL_ADD, MAD_U64_SGPR, OP_COUNT };
+static const char* NAMES[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_fma_f64", "v_add_u32", "v_add_co+v_addc_co", "v_add3_u32", "v_mad_u64_u32(dep chain)", "v_fma_f32", "v_lshl_add_u32", "v_mad_u64_u32(sgpr multiplicand)"};
 
 template <int OP>
 __global__ void k(uint64_t* out, uint64_t* cyc, int iters, uint32_t seed) {
@@ -34,6 +34,7 @@ __global__ void k(uint64_t* out, uint64_t* cyc, int iters, uint32_t seed) {
         uint64_t carry;
         uint32_t lo = (uint32_t)acc[c], hi = (uint32_t)(acc[c] >> 32);
         if (OP == MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[c]), "=s"(carry) : "v"(a), "v"(b));
+        if (OP == MAD_U64_SGPR) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[c]), "=s"(carry) : "v"(a), "s"(seed));
         if (OP == MAD_U64_DEP) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[0]), "=s"(carry) : "v"(a), "v"(b));
         if (OP == MUL_LO_U32) { asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[c] = lo; }
         if (OP == MUL_HI_U32) { asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[c] = lo; }
@@ -93,7 +94,7 @@ void sweep() { for (int w : {1, 2, 4, 8}) run<OP>(w); }
 
 int main() {
   sweep<ADD_U32>(); sweep<FMA_F32>(); sweep<ADD3_U32>(); sweep<LSHL_ADD>(); sweep<ADD_CO_PAIR>();
-  sweep<MAD_U64_U32>(); sweep<MAD_U64_DEP>(); sweep<MUL_LO_U32>(); sweep<MUL_HI_U32>();
+  sweep<MAD_U64_U32>(); sweep<MAD_U64_SGPR>(); sweep<MAD_U64_DEP>(); sweep<MUL_LO_U32>(); sweep<MUL_HI_U32>();
   sweep<MAD_U32_U24>(); sweep<MUL_HI_U32_U24>(); sweep<FMA_F64>();
   return 0;
 }
