@@ -243,6 +243,15 @@ int32_t zkmi_poseidon_hash_batch_dev(zkmi_ctx* ctx, int32_t field, const void* d
  * d_nodes holds 2^(log_leaves+1) - 1 elements of 32 B; the caller fills the first 2^log_leaves
  * (the leaves); each level is appended behind the previous one, the root is the last element. */
 int32_t zkmi_poseidon_merkle_tree_dev(zkmi_ctx* ctx, int32_t field, void* d_nodes, uint32_t log_leaves);
+/* Merkle paths of n leaves out of that node array: out_shape = n x log_leaves selector bytes
+ * (0: the sibling is the left input, merkle_proof.rs:53-55), out_paths = n x log_leaves x 32 B siblings
+ * (host buffers) = MerkleProof::{path_shape, path} of zkmi_note_update. */
+int32_t zkmi_poseidon_merkle_paths_dev(zkmi_ctx* ctx, const void* d_nodes, uint32_t log_leaves, const uint32_t* leaf_idx,
+                                       uint32_t n, uint8_t* out_shape, uint8_t* out_paths);
+/* n Merkle-path recomputations (the value CircuitMerkleProof::verify compares with the root):
+ * d_leaves n x 32 B, d_shape n x depth bytes, d_paths n x depth x 32 B -> d_roots n x 32 B. */
+int32_t zkmi_poseidon_merkle_roots_dev(zkmi_ctx* ctx, int32_t field, const void* d_leaves, const void* d_shape,
+                                       const void* d_paths, uint32_t depth, uint64_t n, void* d_roots);
 /* Host-executed self-test: the sparse partial-round form the kernels run equals the plain
  * 64-round definition on `iters` random states; *out_mismatches must be 0. */
 int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches);

@@ -894,3 +894,55 @@ def test_groth16_every_domain_size_verifies(ctx, zk, lg):
     assert zk.groth16_verify(vk, bytes(bad), proof) is False
     pk.free()
     r1.free()
+
+
+def test_poseidon_merkle_paths_and_roots_on_device(ctx, zk):
+    """Note tree on the device -> paths of chosen leaves -> (a) the batch root kernel recomputes the
+    tree's root for every path, (b) the oracle agrees, (c) the paths feed the update_note witness
+    generator, whose public merkle_root is then the root of the device-built tree."""
+    import torch
+    from oracle import poseidon as ps
+
+    lg = 10  # TREE_HEIGHT of the relation
+    n = 1 << lg
+    rng = ec.SplitMix64(4711)
+    # leaf 77 is a real old note; the others are arbitrary field elements
+    tok = [rng.fr(), rng.fr()]
+    bal = [500, 9]
+    old_id, ot, on = rng.fr(), rng.fr(), rng.fr()
+    old_acc = ps.hash_fix_len([tok[0], bal[0], tok[1], bal[1]])
+    leaves = [rng.fr() for _ in range(n)]
+    leaves[77] = ps.hash_fix_len([old_id, ot, on, old_acc])
+    nodes = torch.zeros((2 * n - 1, 32), dtype=torch.uint8, device="cuda")
+    nodes[:n] = torch.frombuffer(bytearray(frs(leaves)), dtype=torch.uint8).view(n, 32).cuda()
+    torch.cuda.synchronize()
+    ctx.poseidon_merkle_tree_dev(nodes.data_ptr(), lg)
+    root = int.from_bytes(bytes(nodes[-1].cpu().numpy().tobytes()), "little")
+    idx = [77, 0, 1, 1023, 512, 333]
+    shape, paths = ctx.poseidon_merkle_paths_dev(nodes.data_ptr(), lg, idx)
+    for k, i in enumerate(idx):
+        sh = list(shape[lg * k : lg * (k + 1)])
+        pa = unfrs(paths[32 * lg * k : 32 * lg * (k + 1)])
+        assert sh == [1 - ((i >> lv) & 1) for lv in range(lg)]
+        assert ps.merkle_root(leaves[i], sh, pa) == root
+    d_leaves = torch.frombuffer(bytearray(frs([leaves[i] for i in idx])), dtype=torch.uint8).cuda()
+    d_shape = torch.frombuffer(bytearray(shape), dtype=torch.uint8).cuda()
+    d_paths = torch.frombuffer(bytearray(paths), dtype=torch.uint8).cuda()
+    d_roots = torch.zeros(32 * len(idx), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.poseidon_merkle_roots_dev(d_leaves.data_ptr(), d_shape.data_ptr(), d_paths.data_ptr(), lg, len(idx), d_roots.data_ptr())
+    assert unfrs(bytes(d_roots.cpu().numpy().tobytes())) == [root] * len(idx)
+    # a wrong sibling gives a different root
+    bad = bytearray(paths)
+    bad[5] ^= 1
+    d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    ctx.poseidon_merkle_roots_dev(d_leaves.data_ptr(), d_shape.data_ptr(), d_bad.data_ptr(), lg, len(idx), d_roots.data_ptr())
+    got = unfrs(bytes(d_roots.cpu().numpy().tobytes()))
+    assert got[0] != root and got[1:] == [root] * (len(idx) - 1)
+    # the path of leaf 77 drives the relation's witness generator
+    user, nt, nn, new_id = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    inp = zk.note_update(40, tok[0], user, (new_id, nt, nn), (old_id, ot, on), list(shape[:lg]), unfrs(paths[: 32 * lg]), user,
+                         (tok[0], bal[0], tok[1], bal[1]))
+    _, pub, rc = zk.update_note_witness(14, 1, inp)
+    assert rc == 0 and pub[4] == root

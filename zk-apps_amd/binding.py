@@ -585,6 +585,18 @@ class Context:
     def poseidon_merkle_tree_dev(self, d_nodes, log_leaves, field=0):
         self._chk(self.lib.zkmi_poseidon_merkle_tree_dev(self.h, C.c_int32(field), C.c_void_p(d_nodes), C.c_uint32(log_leaves)))
 
+    def poseidon_merkle_paths_dev(self, d_nodes, log_leaves, leaf_idx):
+        """(shape bytes n x log_leaves, path bytes n x log_leaves x 32) for the given leaf indices."""
+        n = len(leaf_idx)
+        idx = (C.c_uint32 * max(1, n))(*leaf_idx)
+        shape = (C.c_uint8 * max(1, n * log_leaves))()
+        paths = (C.c_uint8 * max(1, 32 * n * log_leaves))()
+        self._chk(self.lib.zkmi_poseidon_merkle_paths_dev(self.h, C.c_void_p(d_nodes), C.c_uint32(log_leaves), idx, C.c_uint32(n), shape, paths))
+        return bytes(shape)[: n * log_leaves], bytes(paths)[: 32 * n * log_leaves]
+
+    def poseidon_merkle_roots_dev(self, d_leaves, d_shape, d_paths, depth, n, d_roots, field=0):
+        self._chk(self.lib.zkmi_poseidon_merkle_roots_dev(self.h, C.c_int32(field), C.c_void_p(d_leaves), C.c_void_p(d_shape), C.c_void_p(d_paths), C.c_uint32(depth), C.c_uint64(n), C.c_void_p(d_roots)))
+
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
         out = (C.c_uint8 * (96 * 64))()
         nwin, cbits = C.c_uint32(), C.c_uint32()

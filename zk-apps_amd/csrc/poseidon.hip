@@ -240,6 +240,55 @@ hipError_t hash_batch(zkmi_ctx* ctx, int field, const void* d_in, uint64_t n, ui
   return hipGetLastError();
 }
 
+// Merkle paths out of a tree laid out level after level (zkmi_poseidon_merkle_tree_dev): thread (i, lv)
+// copies the sibling of leaf idx[i] at level lv and writes the selector bit of merkle_proof.rs:38-61
+// (shape = 0: the sibling is the LEFT input, i.e. the running node is a right child).
+__global__ __launch_bounds__(256) void k_merkle_paths(const uint4* __restrict__ nodes, uint32_t log_leaves,
+                                                      const uint32_t* __restrict__ idx, uint32_t n,
+                                                      uint8_t* __restrict__ shape, uint4* __restrict__ paths) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * log_leaves) return;
+  const uint32_t i = t / log_leaves, lv = t % log_leaves;
+  const uint64_t n_leaves = 1ull << log_leaves;
+  const uint64_t level_off = 2 * n_leaves - (n_leaves >> (lv ? lv - 1 : 0)) * (lv ? 1 : 2);  // sum_{k<lv} n_leaves >> k
+  const uint32_t pos = idx[i] >> lv;
+  const uint64_t node = level_off + (pos ^ 1u);
+  shape[t] = (uint8_t)(1u - (pos & 1u));
+  paths[2 * (uint64_t)t] = nodes[2 * node];
+  paths[2 * (uint64_t)t + 1] = nodes[2 * node + 1];
+}
+
+// roots[i] = CircuitMerkleProof::verify's running node after `depth` levels (merkle_proof.rs:38-61)
+template <class F>
+__global__ __launch_bounds__(256, 3) void k_merkle_roots(const uint32_t* __restrict__ leaves,
+                                                         const uint8_t* __restrict__ shape,
+                                                         const uint32_t* __restrict__ paths, uint32_t depth, uint64_t n,
+                                                         uint32_t* __restrict__ roots,
+                                                         const PoseidonConsts<F>* __restrict__ c) {
+  __shared__ int32_t tile[POS_LDS_WORDS];
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t pair[16];
+  uint32_t cur[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) cur[k] = leaves[8 * i + k];
+#pragma unroll 1
+  for (uint32_t lv = 0; lv < depth; lv++) {
+    const uint32_t* sib = paths + 8 * (i * depth + lv);
+    const bool sibling_left = shape[i * depth + lv] == 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t s = sib[k];
+      pair[k] = sibling_left ? s : cur[k];
+      pair[8 + k] = sibling_left ? cur[k] : s;
+    }
+    const F h = poseidon_hash_words_lds<F>(pair, 2, c, tile + threadIdx.x);
+    h.to_canonical(cur);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) roots[8 * i + k] = cur[k];
+}
+
 hipError_t hash_batch_any(zkmi_ctx* ctx, int field, const void* d_in, uint64_t n, uint32_t arity, void* d_out) {
   return field == ZKMI_FIELD_BLS12_381_FR
              ? hash_batch<Fr28>(ctx, field, d_in, n, arity, d_out, spec<Fr28Params>().consts)
@@ -370,6 +419,59 @@ int32_t zkmi_poseidon_merkle_tree_dev(zkmi_ctx* ctx, int32_t field, void* d_node
     level = next;
   }
   if (ctx->timer()) ctx->timer()->end(PH_WITNESS, ctx->stream);
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+// Paths of n leaves out of the node array of zkmi_poseidon_merkle_tree_dev: out_shape = n x log_leaves
+// selector bytes, out_paths = n x log_leaves x 32 B siblings (host buffers) -- the MerkleProof inputs of
+// zkmi_note_update.
+int32_t zkmi_poseidon_merkle_paths_dev(zkmi_ctx* ctx, const void* d_nodes, uint32_t log_leaves, const uint32_t* leaf_idx,
+                                       uint32_t n, uint8_t* out_shape, uint8_t* out_paths) {
+  ZK_ENTER(ctx);
+  if (!d_nodes || log_leaves == 0 || log_leaves > 30 || (n && (!leaf_idx || !out_shape || !out_paths)))
+    return ZKMI_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++)
+    if (leaf_idx[i] >> log_leaves) return ZKMI_ERR_BAD_ARG;
+  if (n == 0) return ZKMI_OK;
+  const uint64_t cnt = (uint64_t)n * log_leaves;
+  const uint64_t off_shape = ((uint64_t)n * 4 + 255) & ~255ull, off_paths = (off_shape + cnt + 255) & ~255ull;
+  ZK_HIP(ctx, ctx->staging(off_paths + 32 * cnt));
+  uint8_t* d = static_cast<uint8_t*>(ctx->d_tmp);
+  ZK_HIP(ctx, hipMemcpyAsync(d, leaf_idx, (uint64_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_merkle_paths, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const uint4*>(d_nodes), log_leaves, reinterpret_cast<const uint32_t*>(d), n,
+                     d + off_shape, reinterpret_cast<uint4*>(d + off_paths));
+  ZK_HIP(ctx, hipGetLastError());
+  ZK_HIP(ctx, hipMemcpyAsync(out_shape, d + off_shape, cnt, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(out_paths, d + off_paths, 32 * cnt, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKMI_OK;
+}
+
+// Batch of Merkle-path recomputations on the device (what CircuitMerkleProof::verify constrains):
+// d_leaves n x 32 B, d_shape n x depth bytes, d_paths n x depth x 32 B -> d_roots n x 32 B.
+int32_t zkmi_poseidon_merkle_roots_dev(zkmi_ctx* ctx, int32_t field, const void* d_leaves, const void* d_shape,
+                                       const void* d_paths, uint32_t depth, uint64_t n, void* d_roots) {
+  ZK_ENTER(ctx);
+  if (!field_ok(field) || depth > 64 || (n && (!d_leaves || !d_roots || (depth && (!d_shape || !d_paths)))))
+    return ZKMI_ERR_BAD_ARG;
+  if (n == 0) return ZKMI_OK;
+  // make sure the constants are resident (hash_batch uploads them on first use)
+  hipError_t e = hash_batch_any(ctx, field, nullptr, 0, 2, nullptr);
+  if (e != hipSuccess) return ctx->hip_fail(e, "poseidon constants");
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  if (ctx->timer()) ctx->timer()->begin(PH_WITNESS, ctx->stream);
+  if (field == ZKMI_FIELD_BLS12_381_FR)
+    hipLaunchKernelGGL(k_merkle_roots<Fr28>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_leaves),
+                       static_cast<const uint8_t*>(d_shape), static_cast<const uint32_t*>(d_paths), depth, n,
+                       static_cast<uint32_t*>(d_roots), static_cast<const PoseidonConsts<Fr28>*>(ctx->d_pos[field]));
+  else
+    hipLaunchKernelGGL(k_merkle_roots<BnFr28>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(d_leaves),
+                       static_cast<const uint8_t*>(d_shape), static_cast<const uint32_t*>(d_paths), depth, n,
+                       static_cast<uint32_t*>(d_roots), static_cast<const PoseidonConsts<BnFr28>*>(ctx->d_pos[field]));
+  if (ctx->timer()) ctx->timer()->end(PH_WITNESS, ctx->stream);
+  ZK_HIP(ctx, hipGetLastError());
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKMI_OK;
 }
