@@ -333,6 +333,14 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
   const uint64_t mean = (items + buckets - 1) / buckets;
   uint64_t thr = 256;
   while (thr < 8 * mean) thr <<= 1;
+  // Small problems (<= 2^16 buckets) cannot fill the chip, so the accumulation lasts as long as its longest
+  // thread: send everything above three times the mean load to the cooperative kernels.  (n = 2^12, c = 12:
+  // the partial top digit gives one bucket 4 x the mean, 180 points = a 3 ms chain, yet below the old
+  // threshold; twice the mean would flood the cooperative path at c = 13, where 116 buckets carry 2.75 x.)
+  if (buckets <= (1u << 16)) {
+    thr = 3 * mean;
+    if (thr < 48) thr = 48;
+  }
   p.heavy_thr = (uint32_t)thr;
   p.heavy_shift = 0;
   while ((thr >> p.heavy_shift) > 256) p.heavy_shift++;
