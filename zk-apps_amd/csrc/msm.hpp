@@ -49,6 +49,9 @@ struct MsmPlan {
   // workgroups; load ordering uses the key (count >> heavy_shift) <= 256
   uint32_t heavy_thr = 256;
   int heavy_shift = 0;
+  // k_segreduce walks 2^seg_log buckets per thread (a dependent chain of 2 * 2^seg_log additions):
+  // 16 buckets when the chip is full anyway, 4 for small problems whose reduction is pure latency
+  int seg_log = 4;
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);

@@ -35,8 +35,8 @@
 
 namespace zkmi {
 
-constexpr int MSM_SEG = 16;  // buckets per segment in k_segreduce
-constexpr int MSM_SEG_LOG = 4;
+// segment arrays: 16-bucket segments for big plans, down to 1-bucket segments for plans of <= 2^16 buckets
+static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
 constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
@@ -275,13 +275,13 @@ k_heavy_combine(const uint32_t* __restrict__ heavy, const XYZZ<F>* __restrict__ 
 template <class F>
 __global__ void __launch_bounds__(256)
 k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, XYZZ<F>* __restrict__ segw,
-            uint32_t total_segs) {
+            uint32_t total_segs, int seg) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_segs) return;
   XYZZ<F> run = XYZZ<F>::infinity();
   XYZZ<F> acc = XYZZ<F>::infinity();
-  for (int i = MSM_SEG - 1; i >= 0; i--) {
-    XYZZ<F> bk = load_vec(buckets + (size_t)t * MSM_SEG + i);
+  for (int i = seg - 1; i >= 0; i--) {
+    XYZZ<F> bk = load_vec(buckets + (size_t)t * seg + i);
     run.add(bk);
     acc.add(run);
   }
@@ -310,14 +310,14 @@ __device__ __forceinline__ void st_xyzz_split(XYZZ<Fq2_28>* p, const XYZZ<Fq2P>&
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(256, 2)
 k_segreduce_g2_split(const XYZZ<Fq2_28>* __restrict__ buckets, XYZZ<Fq2_28>* __restrict__ segsum,
-                     XYZZ<Fq2_28>* __restrict__ segw, uint32_t total_segs) {
+                     XYZZ<Fq2_28>* __restrict__ segw, uint32_t total_segs, int seg) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = gt >> 1, comp = gt & 1u;
   if (t >= total_segs) return;  // pair-uniform
   XYZZ<Fq2P> run = XYZZ<Fq2P>::infinity();
   XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-  for (int i = MSM_SEG - 1; i >= 0; i--) {
-    XYZZ<Fq2P> bk = ld_xyzz_split(buckets + (size_t)t * MSM_SEG + i, comp);
+  for (int i = seg - 1; i >= 0; i--) {
+    XYZZ<Fq2P> bk = ld_xyzz_split(buckets + (size_t)t * seg + i, comp);
     run.add(bk);
     acc.add(run);
   }
@@ -410,8 +410,8 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   release();
   hipError_t e;
   if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need * SLOTS)) != hipSuccess) return e;
-  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
-  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * (need / MSM_SEG + 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
+  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT)) != hipSuccess) return e;
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
@@ -424,7 +424,7 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
 }
 
 static inline int msm_seg_bits(const MsmPlan& pl) {
-  const uint32_t segs_per_win = pl.nb / MSM_SEG;
+  const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   int seg_bits = 0;
   while ((1u << seg_bits) < segs_per_win) seg_bits++;
   return seg_bits;
@@ -462,13 +462,14 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
   if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
   if (prof) prof->begin(ph_reduce, st_reduce);
-  const uint32_t segs_per_win = pl.nb / MSM_SEG;
+  const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
+  const int seg = 1 << pl.seg_log;
   if constexpr (std::is_same<F, Fq2_28>::value) {
     hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw,
-                       tot_segs);
+                       tot_segs, seg);
   } else {
-    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs);
+    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs, seg);
   }
   const int plain_job = pl.shared ? 1 + msm_seg_bits(pl) : -1;
   const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
@@ -497,7 +498,7 @@ hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
       u.dbl_inplace();
       u.add(h[(size_t)w * njobs + 1 + j]);
     }
-    for (int i = 0; i < MSM_SEG_LOG; i++) u.dbl_inplace();
+    for (int i = 0; i < pl.seg_log; i++) u.dbl_inplace();
     u.add(h[(size_t)w * njobs]);
     out_windows[w] = u;
   }

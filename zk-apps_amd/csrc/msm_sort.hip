@@ -341,6 +341,8 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
     thr = 3 * mean;
     if (thr < 48) thr = 48;
   }
+  p.seg_log = buckets <= (1u << 13) ? 2 : 4;  // 4-bucket segments only where the reduction is pure latency
+  if ((1u << p.seg_log) > p.nb) p.seg_log = 0;
   p.heavy_thr = (uint32_t)thr;
   p.heavy_shift = 0;
   while ((thr >> p.heavy_shift) > 256) p.heavy_shift++;
