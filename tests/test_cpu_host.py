@@ -412,3 +412,30 @@ def test_update_note_witness_matches_golden_publics(zk):
         rc_, mds = zk.poseidon_spec(field)
         flat = b"".join(v.to_bytes(32, "little") for row in rc_ for v in row) + b"".join(v.to_bytes(32, "little") for row in mds for v in row)
         assert hashlib.sha256(flat).hexdigest() == golden("poseidon.json")[name]["constants_sha256"]
+
+
+def _build_c_example(tmp_path):
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "prove_withdraw")
+    lib_dir = os.path.join(root, "zk-apps_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "prove_withdraw.c"), "-L" + lib_dir, "-lzkmi",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_c_example_builds_against_the_header_and_fails_loudly_without_gpu(tmp_path):
+    """include/zkmi.h is plain C: examples/prove_withdraw.c compiles with gcc -Wall -Werror and links
+    libzkmi.so; on a machine without a GPU it stops at zkmi_ctx_create (no CPU fallback)."""
+    import subprocess
+
+    import torch
+
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the GPU test")
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "no CPU fallback" in p.stderr

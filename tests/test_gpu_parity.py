@@ -946,3 +946,17 @@ def test_poseidon_merkle_paths_and_roots_on_device(ctx, zk):
                          (tok[0], bal[0], tok[1], bal[1]))
     _, pub, rc = zk.update_note_witness(14, 1, inp)
     assert rc == 0 and pub[4] == root
+
+
+def test_c_example_proves_and_verifies(tmp_path):
+    """examples/prove_withdraw.c (plain C against include/zkmi.h) on the GPU: proof verified, tampered
+    public input rejected, impossible update reported with the mock's error code."""
+    import subprocess
+
+    from test_cpu_host import _build_c_example
+
+    p = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "proof of the withdraw: verified" in p.stdout
+    assert "amount tampered: rejected" in p.stdout
+    assert "-> -6 (ZKMI_ERR_ACCOUNT_UPDATE = -6)" in p.stdout
