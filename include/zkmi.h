@@ -92,6 +92,8 @@ int32_t zkmi_bases_g2_free(zkmi_bases_g2* b);
  * (SURVEY.md §8d).  Used by bench.py and the large-size property tests. */
 int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out);
 int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out);
+/* the slice P_first .. P_{first+n-1} of the same sequence (a rank's share of a point-split MSM) */
+int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n, zkmi_bases_g1** out);
 int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out_affine);
 int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first, uint64_t count, uint8_t* out_affine);
 
@@ -135,6 +137,9 @@ int32_t zkmi_g1_mul(const uint8_t affine[96], const uint8_t scalar[32], uint8_t 
 int32_t zkmi_g2_mul(const uint8_t affine[192], const uint8_t scalar[32], uint8_t out_affine[192]);
 int32_t zkmi_g1_add(const uint8_t a[96], const uint8_t b[96], uint8_t out_affine[96]);
 int32_t zkmi_g2_add(const uint8_t a[192], const uint8_t b[192], uint8_t out_affine[192]);
+/* [r]P = O (points on the curve but outside the prime-order subgroup exist on both curves) */
+int32_t zkmi_g1_in_subgroup(const uint8_t affine[96]);   /* ZKMI_OK / ZKMI_ERR_NON_CANONICAL */
+int32_t zkmi_g2_in_subgroup(const uint8_t affine[192]);
 int32_t zkmi_g1_generator(uint8_t out_affine[96]);
 int32_t zkmi_g2_generator(uint8_t out_affine[192]);
 /* reduced optimal-ate pairing e(P,Q) as 12 x 48-byte LE Fq coefficients in the
@@ -262,21 +267,27 @@ int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uin
  * and update_account_circuit (update_account.rs:68-95) over the concrete account the
  * mock defines (two (token, balance) slots, u128 balances; mocked_zk/src/account.rs),
  * arithmetised as R1CS with Poseidon-5 and padded with the multiplication chain to
- * constraints + publics = 2^log_n, variables = 2^log_n (log_n >= 14).
+ * constraints + publics = 2^log_n, variables = 2^log_n (log_n >= 13).
  * Public inputs, in the order update_note.rs:121,127 fixes:
  *   amount, token, user, new_note_hash, merkle_root, old_note.nullifier. */
 #define ZKMI_OP_DEPOSIT 0
 #define ZKMI_OP_WITHDRAW 1
+#define ZKMI_MAX_TREE_HEIGHT 32
 typedef struct {
   zkmi_fr amount, token, user;   /* op_pub                                          */
   zkmi_fr new_note[3];           /* zk_id, trapdoor, nullifier (account_hash derived) */
   zkmi_fr old_note[3];           /* zk_id, trapdoor, nullifier                      */
-  uint8_t path_shape[10];        /* MerkleProof::path_shape                         */
-  zkmi_fr path[10];              /* MerkleProof::path                               */
+  /* TREE_HEIGHT is a const generic of the reference (merkle_proof.rs:11); here a run-time field:
+   * the first tree_height entries of path_shape / path are used.  0 = ZKMI_MERKLE_TREE_DEPTH (10). */
+  uint32_t tree_height;
+  uint8_t path_shape[ZKMI_MAX_TREE_HEIGHT]; /* MerkleProof::path_shape              */
+  zkmi_fr path[ZKMI_MAX_TREE_HEIGHT];       /* MerkleProof::path                    */
   zkmi_fr op_priv_user;          /* op_priv                                         */
   zkmi_fr account[4];            /* old account: token_0, balance_0, token_1, balance_1 */
 } zkmi_note_update;
-int32_t zkmi_update_note_r1cs(uint32_t log_n, int32_t op_kind, zkmi_r1cs** out);
+/* log_n >= 13 (the relation proper has ~5.7 k constraints at height 10); tree_height 1..32 */
+int32_t zkmi_update_note_r1cs(uint32_t log_n, int32_t op_kind, zkmi_r1cs** out); /* height 10 */
+int32_t zkmi_update_note_r1cs_h(uint32_t log_n, int32_t op_kind, uint32_t tree_height, zkmi_r1cs** out);
 /* Full assignment (2^log_n x 32 B) from the semantic inputs; the note/account hashes, the
  * Merkle root and every S-box intermediate are computed here.  out_publics (optional)
  * receives the 6 public inputs.  Returns ZKMI_ERR_ACCOUNT_UPDATE / ZKMI_ERR_OPERATION_COMBINE
@@ -309,6 +320,7 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t alpha_g
                      const uint8_t* a_query, const uint8_t* b_g1_query, const uint8_t* b_g2_query,
                      const uint8_t* h_query, const uint8_t* l_query, zkmi_pk** out_pk);
 int32_t zkmi_pk_free(zkmi_pk* pk);
+int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint32_t* log_n);
 /* export one query of a resident key (0=a,1=b_g1,2=b_g2,3=h,4=l) in wire format */
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count, uint8_t* out);
 /* witness -> proof.  z = full assignment (n_vars x 32 B, z[0] = 1); r, s =
@@ -316,8 +328,9 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
  * Replaces ark_groth16::prover::create_proof_with_assignment [not in tree]. */
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r[32], const uint8_t s[32],
                            uint8_t out_proof[192]);
-/* same with the witness already resident in HBM (n_vars x 32 B canonical LE;
- * elements are trusted to be < r) — the entry point bench.py times. */
+/* same with the witness already resident in HBM (n_vars x 32 B canonical LE) — the entry point bench.py
+ * times.  Every prove entry point checks on the device that the elements are < r, that z[0] = 1 and that
+ * the assignment satisfies the relation (ZKMI_ERR_NON_CANONICAL / ZKMI_ERR_UNSATISFIED). */
 int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z, const uint8_t r[32], const uint8_t s[32],
                                uint8_t out_proof[192]);
 /* Batch of n_proofs independent proofs over one resident key (BASELINE config 2):
@@ -325,9 +338,17 @@ int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z
  * Two proofs are kept in flight (GPU works on proof i+1 while the CPU finishes proof i). */
 int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
                                      const uint8_t* r, const uint8_t* s, uint8_t* out_proofs);
+/* The same pipeline over HOST witnesses (z[i] = n_vars x 32 B): witness i+1 is uploaded on a copy stream
+ * while earlier proofs compute.  Pin the buffers for a truly asynchronous copy.  Elements >= r are
+ * detected on the device (ZKMI_ERR_NON_CANONICAL). */
+int32_t zkmi_groth16_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const uint8_t* const* z,
+                                 const uint8_t* r, const uint8_t* s, uint8_t* out_proofs);
 /* h-polynomial coefficients only (row a7), N x 32 B canonical LE */
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h);
-/* row a11: pairing check on the host CPU.  publics excludes the leading 1. */
+/* row a11: pairing check on the host CPU.  publics excludes the leading 1.
+ * Validating, like arkworks' / zcash's deserialisation: proof points must be canonical compressed
+ * encodings (one encoding of infinity) of points in the r-order subgroups, and so must the vk's points;
+ * anything else returns ZKMI_ERR_NON_CANONICAL, a failed pairing equation ZKMI_ERR_VERIFICATION. */
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]);
 
 /* ---- row a12: the reference's prove/verify surface ------------------------ */
@@ -363,6 +384,45 @@ int32_t zkmi_zkproof_verify_creation(const zkmi_zkproof* self, const zkmi_scalar
                                      const zkmi_scalar tokens[ZKMI_TOKENS_NUMBER]);       /* relations.rs:127-136 */
 int32_t zkmi_zkproof_verify_update(const zkmi_zkproof* self, const zkmi_op_pub* op_pub, const zkmi_scalar* h_note_new,
                                    const zkmi_scalar* merkle_root, const zkmi_scalar* nullifier_old); /* relations.rs:138-155 */
+
+
+/* ---- the same surface with REAL proofs --------------------------------------- *
+ * The mock's "proof" is the witness; these entry points produce / check a Groth16 proof of the
+ * Poseidon relations instead.  Scalars are arbitrary 32-byte strings in the mock; the relations
+ * work over Fr, so every Scalar enters as its value mod r (zkmi_fr_reduce) and `amount` as its
+ * u128 value.  h_note_new / merkle_root are Poseidon outputs (canonical Fr) produced by the prover.
+ *
+ * Creation relation = what verify_creation stands for (relations.rs:127-136, contract/lib.rs:50-58):
+ * verify_account_circuit (update_account.rs:52-65) on Account::new(tokens) (account.rs:27-34) +
+ * verify_note_circuit (update_note.rs:91-103).  Publics: h_note_new, token_0, token_1. */
+typedef struct {
+  zkmi_fr tokens[ZKMI_TOKENS_NUMBER];
+  zkmi_fr note[3]; /* zk_id, trapdoor, nullifier */
+} zkmi_note_create;
+int32_t zkmi_create_note_r1cs(uint32_t log_n, zkmi_r1cs** out); /* log_n >= 11 */
+int32_t zkmi_create_note_witness(uint32_t log_n, const zkmi_note_create* in, uint8_t* out_z, uint8_t* out_publics /* 3 x 32 B */);
+/* ZkProof::new (relations.rs:37-55) + a proof that verify_creation's statement holds */
+int32_t zkmi_shielder_prove_creation(zkmi_ctx* ctx, const zkmi_pk* pk_create, const zkmi_zkproof* knowledge,
+                                     const zkmi_scalar tokens[ZKMI_TOKENS_NUMBER], const uint8_t r[32], const uint8_t s[32],
+                                     zkmi_scalar* out_h_note_new, uint8_t out_proof[192]);
+/* verify_creation (relations.rs:127-136): ZKMI_OK or ZKMI_ERR_VERIFICATION */
+int32_t zkmi_shielder_verify_creation(const uint8_t* vk_create, const zkmi_scalar* h_note_new,
+                                      const zkmi_scalar tokens[ZKMI_TOKENS_NUMBER], const uint8_t proof[192]);
+/* ZkProof::update_account (relations.rs:79-98): same arguments (merkle_proof = tree_height siblings,
+ * leaf first; leaf_id), same error codes (ZKMI_ERR_OPERATION_COMBINE / ZKMI_ERR_ACCOUNT_UPDATE), returns
+ * (h_note_new, new ZkProof) plus the recomputed Merkle root and the 192-byte proof.  The key is picked by
+ * op_pub->kind (one circuit per operation kind: deposit adds, withdraw subtracts). */
+int32_t zkmi_shielder_prove_update(zkmi_ctx* ctx, const zkmi_pk* pk_deposit, const zkmi_pk* pk_withdraw,
+                                   const zkmi_zkproof* self, const zkmi_op_pub* op_pub, const zkmi_op_priv* op_priv,
+                                   const zkmi_scalar* trapdoor, const zkmi_scalar* nullifier,
+                                   const zkmi_scalar* merkle_proof, uint32_t tree_height, uint32_t leaf_id,
+                                   const uint8_t r[32], const uint8_t s[32], zkmi_scalar* out_h_note_new,
+                                   zkmi_scalar* out_merkle_root, zkmi_zkproof* out_new, uint8_t out_proof[192]);
+/* verify_update (relations.rs:138-155, called at contract/lib.rs:74): OpPub -> publics
+ * (amount, token, user | h_note_new | merkle_root | nullifier_old: ops.rs:6-25, update_note.rs:121,127) */
+int32_t zkmi_shielder_verify_update(const uint8_t* vk_deposit, const uint8_t* vk_withdraw, const zkmi_op_pub* op_pub,
+                                    const zkmi_scalar* h_note_new, const zkmi_scalar* merkle_root,
+                                    const zkmi_scalar* nullifier_old, const uint8_t proof[192]);
 
 #ifdef __cplusplus
 }

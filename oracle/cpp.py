@@ -85,3 +85,26 @@ def groth16_prove(n_vars, n_pub, nc, log_n, mats, pk, z, r, s, nthreads=0):
         C.c_uint32(n_vars), C.c_uint32(n_pub), C.c_uint32(nc), C.c_uint32(log_n), rp, cl, vl, *bufs, _buf(z), _buf(r), _buf(s), out, C.c_int(nthreads)
     )
     return bytes(out)
+
+
+def groth16_setup(n_vars, n_pub, nc, log_n, mats, toxic, nthreads=0):
+    """Trusted setup with explicit toxic waste on the CPU.  Returns (vk bytes, key dict in the wire
+    format groth16_prove takes)."""
+    rp, cl, vl, keep = _csr_args(mats)
+    N = 1 << log_n
+    vk = (C.c_uint8 * (672 + 96 * n_pub))()
+    beta_g1, delta_g1 = (C.c_uint8 * 96)(), (C.c_uint8 * 96)()
+    a, b1, b2 = (C.c_uint8 * (96 * n_vars))(), (C.c_uint8 * (96 * n_vars))(), (C.c_uint8 * (192 * n_vars))()
+    h, l = (C.c_uint8 * (96 * (N - 1)))(), (C.c_uint8 * (96 * (n_vars - n_pub)))()
+    rc = lib().oracle_groth16_setup(
+        C.c_uint32(n_vars), C.c_uint32(n_pub), C.c_uint32(nc), C.c_uint32(log_n), rp, cl, vl, _buf(toxic), vk, beta_g1, delta_g1,
+        a, b1, b2, h, l, C.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("tau lies in the evaluation domain")
+    vkb = bytes(vk)
+    key = {
+        "alpha_g1": vkb[:96], "beta_g1": bytes(beta_g1), "beta_g2": vkb[96:288], "delta_g1": bytes(delta_g1),
+        "delta_g2": vkb[480:672], "a_query": bytes(a), "b_g1_query": bytes(b1), "b_g2_query": bytes(b2),
+        "h_query": bytes(h), "l_query": bytes(l),
+    }
+    return vkb, key

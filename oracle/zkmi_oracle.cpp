@@ -447,3 +447,113 @@ int oracle_groth16_prove(uint32_t n_vars, uint32_t n_pub, uint32_t nc, uint32_t 
 }
 
 }  // extern "C"
+
+// Trusted setup with explicit toxic waste (tau, alpha, beta, gamma, delta), shaped after
+// ark_groth16 0.4 generator::generate_parameters_with_qap + LibsnarkReduction::
+// instance_map_with_evaluation [not in the reference tree]: u = Lagrange coefficients of the domain
+// at tau; a/b/c[col] += u[row] * coeff over the constraint rows; a[i] += u[nc + i] for the instance
+// columns; gamma_abc_i = (beta a_i + alpha b_i + c_i) / gamma, l_i = the same / delta,
+// h_i = tau^i * Z(tau) / delta for i < N - 1; every query entry = scalar * generator.
+// Deliberately different from the product's setup: Lagrange coefficients by the barycentric
+// recurrence with one inversion per element batch, 64-bit limbs, Jacobian fixed-base tables.
+template <class F>
+struct FixedBase {
+  std::vector<Jac<F>> t;  // t[w * 256 + d] = d * 2^(8 w) * G
+  explicit FixedBase(const Jac<F>& g) : t(32 * 256) {
+    Jac<F> base = g;
+    for (int w = 0; w < 32; w++) {
+      t[w * 256] = Jac<F>::inf();
+      for (int d = 1; d < 256; d++) t[w * 256 + d] = t[w * 256 + d - 1].add(base);
+      for (int k = 0; k < 8; k++) base = base.dbl();
+    }
+  }
+  Jac<F> mul(const Fr& s) const {
+    uint8_t b[32];
+    s.to_bytes(b);
+    Jac<F> acc = Jac<F>::inf();
+    for (int w = 0; w < 32; w++)
+      if (b[w]) acc = acc.add(t[w * 256 + b[w]]);
+    return acc;
+  }
+};
+
+static Jac<Fq> g1_gen() {
+  static const uint64_t X[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull, 0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+  static const uint64_t Y[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull, 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+  Fq x, y; memcpy(x.l, X, 48); memcpy(y.l, Y, 48);
+  return {x.to_mont(), y.to_mont(), Fq::one()};
+}
+static Jac<Fq2> g2_gen() {
+  static const uint64_t X0[6] = {0xd48056c8c121bdb8ull, 0x0bac0326a805bbefull, 0xb4510b647ae3d177ull, 0xc6e47ad4fa403b02ull, 0x260805272dc51051ull, 0x024aa2b2f08f0a91ull};
+  static const uint64_t X1[6] = {0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5da61bbdc7f5049ull, 0x596bd0d09920b61aull, 0x7dacd3a088274f65ull, 0x13e02b6052719f60ull};
+  static const uint64_t Y0[6] = {0xe193548608b82801ull, 0x923ac9cc3baca289ull, 0x6d429a695160d12cull, 0xadfd9baa8cbdd3a7ull, 0x8cc9cdc6da2e351aull, 0x0ce5d527727d6e11ull};
+  static const uint64_t Y1[6] = {0xaaa9075ff05f79beull, 0x3f370d275cec1da1ull, 0x267492ab572e99abull, 0xcb3e287e85a763afull, 0x32acd2b02bc28b99ull, 0x0606c4a02ea734ccull};
+  Fq2 x, y;
+  memcpy(x.c0.l, X0, 48); memcpy(x.c1.l, X1, 48); memcpy(y.c0.l, Y0, 48); memcpy(y.c1.l, Y1, 48);
+  return {{x.c0.to_mont(), x.c1.to_mont()}, {y.c0.to_mont(), y.c1.to_mont()}, Fq2::one()};
+}
+
+extern "C" int oracle_groth16_setup(uint32_t n_vars, uint32_t n_pub, uint32_t nc, uint32_t log_n,
+                                    const uint32_t* const rowptr[3], const uint32_t* const col[3],
+                                    const uint8_t* const val[3], const uint8_t toxic[160], uint8_t* out_vk,
+                                    uint8_t out_beta_g1[96], uint8_t out_delta_g1[96], uint8_t* out_a, uint8_t* out_b1,
+                                    uint8_t* out_b2, uint8_t* out_h, uint8_t* out_l, int threads) {
+  if (threads <= 0) threads = n_threads();
+  const size_t N = size_t(1) << log_n;
+  const Fr tau = Fr::from_bytes(toxic), alpha = Fr::from_bytes(toxic + 32), beta = Fr::from_bytes(toxic + 64),
+           gamma = Fr::from_bytes(toxic + 96), delta = Fr::from_bytes(toxic + 128);
+  // u_i = L_i(tau) = Z(tau) / N * w^i / (tau - w^i)  (ark_poly evaluate_all_lagrange_coefficients)
+  Fr tn = tau;
+  for (uint32_t i = 0; i < log_n; i++) tn = tn.sqr();
+  const Fr zt = tn - Fr::one();
+  if (zt.is_zero()) return -1;
+  const Fr w = root_of_unity((int)log_n);
+  std::vector<Fr> u(N), wi(N);
+  {
+    Fr x = Fr::one();
+    for (size_t i = 0; i < N; i++) { wi[i] = x; x = x * w; }
+    const Fr scale = zt * Fr::from_u64(N).inv();
+    parallel_for((size_t)threads, threads, [&](size_t t) {
+      // chunked batch inversion of (tau - w^i)
+      const size_t chunk = (N + threads - 1) / threads, b = t * chunk, e = std::min(N, b + chunk);
+      if (b >= e) return;
+      std::vector<Fr> pre(e - b);
+      Fr run = Fr::one();
+      for (size_t i = b; i < e; i++) { pre[i - b] = run; run = run * (tau - wi[i]); }
+      Fr inv = run.inv();
+      for (size_t i = e; i-- > b;) { u[i] = inv * pre[i - b] * wi[i] * scale; inv = inv * (tau - wi[i]); }
+    });
+  }
+  std::vector<Fr> abc[3];
+  for (int m = 0; m < 3; m++) {
+    abc[m].assign(n_vars, Fr::zero());
+    for (uint32_t i = 0; i < nc; i++)
+      for (uint32_t k = rowptr[m][i]; k < rowptr[m][i + 1]; k++)
+        abc[m][col[m][k]] = abc[m][col[m][k]] + u[i] * Fr::from_bytes(val[m] + 32ull * k);
+  }
+  for (uint32_t j = 0; j < n_pub; j++) abc[0][j] = abc[0][j] + u[nc + j];
+  const Fr ginv = gamma.inv(), dinv = delta.inv();
+  std::vector<Fr> lq(n_vars), hq(N - 1);
+  for (uint32_t j = 0; j < n_vars; j++) lq[j] = (beta * abc[0][j] + alpha * abc[1][j] + abc[2][j]) * (j < n_pub ? ginv : dinv);
+  {
+    Fr t = zt * dinv;
+    for (size_t i = 0; i + 1 < N; i++) { hq[i] = t; t = t * tau; }
+  }
+  const FixedBase<Fq> t1(g1_gen());
+  const FixedBase<Fq2> t2(g2_gen());
+  parallel_for((size_t)n_vars, threads, [&](size_t j) {
+    write_affine<Fq>(t1.mul(abc[0][j]), out_a + 96 * j);
+    write_affine<Fq>(t1.mul(abc[1][j]), out_b1 + 96 * j);
+    write_affine<Fq2>(t2.mul(abc[1][j]), out_b2 + 192 * j);
+    if (j >= n_pub) write_affine<Fq>(t1.mul(lq[j]), out_l + 96 * (j - n_pub));
+  });
+  parallel_for(N - 1, threads, [&](size_t i) { write_affine<Fq>(t1.mul(hq[i]), out_h + 96 * i); });
+  write_affine<Fq>(t1.mul(alpha), out_vk);
+  write_affine<Fq2>(t2.mul(beta), out_vk + 96);
+  write_affine<Fq2>(t2.mul(gamma), out_vk + 288);
+  write_affine<Fq2>(t2.mul(delta), out_vk + 480);
+  for (uint32_t j = 0; j < n_pub; j++) write_affine<Fq>(t1.mul(lq[j]), out_vk + 672 + 96ull * j);
+  write_affine<Fq>(t1.mul(beta), out_beta_g1);
+  write_affine<Fq>(t1.mul(delta), out_delta_g1);
+  return 0;
+}

@@ -1,6 +1,7 @@
 """Summarise rocprofv3 --pmc passes (counter_collection.csv files) into one JSON: per kernel, the
-average counter value per dispatch.  Usage: python scripts/pmc_summary.py OUT.json DIR [DIR ...]
-(each DIR is the -d directory of one rocprofv3 --pmc pass)."""
+average counter value per dispatch.  Usage: python scripts/pmc_summary.py OUT.json PROOFS DIR [DIR ...]
+(each DIR is the -d directory of one rocprofv3 --pmc pass; PROOFS = warm-up + timed proofs each pass ran,
+recorded in a "__meta__" row so that per-proof totals can be derived)."""
 import collections
 import csv
 import glob
@@ -19,7 +20,7 @@ def short(name):
 
 
 def main():
-    out_path, dirs = sys.argv[1], sys.argv[2:]
+    out_path, proofs, dirs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for path in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
@@ -40,6 +41,7 @@ def main():
             row[c + "_dispatches"] = len(vals)
         rows.append(row)
     rows.sort(key=lambda r: -r.get("SQ_INSTS_VALU_avg_per_dispatch", 0) * r.get("SQ_INSTS_VALU_dispatches", 0))
+    rows.insert(0, {"kernel": "__meta__", "proofs": proofs, "passes": dirs})
     json.dump(rows, open(out_path, "w"), indent=1)
     print("wrote", out_path, len(rows), "kernels")
 

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Regenerates every file under profiles/<round>/ in one command, on the GPU box, from the repo root:
+#
+#     bash scripts/profile.sh r02            # -> gpurun_out/prof_r02/{trace,pmc_*}/..., summaries in profiles/r02/
+#
+# rocprofv3 is always given the program itself after `--` (python3 bench.py ...), tracing and counter
+# collection are separate runs, and the counters are split over passes that fit the hardware slots
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass: /opt/skills/guides/MI355X_MICROARCH.md, PMC slots).
+set -u
+ROUND=${1:-r02}
+OUT=gpurun_out/prof_$ROUND
+DST=profiles/$ROUND
+STEPS_TRACE=${STEPS_TRACE:-8}
+STEPS_PMC=${STEPS_PMC:-3}
+mkdir -p "$OUT" "$DST"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --warmup 1 --no-cpu-baseline --no-secondary --pmc-summary none"
+
+# 1. kernel trace + per-kernel statistics (durations of kernels on different streams overlap)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps "$STEPS_TRACE" > "$OUT/trace.log" 2>&1
+# 2. counters, one pass each
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_icache" -- $BENCH --steps "$STEPS_PMC" \
+  > "$OUT/pmc_icache.log" 2>&1
+
+# 3. summaries that are small enough to commit
+STATS=$(find "$OUT/trace" -name '*_kernel_stats.csv' | head -1)
+TRACE=$(find "$OUT/trace" -name '*_kernel_trace.csv' | head -1)
+[ -n "$STATS" ] && cp "$STATS" "$DST/kernel_stats_bench_steps${STEPS_TRACE}.csv"
+[ -n "$TRACE" ] && python3 scripts/trace_timeline.py "$TRACE" "$DST/timeline_bench_steps${STEPS_TRACE}.txt"
+python3 scripts/pmc_summary.py "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" $((STEPS_PMC + 1)) "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_icache"
+grep -h '^{' "$OUT/trace.log" | tail -1 > "$DST/bench_line_under_trace.json"
+ls -la "$DST"

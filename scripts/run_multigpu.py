@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Multi-GPU legs of BASELINE.json, one process per GPU over RCCL:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        scripts/run_multigpu.py [--config 2|3|both] [--log-n 20] [--proofs 64] [--msm-log-n 26]
+
+config 2  `--proofs` independent withdraw proofs at N = 2^log_n, sharded over the ranks with
+          parallel.shard_units (no data-path collective); every proof is checked by the pairing verifier,
+          the ranks all-gather their 192-byte proofs so that rank 0 holds the whole batch.
+config 3  one G1 MSM of 2^msm_log_n points split by points: each rank generates its slice of the synthetic
+          bases and scalars in HBM, runs the bucket method, and the ranks exchange the per-window partial sums
+          (parallel.msm_g1_split_dev: RCCL all-gather of nwin x 96 B + local combine); the result must equal
+          the closed form sum_i s_i (G + i Q) = [sum s_i] G + [sum i s_i] Q on every rank.
+
+Rank 0 prints one JSON line per config.  Also runs with world size 1 (plain `python scripts/run_multigpu.py`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="both", choices=["2", "3", "both"])
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--proofs", type=int, default=64)
+    ap.add_argument("--msm-log-n", type=int, default=26)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if "MASTER_ADDR" not in os.environ:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from zkmi_loader import load_pkg
+    from bench import SplitMix64, relation_and_witness
+
+    pkg = load_pkg()
+    par = __import__("zk_apps_amd.parallel", fromlist=["x"])
+    z = pkg.Zkmi()
+    ctx = z.context(local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    if args.config in ("2", "both"):
+        lo, hi = par.shard_units(args.proofs, rank, world)
+        # same key on every rank (replicated: 13 GB of 288 GB at 2^20), distinct witnesses per proof
+        r1, wits = relation_and_witness(z, "poseidon", args.log_n, [0x5A4B2000 + i for i in range(lo, min(hi, lo + 2))])
+        rng = SplitMix64(0x5A4B0001)
+        pk, vk = ctx.groth16_setup(r1, b"".join(rng.fr_bytes() for _ in range(5)))
+        d_wits = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
+        prng = SplitMix64(0x5A4B3000 + rank)
+        rs = [prng.fr_bytes() for _ in range(hi - lo)]
+        ss = [prng.fr_bytes() for _ in range(hi - lo)]
+        barrier()
+        t0 = time.perf_counter()
+        proofs = ctx.groth16_prove_batch_dev(pk, [d_wits[i % len(d_wits)].data_ptr() for i in range(hi - lo)], rs, ss) if hi > lo else []
+        ctx.sync()
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        ok = all(z.groth16_verify(vk, wits[i % len(wits)][32 : 32 * r1.n_pub], p) for i, p in enumerate(proofs))
+        # every rank proves the same number of proofs when world divides --proofs; pad for the gather otherwise
+        per = (args.proofs + world - 1) // world
+        blob = b"".join(proofs) + bytes(192 * (per - len(proofs)))
+        gathered = par.allgather_bytes(blob)
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            n_got = sum(1 for g in gathered for k in range(per) if any(g[192 * k : 192 * k + 192]))
+            print(json.dumps({"config": 2, "workload": "%d independent withdraw proofs at N=2^%d over %d GPU(s)" % (args.proofs, args.log_n, world),
+                              "proofs": args.proofs, "proofs_gathered": n_got, "all_verified": bool(okt.item()),
+                              "seconds": float(dt.item()), "proofs_per_s": args.proofs / float(dt.item()), "n_gpus": world}), flush=True)
+        assert okt.item() == 1
+        pk.free()
+        r1.free()
+        del d_wits
+        torch.cuda.empty_cache()
+
+    if args.config in ("3", "both"):
+        n = 1 << args.msm_log_n
+        a, b = par.shard_units(n, rank, world)
+        m = b - a
+        g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+        raw = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device="cuda", generator=g)
+        raw[:, 31] &= 0x3F
+        # closed form needs sum s_i and sum i s_i over the GLOBAL index i = a + j
+        assert args.msm_log_n <= 27  # 255 * i summed over 2^27 terms stays below 2^63
+        idx = torch.arange(a, b, dtype=torch.int64, device="cuda")
+        s0 = raw.to(torch.int64).sum(dim=0)
+        s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0)
+        sums = torch.stack([s0, s1]).contiguous()
+        allsums = [torch.empty_like(sums) for _ in range(world)]
+        dist.all_gather(allsums, sums)
+        tot = wtot = 0
+        for t in allsums:
+            v = t.cpu().tolist()
+            tot += sum(x << (8 * k) for k, x in enumerate(v[0]))
+            wtot += sum(x << (8 * k) for k, x in enumerate(v[1]))
+        tot %= R
+        wtot %= R
+        bases = ctx.bases_g1_synthetic_range(a, m)
+        barrier()
+        t0 = time.perf_counter()
+        got = par.msm_g1_split_dev(z, ctx, raw.data_ptr(), m, bases, n)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        G = z.g1_generator()
+        Q = z.g1_mul(G, (0xC0FFEE).to_bytes(32, "little"))
+        want = z.g1_add(z.g1_mul(G, tot.to_bytes(32, "little")), z.g1_mul(Q, wtot.to_bytes(32, "little")))
+        okt = torch.tensor([1 if got == want else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            print(json.dumps({"config": 3, "workload": "G1 MSM of 2^%d points split by points over %d GPU(s), RCCL all-gather of per-window partials"
+                              % (args.msm_log_n, world), "matches_closed_form_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
+                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
+        assert okt.item() == 1
+        bases.free()
+
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

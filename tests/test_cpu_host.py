@@ -275,7 +275,7 @@ def test_poseidon_constants_match_oracle(zk):
     assert zk.poseidon_spec(1)[0][0][0] != zk.poseidon_spec(0)[0][0][0]
 
 
-def _note_update_case(zk, seed, op_kind, amount=250, balances=(1000, 77), slot=0):
+def _note_update_case(zk, seed, op_kind, amount=250, balances=(1000, 77), slot=0, height=10):
     """A valid update_note instance + the values the oracle's Poseidon gives for its hashes."""
     from oracle import bls12_381 as ec
     from oracle import poseidon as ps
@@ -286,8 +286,8 @@ def _note_update_case(zk, seed, op_kind, amount=250, balances=(1000, 77), slot=0
     new_id, old_id, ot, on, nt, nn, user = (rng.fr() for _ in range(7))
     old_acc = ps.hash_fix_len([tok[0], bal[0], tok[1], bal[1]])
     old_note = ps.hash_fix_len([old_id, ot, on, old_acc])
-    shape = [rng.next() & 1 for _ in range(10)]
-    path = [rng.fr() for _ in range(10)]
+    shape = [rng.next() & 1 for _ in range(height)]
+    path = [rng.fr() for _ in range(height)]
     root = ps.merkle_root(old_note, shape, path)
     nb = list(bal)
     nb[slot] += amount if op_kind == 0 else -amount
@@ -329,6 +329,151 @@ def test_update_note_relation_hashes_match_oracle(zk):
             bad[k] = (bad[k] + 1) % R
             assert not oracle_r1.is_satisfied(bad), "public %d not bound" % k
         r1.free()
+
+
+def _oracle_r1cs(r1):
+    from oracle import groth16 as g16
+
+    rows = []
+    for m in range(3):
+        rp, cl, vl = r1.export(m)
+        vals = [int.from_bytes(vl[32 * k : 32 * k + 32], "little") for k in range(len(cl))]
+        rows.append([[(cl[k], vals[k]) for k in range(rp[i], rp[i + 1])] for i in range(r1.n_constraints)])
+    return g16.R1CS(r1.n_vars, r1.n_pub, *rows)
+
+
+def test_update_note_relation_tree_height_is_a_runtime_field(zk, pkg):
+    """TREE_HEIGHT is a const generic of the reference (merkle_proof.rs:11): heights other than the
+    mock's 10 give a relation of another shape whose root still equals the oracle's fold, the builder and
+    the value-only synthesis agree, and a key for one height does not accept another height's witness."""
+    lg = 14
+    r10 = zk.update_note_r1cs(lg, 1)
+    for height in (1, 4, 20):
+        r1 = zk.update_note_r1cs(lg, 1, tree_height=height)
+        assert (r1.n_vars, r1.n_pub, r1.n_constraints) == (1 << lg, 7, (1 << lg) - 7)
+        inp, publics = _note_update_case(zk, 900 + height, 1, height=height)
+        assert inp.tree_height == height
+        w, pub, rc = zk.update_note_witness(lg, 1, inp)
+        assert rc == 0 and pub == publics
+        assert r1.is_satisfied(w) and not r10.is_satisfied(w)
+        wv, rcv = zk.update_note_witness_values_host(lg, 1, inp)
+        assert rcv == 0 and wv == w
+        r1.free()
+    # height 32 does not fit 2^13 rows; an out-of-range height is an argument error
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.update_note_r1cs(13, 1, tree_height=32)
+    assert e.value.code == -1
+    with pytest.raises(pkg.ZkmiError) as e:
+        zk.update_note_r1cs(14, 1, tree_height=33)
+    assert e.value.code == -1
+    r13 = zk.update_note_r1cs(13, 1)  # the relation proper fits 2^13 (config 0 is quoted at 2^14)
+    inp, publics = _note_update_case(zk, 77, 1)
+    w, pub, rc = zk.update_note_witness(13, 1, inp)
+    assert rc == 0 and pub == publics and r13.is_satisfied(w)
+    r13.free()
+    r10.free()
+
+
+def test_create_note_relation_matches_oracle(zk):
+    """The creation relation (what ZkProof::verify_creation stands for, relations.rs:127-136):
+    publics h_note_new | token_0 | token_1, h_note_new = Poseidon(id, trapdoor, nullifier,
+    Poseidon(token_0, 0, token_1, 0)) as oracle/poseidon.py computes it; the assignment satisfies the
+    exported matrices under the oracle's evaluator and every public input is bound."""
+    from oracle import bls12_381 as ec
+    from oracle import poseidon as ps
+    from oracle.bls12_381 import R
+
+    lg = 12
+    r1 = zk.create_note_r1cs(lg)
+    assert (r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n) == (1 << lg, 4, (1 << lg) - 4, lg)
+    rng = ec.SplitMix64(4242)
+    tok = (rng.fr(), rng.fr())
+    note = (rng.fr(), rng.fr(), rng.fr())
+    w, pub = zk.create_note_witness(lg, zk.note_create(tok, note))
+    acc_hash = ps.hash_fix_len([tok[0], 0, tok[1], 0])
+    assert pub == [ps.hash_fix_len([note[0], note[1], note[2], acc_hash]), tok[0], tok[1]]
+    assert w[32:128] == b"".join(v.to_bytes(32, "little") for v in pub)
+    assert r1.is_satisfied(w)
+    orc = _oracle_r1cs(r1)
+    z_int = [int.from_bytes(w[32 * i : 32 * i + 32], "little") for i in range(1 << lg)]
+    assert orc.is_satisfied(z_int)
+    for k in range(1, 4):
+        bad = list(z_int)
+        bad[k] = (bad[k] + 1) % R
+        assert not orc.is_satisfied(bad), "public %d not bound" % k
+    # another note under the same tokens: different hash, same shape
+    w2, pub2 = zk.create_note_witness(lg, zk.note_create(tok, (note[0], note[1], note[2] + 1)))
+    assert pub2[0] != pub[0] and r1.is_satisfied(w2)
+    r1.free()
+
+
+def test_verifier_rejects_non_canonical_and_small_order_points(zk, pkg):
+    """zkmi_groth16_verify is a validating verifier (as arkworks' deserialisation and the zcash format are):
+    one encoding of infinity, and every proof point must lie in the r-order subgroup."""
+    gd = golden("groth16_n128.json")
+    vk, proof = H(gd["vk"]), H(gd["proof"])
+    publics = H(gd["witness"])[32 : 32 * 7]
+    assert zk.groth16_verify(vk, publics, proof) is True
+
+    def rc_of(pr):
+        import ctypes as C
+
+        buf = lambda b: (C.c_uint8 * len(b)).from_buffer_copy(b)
+        return zk.lib.zkmi_groth16_verify(buf(vk), C.c_uint32(7), buf(publics), buf(pr))
+
+    # infinity with stray bits / bytes / the sort flag: not canonical
+    inf1 = bytes([0xC0]) + bytes(47)
+    for bad_inf in (bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\x01", bytes([0xC1]) + bytes(47)):
+        assert rc_of(bad_inf + proof[48:]) == -2
+        with pytest.raises(pkg.ZkmiError):
+            zk.g1_decompress(bad_inf)
+    assert rc_of(inf1 + proof[48:]) == -5  # canonical infinity parses; the pairing equation then fails
+    assert rc_of(proof[:48] + bytes([0xC0]) + bytes(94) + b"\x01" + proof[144:]) == -2
+    # a curve point outside G1: x = 4 gives y^2 = 68... search small x until decompression succeeds,
+    # the cofactor makes a random curve point miss the subgroup with overwhelming probability
+    found = None
+    for x in range(1, 200):
+        enc = bytearray(x.to_bytes(48, "big"))
+        enc[0] |= 0x80
+        try:
+            aff = zk.g1_decompress(bytes(enc))
+        except pkg.ZkmiError:
+            continue
+        if not zk.g1_in_subgroup(aff):
+            found = bytes(enc)
+            break
+    assert found is not None
+    assert zk.g1_in_subgroup(zk.g1_generator()) and zk.g2_in_subgroup(zk.g2_generator())
+    assert rc_of(found + proof[48:]) == -2          # A outside the subgroup
+    assert rc_of(proof[:144] + found) == -2         # C outside the subgroup
+    # same for G2: x = (k, 0)
+    found2 = None
+    for x in range(1, 200):
+        enc = bytearray(bytes(48) + x.to_bytes(48, "big"))
+        enc[0] |= 0x80
+        try:
+            aff = zk.g2_decompress(bytes(enc))
+        except pkg.ZkmiError:
+            continue
+        if not zk.g2_in_subgroup(aff):
+            found2 = bytes(enc)
+            break
+    assert found2 is not None
+    assert rc_of(proof[:48] + found2 + proof[144:]) == -2
+
+
+def test_r1cs_create_rejects_malformed_csr(zk, pkg):
+    """The ABI promises an error code, not a crash: decreasing row pointers, columns out of range and
+    domains beyond what the NTT supports are argument errors."""
+    one = (1).to_bytes(32, "little")
+    good = ([0, 1, 2], [1, 2], one + one)
+    r = zk.r1cs_create(4, 2, [good, good, good])
+    assert r.n_constraints == 2
+    r.free()
+    for bad in (([0, 2, 1], [1, 2], one + one), ([1, 1, 2], [1, 2], one + one), ([0, 1, 2], [1, 7], one + one)):
+        with pytest.raises(pkg.ZkmiError) as e:
+            zk.r1cs_create(4, 2, [bad, good, good])
+        assert e.value.code == -1
 
 
 def test_update_note_relation_rejects_impossible_updates(zk):

@@ -124,6 +124,22 @@ def test_cpp_oracle_prover_golden(zk):
     assert pf == H(gd["proof"])
 
 
+def test_cpp_oracle_setup_golden(zk):
+    """The C++ restatement of the trusted setup (arkworks generator shape) reproduces the Python oracle's
+    verifying key and all five queries at N = 128, so it can stand in for it at sizes Python cannot reach
+    (the GPU suite checks the product's setup against it at 2^16)."""
+    gd = golden("groth16_n128.json")
+    r1 = zk.shielder_r1cs(gd["log_n"])
+    mats = [r1.export(m) for m in range(3)]
+    vk, key = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, H(gd["toxic"]))
+    assert vk == H(gd["vk"])
+    for name, want in gd["pk"].items():
+        assert key[name] == H(want), name
+    # thread count does not change the result
+    vk1, key1 = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, H(gd["toxic"]), nthreads=1)
+    assert vk1 == vk and key1 == key
+
+
 # ---- Poseidon (SURVEY.md §8f-1) ------------------------------------------------------------
 
 

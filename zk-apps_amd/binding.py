@@ -30,6 +30,7 @@ PHASES = {
     "misc": 7,
 }
 MERKLE_TREE_DEPTH = 10
+MAX_TREE_HEIGHT = 32
 TOKENS_NUMBER = 2
 
 
@@ -66,9 +67,16 @@ class NoteUpdate(C.Structure):
     _fields_ = [
         ("amount", C.c_uint8 * 32), ("token", C.c_uint8 * 32), ("user", C.c_uint8 * 32),
         ("new_note", (C.c_uint8 * 32) * 3), ("old_note", (C.c_uint8 * 32) * 3),
-        ("path_shape", C.c_uint8 * 10), ("path", (C.c_uint8 * 32) * 10),
+        ("tree_height", C.c_uint32),
+        ("path_shape", C.c_uint8 * MAX_TREE_HEIGHT), ("path", (C.c_uint8 * 32) * MAX_TREE_HEIGHT),
         ("op_priv_user", C.c_uint8 * 32), ("account", (C.c_uint8 * 32) * 4),
     ]
+
+
+class NoteCreate(C.Structure):
+    """zkmi_note_create: semantic inputs of the creation relation."""
+
+    _fields_ = [("tokens", (C.c_uint8 * 32) * TOKENS_NUMBER), ("note", (C.c_uint8 * 32) * 3)]
 
 
 class UpdateNoteInput(C.Structure):
@@ -248,10 +256,50 @@ class Zkmi:
         return [rl[5 * i : 5 * i + 5] for i in range(64)], [ml[5 * i : 5 * i + 5] for i in range(5)]
 
     # ---- update_note relation with real Poseidon hashing --------------------
-    def update_note_r1cs(self, log_n, op_kind):
+    def update_note_r1cs(self, log_n, op_kind, tree_height=MERKLE_TREE_DEPTH):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_update_note_r1cs(C.c_uint32(log_n), C.c_int32(op_kind), C.byref(h)))
+        self._chk(self.lib.zkmi_update_note_r1cs_h(C.c_uint32(log_n), C.c_int32(op_kind), C.c_uint32(tree_height), C.byref(h)))
         return R1cs(self, h)
+
+    def create_note_r1cs(self, log_n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_create_note_r1cs(C.c_uint32(log_n), C.byref(h)))
+        return R1cs(self, h)
+
+    def note_create(self, tokens, note):
+        """Integers in: tokens = (token_0, token_1), note = (zk_id, trapdoor, nullifier)."""
+        i = NoteCreate()
+        for k in range(2):
+            C.memmove(i.tokens[k], int(tokens[k]).to_bytes(32, "little"), 32)
+        for k in range(3):
+            C.memmove(i.note[k], int(note[k]).to_bytes(32, "little"), 32)
+        return i
+
+    def create_note_witness(self, log_n, inp):
+        """(z bytes, [h_note_new, token_0, token_1] as ints)."""
+        out = (C.c_uint8 * (32 << log_n))()
+        pub = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_create_note_witness(C.c_uint32(log_n), C.byref(inp), out, pub))
+        p = bytes(pub)
+        return bytes(out), [int.from_bytes(p[32 * k : 32 * k + 32], "little") for k in range(3)]
+
+    def g1_in_subgroup(self, a):
+        return self.lib.zkmi_g1_in_subgroup(_buf(a)) == 0
+
+    def g2_in_subgroup(self, a):
+        return self.lib.zkmi_g2_in_subgroup(_buf(a)) == 0
+
+    # ---- the ZkProof surface with real proofs (SURVEY.md 8f-2) ---------------
+    def shielder_verify_creation(self, vk_create, h_note_new, tokens, proof):
+        arr = (Scalar * TOKENS_NUMBER)(*[scalar(t) for t in tokens])
+        h = scalar(h_note_new)
+        self._chk(self.lib.zkmi_shielder_verify_creation(_buf(vk_create), C.byref(h), arr, _buf(proof)))
+
+    def shielder_verify_update(self, vk_deposit, vk_withdraw, op_pub, h_note_new, merkle_root, nullifier_old, proof):
+        a = [scalar(x) for x in (h_note_new, merkle_root, nullifier_old)]
+        vd = _buf(vk_deposit) if vk_deposit else None
+        vw = _buf(vk_withdraw) if vk_withdraw else None
+        self._chk(self.lib.zkmi_shielder_verify_update(vd, vw, C.byref(op_pub), *[C.byref(x) for x in a], _buf(proof)))
 
     def note_update(self, amount, token, user, new_note, old_note, path_shape, path, op_priv_user, account):
         """Integers in, zkmi_note_update out (new_note / old_note = (zk_id, trapdoor, nullifier),
@@ -261,7 +309,10 @@ class Zkmi:
         put(i.amount, amount), put(i.token, token), put(i.user, user), put(i.op_priv_user, op_priv_user)
         for k in range(3):
             put(i.new_note[k], new_note[k]), put(i.old_note[k], old_note[k])
-        for k in range(10):
+        height = len(path)
+        assert len(path_shape) == height and 1 <= height <= MAX_TREE_HEIGHT
+        i.tree_height = height
+        for k in range(height):
             i.path_shape[k] = int(path_shape[k])
             put(i.path[k], path[k])
         for k in range(4):
@@ -484,6 +535,11 @@ class Context:
         self._chk(self.lib.zkmi_bases_g2_load(self.h, _buf(affine), C.c_uint64(len(affine) // 192), C.c_int32(check), C.byref(h)))
         return Bases(self, h, 2, len(affine) // 192)
 
+    def bases_g1_synthetic_range(self, first, n):
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_bases_g1_synthetic_range(self.h, C.c_uint64(first), C.c_uint64(n), C.byref(h)))
+        return Bases(self, h, 1, n)
+
     def bases_g1_synthetic(self, n):
         h = C.c_void_p()
         self._chk(self.lib.zkmi_bases_g1_synthetic(self.h, C.c_uint64(n), C.byref(h)))
@@ -624,6 +680,28 @@ class Context:
         )
         return ProvingKey(self, h, r1cs)
 
+    def shielder_prove_creation(self, pk_create, knowledge, tokens, r, s):
+        """(h_note_new bytes, proof bytes) from the ZkProof `knowledge` built by zkproof_new."""
+        arr = (Scalar * TOKENS_NUMBER)(*[scalar(t) for t in tokens])
+        h = Scalar()
+        out = (C.c_uint8 * 192)()
+        self._chk(self.z.lib.zkmi_shielder_prove_creation(self.h, pk_create.h, C.byref(knowledge), arr, _buf(r), _buf(s), C.byref(h), out))
+        return bytes(h.bytes), bytes(out)
+
+    def shielder_prove_update(self, pk_deposit, pk_withdraw, knowledge, op_pub, op_priv, trapdoor, nullifier, merkle_proof,
+                              leaf_id, r, s):
+        """ZkProof::update_account with a real proof: (h_note_new, merkle_root, new ZkProof, proof bytes)."""
+        height = len(merkle_proof)
+        mp = (Scalar * height)(*[scalar(x) for x in merkle_proof])
+        t, n = scalar(trapdoor), scalar(nullifier)
+        h, root, new = Scalar(), Scalar(), ZkProof()
+        out = (C.c_uint8 * 192)()
+        self._chk(self.z.lib.zkmi_shielder_prove_update(
+            self.h, pk_deposit.h if pk_deposit else None, pk_withdraw.h if pk_withdraw else None, C.byref(knowledge),
+            C.byref(op_pub), C.byref(op_priv), C.byref(t), C.byref(n), mp, C.c_uint32(height), C.c_uint32(leaf_id),
+            _buf(r), _buf(s), C.byref(h), C.byref(root), C.byref(new), out))
+        return bytes(h.bytes), bytes(root.bytes), new, bytes(out)
+
     def groth16_prove(self, pk, z, r, s):
         out = (C.c_uint8 * 192)()
         self._chk(self.lib.zkmi_groth16_prove(self.h, pk.h, _buf(z), _buf(r), _buf(s), out))
@@ -639,6 +717,15 @@ class Context:
         ptrs = (C.c_void_p * n)(*d_z_ptrs)
         out = (C.c_uint8 * (192 * n))()
         self._chk(self.lib.zkmi_groth16_prove_batch_dev(self.h, pk.h, C.c_uint32(n), ptrs, _buf(b"".join(rs)), _buf(b"".join(ss)), out))
+        raw = bytes(out)
+        return [raw[192 * i : 192 * i + 192] for i in range(n)]
+
+    def groth16_prove_batch_host(self, pk, z_ptrs, rs, ss):
+        """z_ptrs: HOST addresses of the witnesses (pinned for an asynchronous upload)."""
+        n = len(z_ptrs)
+        ptrs = (C.c_void_p * n)(*z_ptrs)
+        out = (C.c_uint8 * (192 * n))()
+        self._chk(self.lib.zkmi_groth16_prove_batch(self.h, pk.h, C.c_uint32(n), ptrs, _buf(b"".join(rs)), _buf(b"".join(ss)), out))
         raw = bytes(out)
         return [raw[192 * i : 192 * i + 192] for i in range(n)]
 

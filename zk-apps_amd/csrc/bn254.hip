@@ -189,6 +189,8 @@ int32_t zkmi_bn254_srs_prepare(zkmi_ctx* ctx, zkmi_bn_bases* b) {
   if (!b || b->n == 0) return ZKMI_ERR_BAD_ARG;
   if (b->tab) return ZKMI_OK;
   const MsmPlan plan = msm_make_plan_shared(b->n);
+  // table indices (digit * n + point) share a 32-bit word with the sign bit
+  if ((uint64_t)plan.ndigits * b->n >= (1ull << 31)) return ctx->fail(ZKMI_ERR_BAD_ARG, "SRS too long for a table");
   hipError_t e = msm_build_table<BnFq28>(b->d28, b->n, plan, &b->tab, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
@@ -210,14 +212,14 @@ int32_t zkmi_bn254_bases_free(zkmi_bn_bases* b) {
 int32_t zkmi_bn254_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_bases* bases,
                               uint8_t out_affine[64]) {
   ZK_ENTER(ctx);
-  if (!bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
   return msm_dev(ctx, d_scalars, n, bases, out_affine);
 }
 
 int32_t zkmi_bn254_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bn_bases* bases,
                           uint8_t out_affine[64]) {
   ZK_ENTER(ctx);
-  if (!bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
   if (!scalars_canonical(scalars, n)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 scalar >= r");
   ZK_HIP(ctx, ctx->staging(n * 32 + 32));
   if (n) ZK_HIP(ctx, hipMemcpyAsync(ctx->d_tmp, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));

@@ -10,8 +10,8 @@
 using namespace zkmi;
 
 namespace zkmi {
-hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t st);
-hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t st);
+hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t st, uint64_t first = 0);
+hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t st, uint64_t first = 0);
 }
 
 template <class B>
@@ -82,13 +82,21 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
+      false) {
     delete c;
     return ZKMI_ERR_HIP;
   }
+  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++)
+    if (hipEventCreateWithFlags(&c->ev_sort[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_z[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming) != hipSuccess) {
+      delete c;
+      return ZKMI_ERR_HIP;
+    }
   hipError_t e = ntt_enable_big_lds();
+  if (e == hipSuccess) e = msm_sort_enable_big_lds();
   if (e != hipSuccess) {
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -102,10 +110,12 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stream_aux) (void)hipStreamSynchronize(ctx->stream_aux);
+  for (hipStream_t s : {ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
+    if (s) (void)hipStreamSynchronize(s);
   ctx->domains.clear();
   ctx->domains_bn.clear();
   ctx->sort.release();
+  ctx->sort_h.release();
   ctx->g1.release();
   ctx->g2.release();
   ctx->g1_bn.release();
@@ -116,10 +126,14 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
   if (ctx->stream_g2) (void)hipStreamDestroy(ctx->stream_g2);
-  if (ctx->ev_sort) (void)hipEventDestroy(ctx->ev_sort);
+  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) {
+    if (ctx->ev_sort[i]) (void)hipEventDestroy(ctx->ev_sort[i]);
+    if (ctx->ev_z[i]) (void)hipEventDestroy(ctx->ev_z[i]);
+    if (ctx->ev_h[i]) (void)hipEventDestroy(ctx->ev_h[i]);
+  }
   if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
-  if (ctx->ev_z) (void)hipEventDestroy(ctx->ev_z);
-  if (ctx->ev_h) (void)hipEventDestroy(ctx->ev_h);
+  if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
+  if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
   delete ctx;
   return ZKMI_OK;
 }
@@ -133,6 +147,8 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_g2));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_heavy));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -156,6 +172,7 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   (void)hipStreamSynchronize(ctx->stream_aux);
   (void)hipStreamSynchronize(ctx->stream_g2);
   (void)hipStreamSynchronize(ctx->stream_front);
+  (void)hipStreamSynchronize(ctx->stream_heavy);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];
@@ -230,14 +247,17 @@ int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
 }
 
 int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
+  return zkmi_bases_g1_synthetic_range(ctx, 0, n, out);
+}
+int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n, zkmi_bases_g1** out) {
   ZK_ENTER(ctx);
-  if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !out || n == 0 || n >= (1ull << 31) || first >= (1ull << 40)) return ZKMI_ERR_BAD_ARG;
   zkmi_bases_g1* b = new (std::nothrow) zkmi_bases_g1();
   if (!b) return ZKMI_ERR_BAD_ARG;
   b->ctx = ctx;
   b->n = n;
   hipError_t e = hipMalloc(&b->d, sizeof(G1Affine) * n);
-  if (e == hipSuccess) e = synthetic_bases_g1(b->d, n, ctx->stream);
+  if (e == hipSuccess) e = synthetic_bases_g1(b->d, n, ctx->stream, first);
   if (e == hipSuccess) e = bases_finish(b, ctx->stream);
   if (e != hipSuccess) {
     bases_destroy(b);
@@ -289,7 +309,7 @@ int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first
 int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
                         uint8_t out_affine[96]) {
   ZK_ENTER(ctx);
-  if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g1.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
@@ -303,7 +323,7 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
 int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g2* bases,
                         uint8_t out_affine[192]) {
   ZK_ENTER(ctx);
-  if (!ctx || !bases || !out_affine || n > bases->n || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g2.reserve(n));
   ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
@@ -325,7 +345,7 @@ static int32_t upload_scalars(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n)
 int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g1* bases,
                     uint8_t out_affine[96]) {
   ZK_ENTER(ctx);
-  if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
   int32_t rc = upload_scalars(ctx, scalars, n);
   if (rc != ZKMI_OK) return rc;
   return zkmi_msm_g1_dev(ctx, ctx->d_tmp, n, bases, out_affine);
@@ -333,7 +353,7 @@ int32_t zkmi_msm_g1(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkm
 int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkmi_bases_g2* bases,
                     uint8_t out_affine[192]) {
   ZK_ENTER(ctx);
-  if (!ctx || !bases || !out_affine || n > bases->n || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !scalars)) return ZKMI_ERR_BAD_ARG;
   int32_t rc = upload_scalars(ctx, scalars, n);
   if (rc != ZKMI_OK) return rc;
   return zkmi_msm_g2_dev(ctx, ctx->d_tmp, n, bases, out_affine);
@@ -343,7 +363,9 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
                                 uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin,
                                 uint32_t* out_window_bits) {
   ZK_ENTER(ctx);
-  if (!ctx || !bases || !out_windows_affine || !out_nwin || !out_window_bits || n > bases->n) return ZKMI_ERR_BAD_ARG;
+  if (!ctx || !bases || !out_windows_affine || !out_nwin || !out_window_bits || n > bases->n || n > MSM_MAX_TERMS ||
+      plan_n > MSM_MAX_TERMS)
+    return ZKMI_ERR_BAD_ARG;
   if (plan_n < n) plan_n = n;
   ZK_HIP(ctx, ctx->sort.reserve(plan_n));
   ZK_HIP(ctx, ctx->g1.reserve(plan_n));
@@ -370,7 +392,7 @@ int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* con
     if (!ctxs[d] || !bases[d] || counts[d] > bases[d]->n || (counts[d] && !d_scalars[d])) return ZKMI_ERR_BAD_ARG;
     total += counts[d];
   }
-  if (total >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
+  if (total > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
   // one window width for every slice, planned from the global size (as the multi-process path does)
   MsmPlan pl = msm_make_plan(total);
   // enqueue every device's sort + accumulation + reduction first, then collect: the devices run concurrently
@@ -418,6 +440,18 @@ int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uin
 // ---------------------------------------------------------------------------
 // group helpers (host)
 // ---------------------------------------------------------------------------
+int32_t zkmi_g1_in_subgroup(const uint8_t affine[96]) {
+  G1Affine p;
+  if (!affine) return ZKMI_ERR_BAD_ARG;
+  if (!g1_from_wire(affine, &p, true)) return ZKMI_ERR_NON_CANONICAL;
+  return g1_in_subgroup(p) ? ZKMI_OK : ZKMI_ERR_NON_CANONICAL;
+}
+int32_t zkmi_g2_in_subgroup(const uint8_t affine[192]) {
+  G2Affine p;
+  if (!affine) return ZKMI_ERR_BAD_ARG;
+  if (!g2_from_wire(affine, &p, true)) return ZKMI_ERR_NON_CANONICAL;
+  return g2_in_subgroup(p) ? ZKMI_OK : ZKMI_ERR_NON_CANONICAL;
+}
 int32_t zkmi_g1_generator(uint8_t out[96]) {
   if (!out) return ZKMI_ERR_BAD_ARG;
   g1_to_wire(g1_generator(), out);

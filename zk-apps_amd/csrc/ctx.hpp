@@ -16,11 +16,15 @@ struct zkmi_ctx {
   hipStream_t stream_aux = nullptr;  // MSM reductions: overlap the next accumulation
   hipStream_t stream_g2 = nullptr;   // G2 accumulation beside the G1 ones
   hipStream_t stream_front = nullptr;  // witness map + NTTs beside the MSMs over z
-  hipEvent_t ev_sort = nullptr, ev_z = nullptr, ev_h = nullptr;
+  hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof
+  hipStream_t stream_heavy = nullptr;  // heavy-bucket kernels beside the accumulations (msm.hpp run_device)
+  enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
+  hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {};
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;
-  zkmi::MsmSort sort;
+  zkmi::MsmSort sort;    // every MSM entry point; in the prover: the digit sort of z (A, B1, B2, L MSMs)
+  zkmi::MsmSort sort_h;  // the prover's digit sort of the h coefficients (own buffers: see prove_enqueue_h)
   zkmi::MsmEngine<zkmi::Fq28> g1;
   zkmi::MsmEngine<zkmi::Fq2_28> g2;
   zkmi::MsmEngine<zkmi::BnFq28> g1_bn;  // BN254 G1 (bn254.hip)
@@ -121,6 +125,8 @@ G1Affine g1_generator();
 G2Affine g2_generator();
 bool g1_on_curve(const G1Affine& p);
 bool g2_on_curve(const G2Affine& p);
+bool g1_in_subgroup(const G1Affine& p);  // [r]P = O
+bool g2_in_subgroup(const G2Affine& p);
 void g1_compress(const G1Affine& p, uint8_t out[48]);
 bool g1_decompress(const uint8_t in[48], G1Affine* out);
 void g2_compress(const G2Affine& p, uint8_t out[96]);

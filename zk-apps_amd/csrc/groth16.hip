@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <string>
 #include <vector>
 #include "ctx.hpp"
 #include "pairing.hpp"
@@ -58,6 +59,45 @@ k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, 
     acc = ld28(z + (i - nc));
   }
   st28(out + i, acc);
+}
+
+// Satisfaction check on the evaluations the mat-vecs just produced: a_i b_i = c_i on every constraint
+// row and z_0 = 1 (the prover adds the constant column's query entries unconditionally).  A proof
+// from an assignment that fails this cannot verify; the prover reports ZKMI_ERR_UNSATISFIED instead.
+__global__ void __launch_bounds__(256)
+k_check_sat(const Fr28* __restrict__ a, const Fr28* __restrict__ b, const Fr28* __restrict__ c,
+            const Fr28* __restrict__ z, uint32_t nc, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i < nc) {
+    // one more product by R = one() brings the difference back into is_zero()'s exact range
+    const Fr28 d = (ld28(a + i) * ld28(b + i) - ld28(c + i)) * Fr28::one();
+    bad = !d.is_zero();
+  }
+  if (i == 0) {
+    const Fr28 d = (ld28(z) - Fr28::one()) * Fr28::one();
+    bad = bad || !d.is_zero();
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
+// every witness element must be a canonical integer < r: the MSM digits are taken from the raw words while
+// the mat-vec works on residues, so a non-canonical element would make the two halves of the proof disagree
+__global__ void __launch_bounds__(256)
+k_check_canonical(const uint32_t* __restrict__ z, uint32_t n, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(z + (size_t)i * 8);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int k = 7; k >= 0; k--)
+    if (!decided && w[k] != Fr28Params::MOD32[k]) {
+      lt = w[k] < Fr28Params::MOD32[k];
+      decided = true;
+    }
+  if (!lt) atomicOr(flag, 2u);
 }
 
 __global__ void __launch_bounds__(256)
@@ -118,19 +158,26 @@ struct zkmi_pk {
   Affine<Fq2_28>* b2_tab = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
-  Fr* d_z = nullptr;  // witness, canonical words (digit source of the A/B/L MSMs)
-  Fr28 *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;  // limb form (field28.hpp)
-  uint32_t* d_h = nullptr;  // h coefficients, canonical words, bit-reversed order
+  // per proof in flight (ring of zkmi_ctx::PROOF_RING): witness in canonical words (digit source of the
+  // A/B/L MSMs) and h coefficients in canonical words, bit-reversed order (digit source of the H MSM)
+  Fr* d_z[zkmi_ctx::PROOF_RING] = {};
+  uint32_t* d_h[zkmi_ctx::PROOF_RING] = {};
+  Fr28 *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;  // limb form (field28.hpp), front stream only
+  uint32_t* d_unsat = nullptr;  // per proof in flight: set by k_check_sat
+  uint32_t* h_unsat = nullptr;  // pinned host copy, valid once the proof's H MSM has landed
   ~zkmi_pk() {
     for (int m = 0; m < 3; m++) {
       if (d_rowptr[m]) (void)hipFree(d_rowptr[m]);
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
-    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_z, d_zm, d_a, d_b, d_c, d_h, a28, b1_28, h28, h28_rev, l28, b2_28,
-                    a_tab, b1_tab, l_tab, h_tab, b2_tab};
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_zm, d_a, d_b, d_c, a28, b1_28, h28, h28_rev, l28, b2_28,
+                    a_tab, b1_tab, l_tab, h_tab, b2_tab, d_z[0], d_z[1], d_z[2], d_h[0], d_h[1], d_h[2]};
+    static_assert(zkmi_ctx::PROOF_RING == 3, "ring size");
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    if (d_unsat) (void)hipFree(d_unsat);
+    if (h_unsat) (void)hipHostFree(h_unsat);
   }
 };
 
@@ -171,14 +218,20 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->l28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28_rev, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_z, sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
+  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) {
+    if ((e = hipMalloc(&pk->d_z[i], sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
+    if ((e = hipMalloc(&pk->d_h[i], 32ull * N)) != hipSuccess) return e;
+  }
   if ((e = hipMalloc(&pk->d_zm, sizeof(Fr28) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_b, sizeof(Fr28) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_h, 32ull * N)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t))) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
+  if ((e = ctx->sort_h.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
   return hipSuccess;
@@ -429,6 +482,14 @@ int32_t zkmi_pk_free(zkmi_pk* pk) {
   return ZKMI_OK;
 }
 
+int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint32_t* log_n) {
+  if (!pk) return ZKMI_ERR_BAD_ARG;
+  if (n_vars) *n_vars = pk->n_vars;
+  if (n_pub) *n_pub = pk->n_pub;
+  if (log_n) *log_n = pk->log_n;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count,
                              uint8_t* out) {
   ZK_ENTER(ctx);
@@ -455,26 +516,29 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
 // there); everything downstream of it (limb conversion, mat-vec, NTTs -> d_h) runs on `st`,
 // which the prover points at its front stream so that it overlaps the z-MSMs.
 static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z_in,
-                               hipStream_t st) {
+                               hipStream_t st, int par = 0) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   PhaseTimer* t = ctx->timer();
-  if (z) {
-    for (uint32_t i = 0; i < nv; i++)
-      if (!fr_is_canonical(z + 32ull * i)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
-    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, z, 32ull * nv, hipMemcpyHostToDevice, ctx->stream));
-  } else {
-    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z, d_z_in, 32ull * nv, hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  if (st != ctx->stream) {
-    ZK_HIP(ctx, hipEventRecord(ctx->ev_z, ctx->stream));
-    ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z, 0));
-  }
+  // The copy runs on the copy stream: with a pinned host witness the upload of proof i+1 (32 B per variable
+  // over PCIe) proceeds while the compute streams still work on proofs i-1 and i; the ring of witness
+  // buffers makes that safe.  Canonicity (< r) is checked on the device, not in a host loop.
+  ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par], z ? static_cast<const void*>(z) : d_z_in, 32ull * nv,
+                             z ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream_copy));
+  ZK_HIP(ctx, hipEventRecord(ctx->ev_z[par], ctx->stream_copy));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_z[par], 0));
+  if (st != ctx->stream) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z[par], 0));
   if (t) t->begin(PH_WITNESS, st);
-  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z), pk->d_zm, nv, st));
+  ZK_HIP(ctx, hipMemsetAsync(pk->d_unsat + par, 0, sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_check_canonical, dim3((nv + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const uint32_t*>(pk->d_z[par]), nv, pk->d_unsat + par);
+  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, nv, st));
   Fr28* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
   for (int m = 0; m < 3; m++)
     hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
                        pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0);
+  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, pk->d_zm, pk->nc,
+                     pk->d_unsat + par);
+  ZK_HIP(ctx, hipMemcpyAsync(pk->h_unsat + par, pk->d_unsat + par, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   if (t) t->end(PH_WITNESS, st);
   hipError_t e;
   NttDomain* dom = ctx->domain((int)pk->log_n, &e);
@@ -492,9 +556,9 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   const Fr28 zinv28 = Fr28::from_canonical(zinv.l);
   hipLaunchKernelGGL(k_quotient, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv28, N);
   // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
-  ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h, st));
+  ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h[par], st));
   if (t) t->end(PH_NTT, st);
-  if (st != ctx->stream) ZK_HIP(ctx, hipEventRecord(ctx->ev_h, st));
+  if (st != ctx->stream) ZK_HIP(ctx, hipEventRecord(ctx->ev_h[par], st));
   ZK_HIP(ctx, hipGetLastError());
   return ZKMI_OK;
 }
@@ -506,8 +570,9 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   if (rc != ZKMI_OK) return rc;
   const uint32_t N = 1u << pk->log_n;
   std::vector<uint8_t> rev(32ull * N);
-  ZK_HIP(ctx, hipMemcpyAsync(rev.data(), pk->d_h, 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(rev.data(), pk->d_h[0], 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (pk->h_unsat[0] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
   for (uint32_t p = 0; p < N; p++) {
     uint32_t i = 0;
     for (uint32_t b = 0; b < pk->log_n; b++) i |= ((p >> b) & 1u) << (pk->log_n - 1 - b);
@@ -516,21 +581,29 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   return ZKMI_OK;
 }
 
-// Device work of one proof (witness map, two digit sorts, five MSMs) queued on
-// the ctx streams; MSM partials land in slot set `par` (0/1).  Does not block.
-static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, int par) {
-  const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
+// Device work of one proof, queued on the ctx streams in two halves; MSM partials land in slot set
+// `par` (ring of zkmi_ctx::PROOF_RING).  Nothing here blocks the host.
+//   prove_enqueue_z : witness copy, witness map + NTTs (front stream), digit sort of z, the four MSMs over z
+//   prove_enqueue_h : digit sort of h, the H MSM
+// The batch prover queues proof i+1's first half BEFORE proof i's second half: the H MSM is the only
+// consumer of the NTTs, and the NTT kernels (1024-thread blocks, 100 KB of LDS) only get workgroup
+// slots in the gaps the accumulation kernels leave, so h arrives late; with the halves interleaved the
+// main stream always has a full accumulation to run instead of waiting for it.
+static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, int par) {
+  const uint32_t nv = pk->n_vars;
   hipStream_t st = ctx->stream;
-  // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the
-  // four MSMs over z, and the main stream picks h up just before the second digit sort
-  int32_t rc = witness_map_dev(ctx, pk, z, d_z, ctx->stream_front);
+  // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the MSMs over z
+  int32_t rc = witness_map_dev(ctx, pk, z, d_z, ctx->stream_front, par);
   if (rc != ZKMI_OK) return rc;
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
+  // ZKMI_HEAVY_SIDE=0: heavy-bucket kernels back on the accumulation streams (A/B runs)
+  static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
+  const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
   // MSM's reduction runs on the aux stream behind its accumulation and leaves the
   // per-window partials in a pinned host slot + an event.
-  const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z + 1);
+  const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z[par] + 1);
   const bool sh = pk->shared;
   if (sh)
     ZK_HIP(ctx, ctx->sort.run_shared(zs, nv - 1, st, t));
@@ -538,26 +611,38 @@ static int32_t prove_enqueue(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z,
     ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
   // the G2 accumulation runs on its own stream beside the three G1 ones (same sort, disjoint
   // outputs): the kernels' drain tails overlap instead of adding up
-  ZK_HIP(ctx, hipEventRecord(ctx->ev_sort, st));
-  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort, 0));
+  ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], st));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
   ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t,
-                                 PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s));
+                                 PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->a_tab : pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 0));
+                                 PH_MSM_REDUCE_G1, s0 + 0, sth));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->b1_tab : pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 1));
+                                 PH_MSM_REDUCE_G1, s0 + 1, sth));
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 2));
-  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->g2.acc_done[g2s], 0));  // the next sort re-uses the sort buffers
-  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_h, 0));               // h coefficients from the front stream
+                                 PH_MSM_REDUCE_G1, s0 + 2, sth));
+  // the next sort over z re-uses these sort buffers: it must also wait for this G2 accumulation
+  ctx->sort.readers.push_back(ctx->g2.acc_done[g2s]);
+  return ZKMI_OK;
+}
+
+static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, int par) {
+  const uint32_t N = 1u << pk->log_n;
+  hipStream_t st = ctx->stream;
+  PhaseTimer* t = ctx->timer();
+  const bool sh = pk->shared;
+  static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
+  const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
+  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_h[par], 0));  // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
-  // infinity.  Re-uses the sort buffers: stream order keeps it behind the four MSMs above.
+  // infinity.  Own sort buffers (ctx->sort_h): the G2 accumulation of the NEXT proof may still be reading
+  // the z sort when this runs.
   if (sh)
-    ZK_HIP(ctx, ctx->sort.run_shared(pk->d_h, N, st, t));
+    ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], N, st, t));
   else
-    ZK_HIP(ctx, ctx->sort.run(pk->d_h, N, st, t));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->h_tab : pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 3));
+    ZK_HIP(ctx, ctx->sort_h.run(pk->d_h[par], N, st, t));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, 4 * par + 3, sth));
   return ZKMI_OK;
 }
 
@@ -573,6 +658,9 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t r_by
   ZK_HIP(ctx, ctx->g1.finish_host(&acc_l, s0 + 2));
   ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2, g2s));
   ZK_HIP(ctx, ctx->g1.finish_host(&acc_h, s0 + 3));
+  // the flag copy precedes the h coefficients on the front stream, which the H MSM waited for
+  if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+  if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
   uint32_t rk[8], sk[8], rsk[8];
   memcpy(rk, r_bytes, 32);
   memcpy(sk, s_bytes, 32);
@@ -608,7 +696,8 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
                           const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
   if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
-  int32_t rc = prove_enqueue(ctx, pk, z, d_z, 0);
+  int32_t rc = prove_enqueue_z(ctx, pk, z, d_z, 0);
+  if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 0);
   if (rc != ZKMI_OK) return rc;
   return prove_finish(ctx, pk, r_bytes, s_bytes, 0, out_proof);
 }
@@ -627,11 +716,11 @@ int32_t zkmi_groth16_prove_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* d_z
   return prove_impl(ctx, pk, nullptr, d_z, r_bytes, s_bytes, out_proof);
 }
 
-// Batch of independent proofs over one key (BASELINE config 2), two in flight:
-// proof i+1's device work is queued before the CPU combines proof i.
-int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
-                                     const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
-  ZK_ENTER(ctx);
+// Batch of independent proofs over one key (BASELINE config 2), up to three in flight: the device queue
+// always holds proof i+1's z-half and proof i's h-half while the CPU assembles proof i-1.
+//   main stream:  z(0) | z(1) h(0) | z(2) h(1) | ...      host:  finish(0) after queueing [z(2) h(1)], ...
+static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z, bool host,
+                           const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
   if (!ctx || !pk || !d_z || !r_bytes || !s_bytes || !out_proofs) return ZKMI_ERR_BAD_ARG;
   for (uint32_t i = 0; i < n_proofs; i++) {
     if (!d_z[i]) return ZKMI_ERR_BAD_ARG;
@@ -639,17 +728,51 @@ int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t 
       return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
   }
   if (n_proofs == 0) return ZKMI_OK;
-  int32_t rc = prove_enqueue(ctx, pk, nullptr, d_z[0], 0);
-  if (rc != ZKMI_OK) return rc;
+  constexpr int RING = zkmi_ctx::PROOF_RING;
+  // on an error the other proofs in flight still have work queued on every ctx stream: drain them
+  // before handing control (and the right to free buffers) back to the caller
+  auto bail = [&](int32_t code) {
+    const std::string msg = ctx->err;
+    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
+      (void)hipStreamSynchronize(q);
+    ctx->err = msg;
+    return code;
+  };
+  auto finish = [&](uint32_t i) {
+    return prove_finish(ctx, pk, r_bytes + 32ull * i, s_bytes + 32ull * i, (int)(i % RING), out_proofs + 192ull * i);
+  };
+  auto enqueue_z = [&](uint32_t i) {
+    return host ? prove_enqueue_z(ctx, pk, static_cast<const uint8_t*>(d_z[i]), nullptr, (int)(i % RING))
+                : prove_enqueue_z(ctx, pk, nullptr, d_z[i], (int)(i % RING));
+  };
+  int32_t rc = enqueue_z(0);
+  if (rc != ZKMI_OK) return bail(rc);
   for (uint32_t i = 0; i < n_proofs; i++) {
     if (i + 1 < n_proofs) {
-      rc = prove_enqueue(ctx, pk, nullptr, d_z[i + 1], (int)((i + 1) & 1));
-      if (rc != ZKMI_OK) return rc;
+      rc = enqueue_z(i + 1);
+      if (rc != ZKMI_OK) return bail(rc);
     }
-    rc = prove_finish(ctx, pk, r_bytes + 32ull * i, s_bytes + 32ull * i, (int)(i & 1), out_proofs + 192ull * i);
-    if (rc != ZKMI_OK) return rc;
+    rc = prove_enqueue_h(ctx, pk, (int)(i % RING));
+    if (rc != ZKMI_OK) return bail(rc);
+    if (i >= 1 && (rc = finish(i - 1)) != ZKMI_OK) return bail(rc);  // frees slot set (i - 1) % RING = (i + 2) % RING
   }
+  if ((rc = finish(n_proofs - 1)) != ZKMI_OK) return bail(rc);
   return ZKMI_OK;
+}
+
+int32_t zkmi_groth16_prove_batch_dev(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const void* const* d_z,
+                                     const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
+  ZK_ENTER(ctx);
+  return prove_batch(ctx, pk, n_proofs, d_z, false, r_bytes, s_bytes, out_proofs);
+}
+
+// The same pipeline fed from HOST witnesses: each upload runs on the copy stream while earlier proofs
+// compute (pin the buffers -- hipHostMalloc / hipHostRegister / torch pin_memory -- or the runtime stages
+// the copy synchronously).  This is the PCIe-inclusive rate bench.py reports as value_incl_h2d.
+int32_t zkmi_groth16_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, const uint8_t* const* z,
+                                 const uint8_t* r_bytes, const uint8_t* s_bytes, uint8_t* out_proofs) {
+  ZK_ENTER(ctx);
+  return prove_batch(ctx, pk, n_proofs, reinterpret_cast<const void* const*>(z), true, r_bytes, s_bytes, out_proofs);
 }
 
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]) {
@@ -659,14 +782,19 @@ int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* pu
   if (!g1_from_wire(vk, &alpha, true) || !g2_from_wire(vk + 96, &beta, true) ||
       !g2_from_wire(vk + 288, &gamma, true) || !g2_from_wire(vk + 480, &delta, true))
     return ZKMI_ERR_NON_CANONICAL;
+  // canonical encodings only (one encoding of infinity), then subgroup membership of every point
+  // that enters a Miller loop: an on-curve point of small order would make the check malleable
   if (!g1_decompress(proof, &a) || !g2_decompress(proof + 48, &b) || !g1_decompress(proof + 144, &c))
     return ZKMI_ERR_NON_CANONICAL;
+  if (!g1_in_subgroup(a) || !g2_in_subgroup(b) || !g1_in_subgroup(c)) return ZKMI_ERR_NON_CANONICAL;
+  if (!g1_in_subgroup(alpha) || !g2_in_subgroup(beta) || !g2_in_subgroup(gamma) || !g2_in_subgroup(delta))
+    return ZKMI_ERR_NON_CANONICAL;
   G1Affine ic0;
-  if (!g1_from_wire(vk + 672, &ic0, true)) return ZKMI_ERR_NON_CANONICAL;
+  if (!g1_from_wire(vk + 672, &ic0, true) || !g1_in_subgroup(ic0)) return ZKMI_ERR_NON_CANONICAL;
   G1XYZZ acc = G1XYZZ::from_affine(ic0);
   for (uint32_t j = 1; j < n_pub; j++) {
     G1Affine icj;
-    if (!g1_from_wire(vk + 672 + 96ull * j, &icj, true)) return ZKMI_ERR_NON_CANONICAL;
+    if (!g1_from_wire(vk + 672 + 96ull * j, &icj, true) || !g1_in_subgroup(icj)) return ZKMI_ERR_NON_CANONICAL;
     if (!fr_is_canonical(publics + 32ull * (j - 1))) return ZKMI_ERR_NON_CANONICAL;
     uint32_t k[8];
     memcpy(k, publics + 32ull * (j - 1), 32);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "curve.hpp"
 #include "field28.hpp"
 
@@ -35,6 +36,10 @@ enum Phase {
   PH_MISC = 7,
   PH_COUNT = 8
 };
+
+// The sort addresses sorted[] with 32-bit slots: windowed mode uses regions w * n (nwin = 16 at c = 16)
+// and shared mode packs (digit * n + point) below the sign bit, so both need 16 n < 2^32.
+constexpr uint64_t MSM_MAX_TERMS = (1ull << 28) - 1;
 
 struct MsmPlan {
   int c = 0;        // digit bits (signed digits)
@@ -73,6 +78,10 @@ struct MsmSort {
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
   int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
+  // events of kernels on OTHER streams that still read count/begin/heavy/sorted (the heavy-bucket
+  // kernels of MsmEngine::run_device): the next sort waits for them before it overwrites the buffers
+  mutable std::vector<hipEvent_t> readers;
+  hipError_t wait_readers(hipStream_t st);
   ~MsmSort() { release(); }
   void release();
   bool has_shared = false;  // buffers sized for the shared-bucket plan too
@@ -81,6 +90,8 @@ struct MsmSort {
   // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
   hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
 };
+
+hipError_t msm_sort_enable_big_lds();  // per device, see msm_sort.hip
 
 // device field F (lazily reduced 28-bit limbs) <-> host field (32-bit limbs)
 template <class F> struct HostFieldOf;
@@ -91,7 +102,7 @@ template <> struct HostFieldOf<BnFq28> { using type = BnFq; };
 template <class F>
 struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
-  enum { SLOTS = 8, SLOT_PTS = 64 * 32 };  // two proofs in flight x four G1 MSMs
+  enum { SLOTS = 12, SLOT_PTS = 64 * 32 };  // three proofs in flight (groth16.hip PROOF_RING) x four G1 MSMs
   XYZZ<F>* buckets = nullptr;  // SLOTS x cap_buckets: one bucket array per MSM in flight
   XYZZ<F>* segsum = nullptr;
   XYZZ<F>* segw = nullptr;
@@ -102,6 +113,8 @@ struct MsmEngine {
   XYZZ<HF>* h_partial = nullptr;  // pinned host, SLOTS x SLOT_PTS
   hipEvent_t done[SLOTS] = {};      // partials landed in h_partial
   hipEvent_t acc_done[SLOTS] = {};  // bucket accumulation finished
+  hipEvent_t pre[SLOTS] = {};         // recorded in front of the accumulation (the sort is complete)
+  hipEvent_t heavy_done[SLOTS] = {};  // heavy-bucket kernels finished (side stream)
   MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }
@@ -111,9 +124,12 @@ struct MsmEngine {
   // device part: bucket accumulation + reduction down to per-window partials,
   // async copy of the partials to the host and an event; does not block
   // accumulation runs on `st`; the (low-occupancy, latency-bound) reduction runs on
-  // `st_reduce` behind an event so it overlaps the next MSM's accumulation
+  // `st_reduce` behind an event so it overlaps the next MSM's accumulation; the heavy-bucket kernels
+  // (which own buckets the accumulation skips) run on `st_heavy` beside the accumulation when given:
+  // with uniform scalars their list is empty, and on `st` the empty launches waited ~0.8 ms each for
+  // a free workgroup slot before the next accumulation could start
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, hipStream_t st_reduce,
-                        PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0);
+                        PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0, hipStream_t st_heavy = nullptr);
   // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points

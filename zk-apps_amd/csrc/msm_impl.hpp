@@ -385,7 +385,9 @@ void MsmEngine<F>::release() {
   for (int i = 0; i < SLOTS; i++) {
     if (done[i]) (void)hipEventDestroy(done[i]);
     if (acc_done[i]) (void)hipEventDestroy(acc_done[i]);
-    done[i] = acc_done[i] = nullptr;
+    if (pre[i]) (void)hipEventDestroy(pre[i]);
+    if (heavy_done[i]) (void)hipEventDestroy(heavy_done[i]);
+    done[i] = acc_done[i] = pre[i] = heavy_done[i] = nullptr;
   }
   buckets = segsum = segw = nullptr;
   partial = h_partial = nullptr;
@@ -418,6 +420,8 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   for (int i = 0; i < SLOTS; i++) {
     if ((e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&acc_done[i], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&pre[i], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&heavy_done[i], hipEventDisableTiming)) != hipSuccess) return e;
   }
   cap_buckets = need;
   return hipSuccess;
@@ -432,13 +436,21 @@ static inline int msm_seg_bits(const MsmPlan& pl) {
 
 template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
-                                    hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot) {
+                                    hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot,
+                                    hipStream_t st_heavy) {
   const MsmPlan& pl = sort.plan;
   slot_plan[slot] = pl;
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
   XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
+  const bool side = st_heavy && st_heavy != st;
+  if (side) {
+    // heavy and light buckets are disjoint, so the two kernels may run side by side: the heavy stream
+    // only has to see the sort complete
+    if ((e = hipEventRecord(pre[slot], st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st_heavy, pre[slot], 0)) != hipSuccess) return e;
+  }
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     hipLaunchKernelGGL(k_accum_g2_split<0>, dim3((2 * tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
@@ -455,12 +467,18 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
                          sort.count, sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
-  hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st, d_bases,
+  const hipStream_t sh = side ? st_heavy : st;
+  hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, sh, d_bases,
                      sort.begin, sort.count, sort.heavy, sort.sorted, bk, heavy_partial);
-  hipLaunchKernelGGL(k_heavy_combine<F>, dim3(64), dim3(MSM_HSPLIT), sizeof(XYZZ<F>) * MSM_HSPLIT, st, sort.heavy,
+  hipLaunchKernelGGL(k_heavy_combine<F>, dim3(64), dim3(MSM_HSPLIT), sizeof(XYZZ<F>) * MSM_HSPLIT, sh, sort.heavy,
                      heavy_partial, bk);
   if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
   if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
+  if (side) {
+    if ((e = hipEventRecord(heavy_done[slot], st_heavy)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st_reduce, heavy_done[slot], 0)) != hipSuccess) return e;
+    sort.readers.push_back(heavy_done[slot]);  // the next sort must not overwrite what these kernels read
+  }
   if (prof) prof->begin(ph_reduce, st_reduce);
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   const uint32_t tot_segs = pl.nwin * segs_per_win;

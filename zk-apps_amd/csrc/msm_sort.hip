@@ -489,26 +489,39 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   cap_entries = ne;
   cap_buckets = nbk;
   cap_hist = nh;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_shared<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_rec<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_pass_rec<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  return hipSuccess;
+}
+
+// 160 KiB dynamic-LDS opt-in of the histogram kernels for the CURRENT device (function attributes are
+// per device: zkmi_ctx_create calls this after hipSetDevice, next to ntt_enable_big_lds)
+hipError_t msm_sort_enable_big_lds() {
+  const void* fns[] = {reinterpret_cast<const void*>(k_bucket_pass<false>),
+                       reinterpret_cast<const void*>(k_bucket_pass<true>),
+                       reinterpret_cast<const void*>(k_bucket_pass_shared<false>),
+                       reinterpret_cast<const void*>(k_bucket_pass_shared<true>),
+                       reinterpret_cast<const void*>(k_bucket_pass_rec<false>),
+                       reinterpret_cast<const void*>(k_bucket_pass_rec<true>)};
+  for (const void* f : fns) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
+hipError_t MsmSort::wait_readers(hipStream_t st) {
+  for (hipEvent_t ev : readers) {
+    const hipError_t e = hipStreamWaitEvent(st, ev, 0);
+    if (e != hipSuccess) return e;
+  }
+  readers.clear();
+  return hipSuccess;
+}
+
 hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
+  {
+    const hipError_t er = wait_readers(st);
+    if (er != hipSuccess) return er;
+  }
   plan = plan_override ? msm_make_plan_c(n, plan_override) : msm_make_plan(n);
   const uint32_t nb = plan.nb, nwin = (uint32_t)plan.nwin;
   const uint32_t tot_b = nwin * nb;
@@ -551,6 +564,10 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
 }
 
 hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
+  {
+    const hipError_t er = wait_readers(st);
+    if (er != hipSuccess) return er;
+  }
   plan = msm_make_plan_shared(n);
   const uint32_t nb = plan.nb, P = (uint32_t)plan.nwin;
   int nb_log = 0;

@@ -225,6 +225,17 @@ int32_t zkmi_r1cs_create(uint32_t n_vars, uint32_t n_pub, uint32_t n_constraints
                          const uint8_t* b_val, const uint32_t* c_rowptr, const uint32_t* c_col, const uint8_t* c_val,
                          zkmi_r1cs** out) {
   if (!out || !a_rowptr || !b_rowptr || !c_rowptr || n_pub == 0 || n_pub > n_vars) return ZKMI_ERR_BAD_ARG;
+  // domain = next_pow2(constraints + instance variables) must be one the NTT supports (2^26)
+  if ((uint64_t)n_constraints + n_pub > (1ull << 26) || n_vars > (1u << 26)) return ZKMI_ERR_BAD_ARG;
+  {
+    // CSR sanity before anything is copied: row pointers start at 0 and never decrease
+    const uint32_t* rps[3] = {a_rowptr, b_rowptr, c_rowptr};
+    for (const uint32_t* rp : rps) {
+      if (rp[0] != 0) return ZKMI_ERR_BAD_ARG;
+      for (uint32_t i = 0; i < n_constraints; i++)
+        if (rp[i] > rp[i + 1]) return ZKMI_ERR_BAD_ARG;
+    }
+  }
   zkmi_r1cs* r = new (std::nothrow) zkmi_r1cs();
   if (!r) return ZKMI_ERR_BAD_ARG;
   r->n_vars = n_vars;

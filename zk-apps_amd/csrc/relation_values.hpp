@@ -13,10 +13,10 @@
 
 namespace zkmi {
 
-constexpr int RV_TREE_HEIGHT = 10;
 constexpr int RV_BALANCE_BITS = 128;
 constexpr uint32_t RV_N_PUB = 7;
-constexpr uint32_t RV_N_LOADED = 39;  // 1 + 6 publics + 32 witnesses loaded by UpdateNoteInput::new
+// loaded by UpdateNoteInput::new: 1 + 6 publics + 7 note fields + 2 H path entries + op_priv + 4 account
+// fields = 19 + 2 H variables for tree height H (39 at the mock's depth 10)
 
 // streams 32-byte canonical little-endian elements into one assignment vector
 struct WireSink {
@@ -141,7 +141,7 @@ ZK_HD bool rv_range(const Fr28& x, SINK& out) {
 
 // One instance: writes n_vars = 39 + gadget variables + K chain variables + n_free zeros, returns
 // ZKMI_OK or the mock's error code for an update the relation cannot satisfy.
-ZK_HD int32_t rv_update_note(const zkmi_note_update& in, int32_t op_kind, uint64_t K, uint32_t n_free,
+ZK_HD int32_t rv_update_note(const zkmi_note_update& in, int32_t op_kind, int RV_TREE_HEIGHT, uint64_t K, uint32_t n_free,
                              const PoseidonConsts<Fr28>* __restrict__ c, uint32_t* z_out) {
   bool ok = rv_canonical(in.amount) && rv_canonical(in.token) && rv_canonical(in.user) && rv_canonical(in.op_priv_user);
   for (int i = 0; i < 3; i++) ok = ok && rv_canonical(in.new_note[i]) && rv_canonical(in.old_note[i]);
@@ -199,13 +199,13 @@ ZK_HD int32_t rv_update_note(const zkmi_note_update& in, int32_t op_kind, uint64
   for (int i = 0; i < RV_TREE_HEIGHT; i++) {
     const Fr28 p = rv_load(in.path[i]);
     out.put(p);
-    s0 = s0 + Fr28::mul_inline(rv_small(18 + i), p);
+    s0 = s0 + Fr28::mul_inline(rv_small(8 + RV_TREE_HEIGHT + i), p);
   }
   out.put(priv_user);
-  s0 = s0 + Fr28::mul_inline(rv_small(28), priv_user);
+  s0 = s0 + Fr28::mul_inline(rv_small(8 + 2 * RV_TREE_HEIGHT), priv_user);
   for (int i = 0; i < 4; i++) {
     out.put(acc[i]);
-    s0 = s0 + Fr28::mul_inline(rv_small(29 + i), acc[i]);
+    s0 = s0 + Fr28::mul_inline(rv_small(9 + 2 * RV_TREE_HEIGHT + i), acc[i]);
   }
 
   // verify_note_circuit(new_note, new_note_hash)

@@ -38,17 +38,18 @@ __device__ __forceinline__ void st(T* p, const T& v) {
 // table[j] = j*Q affine for j in [0, RUN) (table[0] unused), table[RUN] = Q
 template <class F>
 __global__ void __launch_bounds__(64)
-k_synth(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ table, Affine<F> g, uint64_t n) {
+k_synth(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ table, Affine<F> g, uint64_t n, uint64_t first) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t i0 = t * RUN;
   if (i0 >= n) return;
-  // A = G + i0 * Q
+  // A = G + (first + i0) * Q: out[] holds the points P_first .. P_{first + n - 1}
   XYZZ<F> acc = XYZZ<F>::infinity();
   {
     const Affine<F> q = ld(table + RUN);
+    const uint64_t k0 = first + i0;
     for (int b = 40; b >= 0; b--) {
       acc.dbl_inplace();
-      if ((i0 >> b) & 1) acc.madd(q);
+      if ((k0 >> b) & 1) acc.madd(q);
     }
     acc.madd(g);
   }
@@ -77,7 +78,7 @@ k_synth(Affine<F>* __restrict__ out, const Affine<F>* __restrict__ table, Affine
 }
 
 template <class F>
-hipError_t synth(Affine<F>* d_out, uint64_t n, const Affine<F>& g, hipStream_t stt) {
+hipError_t synth(Affine<F>* d_out, uint64_t n, const Affine<F>& g, hipStream_t stt, uint64_t first) {
   // host: Q = 0xC0FFEE * G and the run table
   uint32_t k[1] = {0xC0FFEEu};
   XYZZ<F> qx = scalar_mul(XYZZ<F>::from_affine(g), k, 1);
@@ -96,7 +97,7 @@ hipError_t synth(Affine<F>* d_out, uint64_t n, const Affine<F>& g, hipStream_t s
   e = hipMemcpyAsync(d_table, table.data(), sizeof(Affine<F>) * table.size(), hipMemcpyHostToDevice, stt);
   if (e == hipSuccess) {
     const uint64_t threads = (n + RUN - 1) / RUN;
-    hipLaunchKernelGGL(k_synth<F>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, stt, d_out, d_table, g, n);
+    hipLaunchKernelGGL(k_synth<F>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, stt, d_out, d_table, g, n, first);
     e = hipGetLastError();
   }
   hipError_t e2 = hipStreamSynchronize(stt);
@@ -106,11 +107,11 @@ hipError_t synth(Affine<F>* d_out, uint64_t n, const Affine<F>& g, hipStream_t s
 
 }  // namespace
 
-hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t stt) {
-  return synth<Fq>(d_out, n, g1_generator(), stt);
+hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t stt, uint64_t first) {
+  return synth<Fq>(d_out, n, g1_generator(), stt, first);
 }
-hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t stt) {
-  return synth<Fq2>(d_out, n, g2_generator(), stt);
+hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t stt, uint64_t first) {
+  return synth<Fq2>(d_out, n, g2_generator(), stt, first);
 }
 
 }  // namespace zkmi

@@ -215,9 +215,24 @@ void g1_compress(const G1Affine& p, uint8_t out[48]) {
   out[0] |= 0x80;
   if (p.y.lex_larger()) out[0] |= 0x20;
 }
+// Subgroup membership [r]P = O (host, O(255) group operations).  Curve points outside the
+// r-order subgroups exist on both curves (cofactors h1, h2 > 1); arkworks' validating
+// deserialisation and the zcash format both reject them, and the Miller loop is only defined on
+// the subgroups.
+bool g1_in_subgroup(const G1Affine& p) {
+  if (p.is_inf()) return true;
+  return scalar_mul(G1XYZZ::from_affine(p), FrParams::MOD, 8).is_inf();
+}
+bool g2_in_subgroup(const G2Affine& p) {
+  if (p.is_inf()) return true;
+  return scalar_mul(G2XYZZ::from_affine(p), FrParams::MOD, 8).is_inf();
+}
+
 bool g1_decompress(const uint8_t in[48], G1Affine* out) {
   if (!(in[0] & 0x80)) return false;
   if (in[0] & 0x40) {
+    // the one canonical encoding of infinity: 0xC0 followed by zeros (sort flag clear)
+    if (in[0] != 0xC0 || !all_zero(in + 1, 47)) return false;
     *out = G1Affine::infinity();
     return true;
   }
@@ -242,6 +257,7 @@ void g2_compress(const G2Affine& p, uint8_t out[96]) {
 bool g2_decompress(const uint8_t in[96], G2Affine* out) {
   if (!(in[0] & 0x80)) return false;
   if (in[0] & 0x40) {
+    if (in[0] != 0xC0 || !all_zero(in + 1, 95)) return false;
     *out = G2Affine::infinity();
     return true;
   }
