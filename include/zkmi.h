@@ -321,6 +321,7 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t alpha_g
                      const uint8_t* h_query, const uint8_t* l_query, zkmi_pk** out_pk);
 int32_t zkmi_pk_free(zkmi_pk* pk);
 int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint32_t* log_n);
+int32_t zkmi_pk_export_g1_elems(const zkmi_pk* pk, uint8_t out_beta_g1[96], uint8_t out_delta_g1[96]);
 /* export one query of a resident key (0=a,1=b_g1,2=b_g2,3=h,4=l) in wire format */
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count, uint8_t* out);
 /* witness -> proof.  z = full assignment (n_vars x 32 B, z[0] = 1); r, s =
@@ -350,6 +351,22 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
  * encodings (one encoding of infinity) of points in the r-order subgroups, and so must the vk's points;
  * anything else returns ZKMI_ERR_NON_CANONICAL, a failed pairing equation ZKMI_ERR_VERIFICATION. */
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]);
+
+/* ---- keys in arkworks' CanonicalSerialize layout (drop-in for keys made by ark-groth16) -------- *
+ * VerifyingKey = alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | Vec<gamma_abc_g1>;
+ * ProvingKey = vk | beta_g1 | delta_g1 | Vec a | Vec b_g1 | Vec b_g2 | Vec h | Vec l; Vec = u64 LE length + elements;
+ * points in the zcash-style big-endian encoding, compressed (48 / 96 B) or not (96 / 192 B).
+ * Layout restated from ark-groth16 0.4 / ark-serialize 0.4 / ark-bls12-381 0.4 [not in the reference tree;
+ * oracle/README.md rows 8, 10].  A compressed Proof is this library's 192-byte proof as is. */
+int32_t zkmi_ark_vk_read(const uint8_t* buf, uint64_t len, int32_t compressed, uint8_t* out_vk, uint64_t vk_cap,
+                         uint32_t* out_n_pub, uint64_t* out_consumed);
+/* out may be NULL to query the size; *out_len receives the bytes needed / written */
+int32_t zkmi_ark_vk_write(const uint8_t* vk, uint32_t n_pub, int32_t compressed, uint8_t* out, uint64_t cap, uint64_t* out_len);
+/* proving key for `r1cs` from arkworks bytes (shape must match: n_vars, n_pub, domain); out_vk optional */
+int32_t zkmi_ark_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t* buf, uint64_t len, int32_t compressed,
+                         int32_t check_curve, zkmi_pk** out_pk, uint8_t* out_vk, uint64_t vk_cap);
+int32_t zkmi_ark_pk_write(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* vk, int32_t compressed, uint8_t* out,
+                          uint64_t cap, uint64_t* out_len);
 
 /* ---- row a12: the reference's prove/verify surface ------------------------ */
 #define ZKMI_MERKLE_TREE_DEPTH 10 /* shielder/mocked_zk/src/lib.rs:16 */

@@ -131,4 +131,8 @@ void g1_compress(const G1Affine& p, uint8_t out[48]);
 bool g1_decompress(const uint8_t in[48], G1Affine* out);
 void g2_compress(const G2Affine& p, uint8_t out[96]);
 bool g2_decompress(const uint8_t in[96], G2Affine* out);
+void g1_write_be(const G1Affine& p, uint8_t out[96]);   // uncompressed big-endian forms (arkworks Compress::No)
+bool g1_read_be(const uint8_t in[96], G1Affine* out, bool check_curve);
+void g2_write_be(const G2Affine& p, uint8_t out[192]);
+bool g2_read_be(const uint8_t in[192], G2Affine* out, bool check_curve);
 }  // namespace zkmi

@@ -490,6 +490,13 @@ int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint
   return ZKMI_OK;
 }
 
+int32_t zkmi_pk_export_g1_elems(const zkmi_pk* pk, uint8_t out_beta_g1[96], uint8_t out_delta_g1[96]) {
+  if (!pk || !out_beta_g1 || !out_delta_g1) return ZKMI_ERR_BAD_ARG;
+  g1_to_wire(pk->beta_g1, out_beta_g1);
+  g1_to_wire(pk->delta_g1, out_delta_g1);
+  return ZKMI_OK;
+}
+
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count,
                              uint8_t* out) {
   ZK_ENTER(ctx);

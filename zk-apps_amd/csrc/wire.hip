@@ -272,4 +272,52 @@ bool g2_decompress(const uint8_t in[96], G2Affine* out) {
   return true;
 }
 
+// ---- uncompressed big-endian point forms (the Compress::No side of the zcash-style encoding) ----
+// G1: x || y (96 B), G2: x.c1 || x.c0 || y.c1 || y.c0 (192 B); byte 0 carries the flags: bit 7 = 0
+// (uncompressed), bit 6 = infinity (all other bits and bytes zero), bit 5 unused.
+void g1_write_be(const G1Affine& p, uint8_t out[96]) {
+  if (p.is_inf()) {
+    memset(out, 0, 96);
+    out[0] = 0x40;
+    return;
+  }
+  be48(p.x, out);
+  be48(p.y, out + 48);
+}
+bool g1_read_be(const uint8_t in[96], G1Affine* out, bool check_curve) {
+  if (in[0] & 0x80) return false;
+  if (in[0] & 0x40) {
+    if (in[0] != 0x40 || !all_zero(in + 1, 95)) return false;
+    *out = G1Affine::infinity();
+    return true;
+  }
+  if (in[0] & 0x20) return false;
+  if (!from_be48(in, 0xFF, &out->x) || !from_be48(in + 48, 0xFF, &out->y)) return false;
+  return !check_curve || g1_on_curve(*out);
+}
+void g2_write_be(const G2Affine& p, uint8_t out[192]) {
+  if (p.is_inf()) {
+    memset(out, 0, 192);
+    out[0] = 0x40;
+    return;
+  }
+  be48(p.x.c1, out);
+  be48(p.x.c0, out + 48);
+  be48(p.y.c1, out + 96);
+  be48(p.y.c0, out + 144);
+}
+bool g2_read_be(const uint8_t in[192], G2Affine* out, bool check_curve) {
+  if (in[0] & 0x80) return false;
+  if (in[0] & 0x40) {
+    if (in[0] != 0x40 || !all_zero(in + 1, 191)) return false;
+    *out = G2Affine::infinity();
+    return true;
+  }
+  if (in[0] & 0x20) return false;
+  if (!from_be48(in, 0xFF, &out->x.c1) || !from_be48(in + 48, 0xFF, &out->x.c0) || !from_be48(in + 96, 0xFF, &out->y.c1) ||
+      !from_be48(in + 144, 0xFF, &out->y.c0))
+    return false;
+  return !check_curve || g2_on_curve(*out);
+}
+
 }  // namespace zkmi
