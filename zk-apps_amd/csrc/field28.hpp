@@ -162,6 +162,8 @@ struct Fp28 {
   ZK_HD friend Fp28 operator*(const Fp28& a, const Fp28& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CALL_MUL28)
     return mul_call(a, b);
+#elif defined(ZK_FIPS28)
+    return mul_fips(a, b);
 #else
     return mul_inline(a, b);
 #endif
@@ -169,6 +171,8 @@ struct Fp28 {
   ZK_HD Fp28 sqr() const {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_CALL_MUL28)
     return sqr_call(*this);
+#elif defined(ZK_FIPS28)
+    return sqr_fips();
 #else
     return sqr_inline();
 #endif
@@ -199,6 +203,84 @@ struct Fp28 {
       for (int j = i + 1; j < NL; j++) T[i + j] += (int64_t)d * l[j];
     }
     return reduce(T);
+  }
+
+  // ---- product-scanning forms ("finely integrated product scanning") -----------------------------
+  // The same Montgomery product column by column: ONE 64-bit accumulator walks the 2 NL columns, the
+  // reduction multiples m_k are produced as soon as their column is complete.  Same NL^2 + NL^2 multiply-adds
+  // as mul_inline, but the live state is a, b, m (NL words) and one accumulator instead of 2 NL 64-bit
+  // columns (56 registers for Fq): what lets the bucket-accumulation kernels keep a third wave per SIMD.
+  // Column bound: <= 2 NL products of < 2^56 (+ lazy operands, see header) + carry < 2^62.
+  // sum_{i+j=k} (a1[i] b1[j] + a2[i] b2[j]) with the second pair optional (lazy a b + c d under one reduction)
+  template <bool TWO>
+  ZK_HD static Fp28 fips(const Fp28& a1, const Fp28& b1, const Fp28& a2, const Fp28& b2) {
+    int32_t m[NL];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (int64_t)a1.l[i] * b1.l[k - i];
+        if (TWO) acc += (int64_t)a2.l[i] * b2.l[k - i];
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P::MOD[k - i];
+      m[k] = (int32_t)(((uint32_t)acc * P::INV) & (uint32_t)MASK);
+      acc += (int64_t)m[k] * P::MOD[0];
+      acc >>= 28;  // exact: the low 28 bits are zero
+    }
+    Fp28 r;
+#pragma unroll
+    for (int k = NL; k < 2 * NL; k++) {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++) {
+        acc += (int64_t)a1.l[i] * b1.l[k - i];
+        if (TWO) acc += (int64_t)a2.l[i] * b2.l[k - i];
+      }
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++) acc += (int64_t)m[i] * P::MOD[k - i];
+      if (k < 2 * NL - 1) {
+        r.l[k - NL] = (int32_t)acc & MASK;
+        acc >>= 28;
+      } else {
+        r.l[NL - 1] = (int32_t)acc;
+      }
+    }
+    return r;
+  }
+  ZK_HD static Fp28 mul_fips(const Fp28& a, const Fp28& b) { return fips<false>(a, b, a, b); }
+  ZK_HD Fp28 sqr_fips() const {
+    // squares: the symmetric terms once, doubled (d = 2 a_i fits 30 bits)
+    int32_t m[NL];
+    int64_t acc = 0;
+    Fp28 r;
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) {
+      const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+#pragma unroll
+      for (int i = lo; i <= hi; i++) {
+        const int j = k - i;
+        if (i < j) acc += (int64_t)(l[i] * 2) * l[j];
+        else if (i == j) acc += (int64_t)l[i] * l[i];
+      }
+      if (k < NL) {
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P::MOD[k - i];
+        m[k] = (int32_t)(((uint32_t)acc * P::INV) & (uint32_t)MASK);
+        acc += (int64_t)m[k] * P::MOD[0];
+        acc >>= 28;
+      } else {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (int64_t)m[i] * P::MOD[k - i];
+        if (k < 2 * NL - 1) {
+          r.l[k - NL] = (int32_t)acc & MASK;
+          acc >>= 28;
+        } else {
+          r.l[NL - 1] = (int32_t)acc;
+        }
+      }
+    }
+    return r;
   }
 
   // Fermat inverse x^(m-2) (0 -> 0); table construction only, never on the proving path
@@ -374,6 +456,14 @@ ZK_HD Fp28<P> f_x3(const Fp28<P>& rr, const Fp28<P>& ppp, const Fp28<P>& q) {
 template <class P>
 ZK_HD Fp28<P> f_mul_sub_mul(const Fp28<P>& a, const Fp28<P>& b, const Fp28<P>& c, const Fp28<P>& d) {
   constexpr int NL = P::NL;
+#if defined(ZK_FIPS28)
+  {
+    Fp28<P> nc;
+#pragma unroll
+    for (int i = 0; i < NL; i++) nc.l[i] = -c.l[i];
+    return Fp28<P>::template fips<true>(a, b, nc, d);
+  }
+#endif
   int64_t T[2 * NL];
 #pragma unroll
   for (int i = 0; i < 2 * NL; i++) T[i] = 0;

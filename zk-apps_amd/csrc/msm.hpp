@@ -115,6 +115,8 @@ struct MsmEngine {
   hipEvent_t acc_done[SLOTS] = {};  // bucket accumulation finished
   hipEvent_t pre[SLOTS] = {};         // recorded in front of the accumulation (the sort is complete)
   hipEvent_t heavy_done[SLOTS] = {};  // heavy-bucket kernels finished (side stream)
+  hipEvent_t redo_done[SLOTS] = {};   // k_accum_redo finished (it still reads the sort)
+  uint32_t* redo = nullptr;           // [0] = count, [1..] = buckets a call-free accumulation kernel left to k_accum_redo
   MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
   ~MsmEngine() { release(); }

@@ -38,6 +38,9 @@ namespace zkmi {
 // segment arrays: 16-bucket segments for big plans, down to 1-bucket segments for plans of <= 2^16 buckets
 static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
+#ifndef ZKMI_ACCUM_DEFAULT
+#define ZKMI_ACCUM_DEFAULT 0
+#endif
 constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
 template <class T>
@@ -195,6 +198,159 @@ k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __res
   st_comp(dst + 2 + comp, acc.y.v);
   st_comp(dst + 4 + comp, acc.zz.v);
   st_comp(dst + 6 + comp, acc.zzz.v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Call-free accumulation kernels.  XYZZ::madd keeps its rare doubling case in an out-of-line function;
+// a call inside the hot kernel costs more than code size: the kernel's register count becomes the
+// callee's (231-248 VGPRs whatever __launch_bounds__ asks for) and the frame needs scratch.  Here the
+// doubling case (two equal points in one bucket: repeated bases with equal digits) never happens in
+// the kernel: the lane appends its bucket to a redo list and stops; k_accum_redo recomputes the
+// listed buckets with the complete addition afterwards.  The list holds bucket ids, so it cannot
+// overflow (capacity = number of buckets).
+// ---------------------------------------------------------------------------------------------
+// returns false when acc + p is a doubling (acc left untouched)
+template <class F>
+__device__ __forceinline__ bool madd_nocall(XYZZ<F>& acc, bool& inf, const Affine<F>& p) {
+  if (p.is_inf()) return true;
+  if (inf) {
+    acc.x = p.x;
+    acc.y = p.y;
+    acc.zz = F::one();
+    acc.zzz = F::one();
+    inf = false;
+    return true;
+  }
+  F pp_ = f_sub_lazy(p.x * acc.zz, acc.x);
+  F r = f_sub_lazy(p.y * acc.zzz, acc.y);
+  F pp = pp_.sqr();
+  F rr = r.sqr();
+  if (pp.is_zero()) {
+    if (rr.is_zero()) return false;
+    inf = true;  // P + (-P)
+    return true;
+  }
+  F ppp = pp_ * pp;
+  acc.zz = acc.zz * pp;
+  acc.zzz = acc.zzz * ppp;
+  F q = acc.x * pp;
+  acc.x = f_x3(rr, ppp, q);
+  acc.y = f_mul_sub_mul(r, f_sub_lazy(q, acc.x), acc.y, ppp);
+  return true;
+}
+
+// G1 (and BN254 G1): thread per bucket, next table entry prefetched through ONE LDS buffer per wave
+// (the entry is read into registers at the top of the iteration, so the buffer is free for the next
+// direct-to-LDS load straight away): 28 KB per 256-thread block.
+template <class F, int W>
+__global__ void __launch_bounds__(256, W)
+k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
+              const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
+              const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
+              uint32_t heavy_thr, uint32_t* __restrict__ redo) {
+  constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
+  __shared__ uint4 tile[4][CHUNKS][64];           // [wave][chunk][lane]
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (t >= total_buckets) return;
+  const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
+  const uint32_t beg = begin[b], end = beg + cnt;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  bool inf = true;
+  auto fetch = [&](uint32_t v) {
+    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[wave][q][0], 16, 0, 0);
+  };
+  uint32_t v_cur = 0, v_next = 0;
+  if (cnt) {
+    v_cur = sorted[beg];
+    fetch(v_cur);
+    if (cnt > 1) v_next = sorted[beg + 1];
+  }
+  for (uint32_t j = beg; j < end; j++) {
+    // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
+    Affine<F> p;
+    uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) d[q] = tile[wave][q][lane];
+    const uint32_t v = v_cur;
+    if (j + 1 < end) {
+      // the reads above must have left the LDS before the buffer is refilled
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      fetch(v_next);
+      v_cur = v_next;
+      if (j + 2 < end) v_next = sorted[j + 2];
+    }
+    if (v >> 31) p.y = p.y.neg();
+    if (!madd_nocall(acc, inf, p)) {
+      redo[1 + atomicAdd(redo, 1u)] = b;
+      return;  // the bucket is recomputed by k_accum_redo
+    }
+  }
+  if (inf) acc = XYZZ<F>::infinity();
+  store_vec(buckets + b, acc);
+}
+
+// G2, lane pair per bucket (see k_accum_g2_split)
+template <int W>
+__global__ void __launch_bounds__(256, W)
+k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+              const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
+              const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets,
+              uint32_t heavy_thr, uint32_t* __restrict__ redo) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt >> 1, comp = gt & 1u;
+  if (t >= total_buckets) return;  // pair-uniform
+  const uint32_t b = perm[t];
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;
+  const uint32_t beg = begin[b], end = beg + cnt;
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  bool inf = true;
+  for (uint32_t j = beg; j < end; j++) {
+    const uint32_t v = sorted[j];
+    const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
+    Affine<Fq2P> p;
+    p.x.v = ld_comp(src + comp);
+    p.y.v = ld_comp(src + 2 + comp);
+    if (v >> 31) p.y = p.y.neg();
+    if (!madd_nocall(acc, inf, p)) {  // pair-uniform (Fq2P::is_zero exchanges the halves)
+      if (comp == 0) redo[1 + atomicAdd(redo, 1u)] = b;
+      return;
+    }
+  }
+  if (inf) acc = XYZZ<Fq2P>::infinity();
+  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);
+  st_comp(dst + comp, acc.x.v);
+  st_comp(dst + 2 + comp, acc.y.v);
+  st_comp(dst + 4 + comp, acc.zz.v);
+  st_comp(dst + 6 + comp, acc.zzz.v);
+}
+
+// the listed buckets again, with the complete addition (rare: repeated bases with equal digits)
+template <class F>
+__global__ void __launch_bounds__(64)
+k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
+             const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
+             XYZZ<F>* __restrict__ buckets, const uint32_t* __restrict__ redo) {
+  const uint32_t n = redo[0];
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint32_t b = redo[1 + k];
+    const uint32_t beg = begin[b], end = beg + count[b];
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t j = beg; j < end; j++) {
+      const uint32_t v = sorted[j];
+      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+    store_vec(buckets + b, acc);
+  }
 }
 
 // Heavy buckets (repeated scalars, booleans: one bucket can hold 20 % of all points):
@@ -381,13 +537,16 @@ void MsmEngine<F>::release() {
   if (partial) (void)hipFree(partial);
   if (heavy_partial) (void)hipFree(heavy_partial);
   heavy_partial = nullptr;
+  if (redo) (void)hipFree(redo);
+  redo = nullptr;
   if (h_partial) (void)hipHostFree(h_partial);
   for (int i = 0; i < SLOTS; i++) {
     if (done[i]) (void)hipEventDestroy(done[i]);
     if (acc_done[i]) (void)hipEventDestroy(acc_done[i]);
     if (pre[i]) (void)hipEventDestroy(pre[i]);
     if (heavy_done[i]) (void)hipEventDestroy(heavy_done[i]);
-    done[i] = acc_done[i] = pre[i] = heavy_done[i] = nullptr;
+    if (redo_done[i]) (void)hipEventDestroy(redo_done[i]);
+    done[i] = acc_done[i] = pre[i] = heavy_done[i] = redo_done[i] = nullptr;
   }
   buckets = segsum = segw = nullptr;
   partial = h_partial = nullptr;
@@ -416,12 +575,14 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT)) != hipSuccess) return e;
+  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
     if ((e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&acc_done[i], hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&pre[i], hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&heavy_done[i], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&redo_done[i], hipEventDisableTiming)) != hipSuccess) return e;
   }
   cap_buckets = need;
   return hipSuccess;
@@ -451,20 +612,40 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     if ((e = hipEventRecord(pre[slot], st)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(st_heavy, pre[slot], 0)) != hipSuccess) return e;
   }
+  // ZKMI_ACCUM: 0 = the first-generation kernels (madd with an out-of-line doubling path), 2/3 = the call-free
+  // kernels at 2 / 3 waves per SIMD (default: see DESIGN.md 4.1 for the measurements behind it)
+  static const int accum_mode = [] {
+    const char* e = getenv("ZKMI_ACCUM");
+    return e ? atoi(e) : ZKMI_ACCUM_DEFAULT;
+  }();
+  const bool nocall = accum_mode == 2 || accum_mode == 3;
+  if (nocall && (e = hipMemsetAsync(redo, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
-    hipLaunchKernelGGL(k_accum_g2_split<0>, dim3((2 * tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                       sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
-  } else {
-    // default: LDS-prefetching kernel (3.62 -> 3.43 ms on the 2^20 windowed MSM); ZKMI_ACCUM_GLDS=0 selects
-    // the plain gather kernel for A/B runs
-    static const bool glds = !(getenv("ZKMI_ACCUM_GLDS") && getenv("ZKMI_ACCUM_GLDS")[0] == '0');
-    if (glds)
-      hipLaunchKernelGGL(k_accum_g1_glds<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin, sort.count,
-                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+    const dim3 grid((2 * tot_b + T - 1) / T);
+    if (accum_mode == 3)
+      hipLaunchKernelGGL(k_accum_g2_nc<3>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk,
+                         tot_b, pl.heavy_thr, redo);
+    else if (accum_mode == 2)
+      hipLaunchKernelGGL(k_accum_g2_nc<2>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk,
+                         tot_b, pl.heavy_thr, redo);
     else
-      hipLaunchKernelGGL(k_accum<F>, dim3((tot_b + T - 1) / T), dim3(T), 0, st, d_bases, sort.begin,
-                         sort.count, sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+      hipLaunchKernelGGL(k_accum_g2_split<0>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
+                         bk, tot_b, pl.heavy_thr);
+  } else {
+    const dim3 grid((tot_b + T - 1) / T);
+    if (accum_mode == 3)
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 3>), grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
+                         bk, tot_b, pl.heavy_thr, redo);
+    else if (accum_mode == 2)
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 2>), grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
+                         bk, tot_b, pl.heavy_thr, redo);
+    else if (accum_mode == 1)
+      hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
+                         pl.heavy_thr);
+    else
+      hipLaunchKernelGGL(k_accum_g1_glds<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
+                         bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
   const hipStream_t sh = side ? st_heavy : st;
@@ -478,6 +659,15 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     if ((e = hipEventRecord(heavy_done[slot], st_heavy)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(st_reduce, heavy_done[slot], 0)) != hipSuccess) return e;
     sort.readers.push_back(heavy_done[slot]);  // the next sort must not overwrite what these kernels read
+  }
+  if (nocall) {
+    // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
+    // heavy buckets are never listed, so the heavy kernels may still be running
+    using RF = typename std::conditional<std::is_same<F, Fq2_28>::value, Fq2_28, F>::type;
+    hipLaunchKernelGGL(k_accum_redo<RF>, dim3(64), dim3(64), 0, st_reduce, d_bases, sort.begin, sort.count, sort.sorted, bk, redo);
+    // the list reads the sort: the next sort must wait for this kernel too
+    if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;
+    sort.readers.push_back(redo_done[slot]);
   }
   if (prof) prof->begin(ph_reduce, st_reduce);
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
