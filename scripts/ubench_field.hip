@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "curve.hpp"
@@ -310,6 +311,35 @@ int main() {
   for (size_t off = 0; off < npts; off += distinct - 1)  // stride distinct-1: neighbours in a pair differ
     hipMemcpy(d_pts + off, d_small, sizeof(Affine<Fq28>) * std::min<size_t>(distinct - 1, npts - off), hipMemcpyDeviceToDevice);
   hipDeviceSynchronize();
+  // C. does the dispatcher keep 2 big-register waves per SIMD resident when it has to REFILL slots?  Same mixed-addition
+  // loop, k = 32 additions per lane, grid = 1x / 4x / 8x the resident capacity (2048 waves), workgroups of 256 and 64
+  // threads: with perfect refill the time scales with the number of rounds.
+  printf("C. refill: k_xyzz_chain, 32 additions per lane, grids of R x 2048 waves\n");
+  for (uint32_t bs : {256u, 64u}) {
+    for (uint32_t rounds : {1u, 4u, 8u}) {
+      const uint32_t L = lanes * rounds, k = 32;
+      if ((size_t)L * k * 2 > npts) continue;
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      XYZZ<Fq28>* d_acc2;
+      hipMalloc(&d_acc2, sizeof(XYZZ<Fq28>) * L);
+      uint64_t* d_cyc2;
+      hipMalloc(&d_cyc2, 8ull * (L / 64));
+      float ms = 0;
+      for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_xyzz_chain, dim3(L / bs), dim3(bs), 0, 0, d_pts, d_acc2, L, k, d_cyc2);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+      }
+      printf("  block %3u, %u round(s): %7.3f ms  (%.3f ms per round)  %6.2f G adds/s\n", bs, rounds, ms, ms / rounds, (double)L * k / (ms * 1e-3) / 1e9);
+      hipFree(d_acc2);
+      hipFree(d_cyc2);
+    }
+  }
+  if (getenv("UBENCH_SKIP_B")) return 0;
   for (uint32_t k : {16u, 64u, 256u, 1024u}) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);

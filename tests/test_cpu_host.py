@@ -462,6 +462,32 @@ def test_verifier_rejects_non_canonical_and_small_order_points(zk, pkg):
     assert rc_of(proof[:48] + found2 + proof[144:]) == -2
 
 
+def test_arkworks_vk_layout_round_trip(zk, pkg):
+    """VerifyingKey in arkworks' CanonicalSerialize layout (restated in csrc/arkworks.hip and, independently, in
+    oracle/ark_serialize.py): both restatements emit the same bytes, compressed and uncompressed, and the reader
+    returns the original key; truncated or corrupted input is an error, not a crash."""
+    from oracle import ark_serialize as ark
+
+    gd = golden("groth16_n128.json")
+    vk = H(gd["vk"])
+    n_pub = (len(vk) - 672) // 96
+    for compressed in (True, False):
+        blob = zk.ark_vk_write(vk, n_pub, compressed)
+        assert blob == ark.verifying_key(vk, n_pub, compressed)
+        assert len(blob) == (48 + 3 * 96 + 8 + 48 * n_pub) * (1 if compressed else 2) - (0 if compressed else 8)
+        back, n, used = zk.ark_vk_read(blob + b"tail", compressed)
+        assert (back, n, used) == (vk, n_pub, len(blob))
+        with pytest.raises(pkg.ZkmiError):
+            zk.ark_vk_read(blob[:-1], compressed)
+        bad = bytearray(blob)
+        bad[5] ^= 1  # alpha_g1.x: no longer on the curve / not a valid x
+        with pytest.raises(pkg.ZkmiError):
+            zk.ark_vk_read(bytes(bad), compressed)
+    # a compressed arkworks Proof is the 192-byte proof as is: A | B | C
+    pr = H(gd["proof"])
+    assert zk.g1_compress(zk.g1_decompress(pr[:48])) == pr[:48] and zk.g2_compress(zk.g2_decompress(pr[48:144])) == pr[48:144]
+
+
 def test_r1cs_create_rejects_malformed_csr(zk, pkg):
     """The ABI promises an error code, not a crash: decreasing row pointers, columns out of range and
     domains beyond what the NTT supports are argument errors."""

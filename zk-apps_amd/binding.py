@@ -289,6 +289,22 @@ class Zkmi:
     def g2_in_subgroup(self, a):
         return self.lib.zkmi_g2_in_subgroup(_buf(a)) == 0
 
+    # ---- keys in arkworks' CanonicalSerialize layout --------------------------
+    def ark_vk_read(self, buf, compressed):
+        cap = 672 + 96 * 64
+        out = (C.c_uint8 * cap)()
+        n_pub, used = C.c_uint32(), C.c_uint64()
+        self._chk(self.lib.zkmi_ark_vk_read(_buf(buf), C.c_uint64(len(buf)), C.c_int32(int(compressed)), out, C.c_uint64(cap),
+                                            C.byref(n_pub), C.byref(used)))
+        return bytes(out)[: 672 + 96 * n_pub.value], n_pub.value, used.value
+
+    def ark_vk_write(self, vk, n_pub, compressed):
+        need = C.c_uint64()
+        self.lib.zkmi_ark_vk_write(_buf(vk), C.c_uint32(n_pub), C.c_int32(int(compressed)), None, C.c_uint64(0), C.byref(need))
+        out = (C.c_uint8 * need.value)()
+        self._chk(self.lib.zkmi_ark_vk_write(_buf(vk), C.c_uint32(n_pub), C.c_int32(int(compressed)), out, need, C.byref(need)))
+        return bytes(out)
+
     # ---- the ZkProof surface with real proofs ---------------
     def shielder_verify_creation(self, vk_create, h_note_new, tokens, proof):
         arr = (Scalar * TOKENS_NUMBER)(*[scalar(t) for t in tokens])
@@ -701,6 +717,22 @@ class Context:
             C.byref(op_pub), C.byref(op_priv), C.byref(t), C.byref(n), mp, C.c_uint32(height), C.c_uint32(leaf_id),
             _buf(r), _buf(s), C.byref(h), C.byref(root), C.byref(new), out))
         return bytes(h.bytes), bytes(root.bytes), new, bytes(out)
+
+    def ark_pk_load(self, r1cs, buf, compressed, check_curve=True):
+        """Proving key from arkworks' ProvingKey::serialize_{compressed,uncompressed} bytes -> (ProvingKey, vk bytes)."""
+        h = C.c_void_p()
+        cap = 672 + 96 * r1cs.n_pub
+        vk = (C.c_uint8 * cap)()
+        self._chk(self.lib.zkmi_ark_pk_load(self.h, r1cs.h, _buf(buf), C.c_uint64(len(buf)), C.c_int32(int(compressed)),
+                                            C.c_int32(int(check_curve)), C.byref(h), vk, C.c_uint64(cap)))
+        return ProvingKey(self, h, r1cs), bytes(vk)
+
+    def ark_pk_write(self, pk, vk, compressed):
+        need = C.c_uint64()
+        self.lib.zkmi_ark_pk_write(self.h, pk.h, _buf(vk), C.c_int32(int(compressed)), None, C.c_uint64(0), C.byref(need))
+        out = (C.c_uint8 * need.value)()
+        self._chk(self.lib.zkmi_ark_pk_write(self.h, pk.h, _buf(vk), C.c_int32(int(compressed)), out, need, C.byref(need)))
+        return bytes(out)
 
     def groth16_prove(self, pk, z, r, s):
         out = (C.c_uint8 * 192)()

@@ -68,8 +68,9 @@ struct MsmSort {
   uint32_t* count = nullptr;      // nwin*nb   points per bucket
   uint32_t* begin = nullptr;      // nwin*nb   first slot of the bucket in sorted[] (window w owns [w*n, (w+1)*n))
   uint32_t* blockhist = nullptr;  // nwin*nch*nb  per-(window, chunk) tile histogram -> tile base slots
-  uint32_t* perm = nullptr;       // nwin*nb   bucket ids ordered by descending load (per window)
+  uint32_t* perm = nullptr;       // nwin*nb   bucket ids of ALL windows ordered by descending load
   uint32_t* heavy = nullptr;      // [0] = number of heavy buckets, [1..] their ids
+  uint32_t* order_bins = nullptr; // load-ordering: global key histogram -> running offsets
   uint32_t* part_total = nullptr; // shared mode: entries per partition
   uint32_t* blkcnt = nullptr;     // shared mode record pre-pass: per-(block, partition) counts -> slots
   uint32_t* rec_entry = nullptr;  // records grouped by partition: table index | sign

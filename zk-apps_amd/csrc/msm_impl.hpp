@@ -41,6 +41,12 @@ constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LD
 #ifndef ZKMI_ACCUM_DEFAULT
 #define ZKMI_ACCUM_DEFAULT 0
 #endif
+#ifndef ZKMI_ACCUM_BLOCK_DEFAULT
+#define ZKMI_ACCUM_BLOCK_DEFAULT 64
+#endif
+#ifndef ZKMI_ACCUM_ROUNDS_DEFAULT
+#define ZKMI_ACCUM_ROUNDS_DEFAULT 0
+#endif
 constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
 template <class T>
@@ -101,52 +107,58 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
 // LDS: 2 buffers x 256 threads x 112 B = 56 KB per block, two blocks per CU (VGPR-limited anyway).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-template <class F>
-__global__ void __launch_bounds__(256, AccumWaves<F>::value)
+// BW = waves per workgroup.  One-wave workgroups (BW = 1) free their slot the moment the wave retires; a
+// 4-wave workgroup can only start once all four SIMDs of a CU have a free slot at the same time.
+// The loop strides the load-ordered bucket list by the grid size: with a grid of one wave per bucket group
+// it runs once (dynamic dispatch, heaviest groups first); with a smaller grid every wave takes a heavy, a
+// medium and a light group in turn (ZKMI_ACCUM_ROUNDS) and nothing depends on the dispatcher's refill rate.
+template <class F, int BW>
+__global__ void __launch_bounds__(64 * BW, AccumWaves<F>::value)
 k_accum_g1_glds(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
                 const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
                 const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
                 uint32_t heavy_thr) {
   constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
-  __shared__ uint4 tile[2][4][CHUNKS][64];            // [buffer][wave][chunk][lane]
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint4 tile[2][BW][CHUNKS][64];           // [buffer][wave][chunk][lane]
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (t >= total_buckets) return;
-  const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
-  const uint32_t cnt = count[b];
-  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
-  const uint32_t beg = begin[b], end = beg + cnt;
-  XYZZ<F> acc = XYZZ<F>::infinity();
-  auto fetch = [&](uint32_t v, int buf) {
-    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total_buckets; t += stride) {
+    const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
+    const uint32_t cnt = count[b];
+    if (cnt > heavy_thr) continue;  // k_accum_heavy owns it
+    const uint32_t beg = begin[b], end = beg + cnt;
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    auto fetch = [&](uint32_t v, int buf) {
+      const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
 #pragma unroll
-    for (int q = 0; q < CHUNKS; q++)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[buf][wave][q][0], 16, 0, 0);
-  };
-  uint32_t v_cur = 0, v_next = 0;
-  if (cnt) {
-    v_cur = sorted[beg];
-    fetch(v_cur, 0);
-    if (cnt > 1) v_next = sorted[beg + 1];
-  }
-  int buf = 0;
-  for (uint32_t j = beg; j < end; j++) {
-    // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
-    Affine<F> p;
-    uint4* d = reinterpret_cast<uint4*>(&p);
-#pragma unroll
-    for (int q = 0; q < CHUNKS; q++) d[q] = tile[buf][wave][q][lane];
-    const uint32_t v = v_cur;
-    if (j + 1 < end) {
-      fetch(v_next, buf ^ 1);
-      v_cur = v_next;
-      if (j + 2 < end) v_next = sorted[j + 2];
+      for (int q = 0; q < CHUNKS; q++)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[buf][wave][q][0], 16, 0, 0);
+    };
+    uint32_t v_cur = 0, v_next = 0;
+    if (cnt) {
+      v_cur = sorted[beg];
+      fetch(v_cur, 0);
+      if (cnt > 1) v_next = sorted[beg + 1];
     }
-    buf ^= 1;
-    if (v >> 31) p.y = p.y.neg();
-    acc.madd(p);
+    int buf = 0;
+    for (uint32_t j = beg; j < end; j++) {
+      // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
+      Affine<F> p;
+      uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+      for (int q = 0; q < CHUNKS; q++) d[q] = tile[buf][wave][q][lane];
+      const uint32_t v = v_cur;
+      if (j + 1 < end) {
+        fetch(v_next, buf ^ 1);
+        v_cur = v_next;
+        if (j + 2 < end) v_next = sorted[j + 2];
+      }
+      buf ^= 1;
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+    store_vec(buckets + b, acc);
   }
-  store_vec(buckets + b, acc);
 }
 
 // G2 accumulation with every Fq2 value split across a lane pair (field28.hpp Fq2P):
@@ -170,34 +182,35 @@ __device__ __forceinline__ void st_comp(Fq28* p, const Fq28& v) {
   for (int i = 0; i < 7; i++) q[i] = make_uint2((uint32_t)v.l[2 * i], (uint32_t)v.l[2 * i + 1]);
 }
 
-template <int UNUSED = 0>
-__global__ void __launch_bounds__(256, 2)
+template <int BW>
+__global__ void __launch_bounds__(64 * BW, 2)
 k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
                  const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
                  const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets,
                  uint32_t heavy_thr) {
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t = gt >> 1, comp = gt & 1u;
-  if (t >= total_buckets) return;  // pair-uniform
-  const uint32_t b = perm[t];
-  const uint32_t cnt = count[b];
-  if (cnt > heavy_thr) return;
-  const uint32_t beg = begin[b], end = beg + cnt;
-  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-  for (uint32_t j = beg; j < end; j++) {
-    const uint32_t v = sorted[j];
-    const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
-    Affine<Fq2P> p;
-    p.x.v = ld_comp(src + comp);
-    p.y.v = ld_comp(src + 2 + comp);
-    if (v >> 31) p.y = p.y.neg();
-    acc.madd(p);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x; (gt >> 1) < total_buckets; gt += stride) {
+    const uint32_t t = gt >> 1, comp = gt & 1u;
+    const uint32_t b = perm[t];
+    const uint32_t cnt = count[b];
+    if (cnt > heavy_thr) continue;  // pair-uniform
+    const uint32_t beg = begin[b], end = beg + cnt;
+    XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+    for (uint32_t j = beg; j < end; j++) {
+      const uint32_t v = sorted[j];
+      const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
+      Affine<Fq2P> p;
+      p.x.v = ld_comp(src + comp);
+      p.y.v = ld_comp(src + 2 + comp);
+      if (v >> 31) p.y = p.y.neg();
+      acc.madd(p);
+    }
+    Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+    st_comp(dst + comp, acc.x.v);
+    st_comp(dst + 2 + comp, acc.y.v);
+    st_comp(dst + 4 + comp, acc.zz.v);
+    st_comp(dst + 6 + comp, acc.zzz.v);
   }
-  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
-  st_comp(dst + comp, acc.x.v);
-  st_comp(dst + 2 + comp, acc.y.v);
-  st_comp(dst + 4 + comp, acc.zz.v);
-  st_comp(dst + 6 + comp, acc.zzz.v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,6 +632,21 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     return e ? atoi(e) : ZKMI_ACCUM_DEFAULT;
   }();
   const bool nocall = accum_mode == 2 || accum_mode == 3;
+  // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
+  // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
+  static const int accum_block = [] {
+    const char* e = getenv("ZKMI_ACCUM_BLOCK");
+    return (e && atoi(e) == 64) ? 64 : (e && atoi(e) == 256) ? 256 : ZKMI_ACCUM_BLOCK_DEFAULT;
+  }();
+  static const int accum_rounds = [] {
+    const char* e = getenv("ZKMI_ACCUM_ROUNDS");
+    return e ? atoi(e) : ZKMI_ACCUM_ROUNDS_DEFAULT;
+  }();
+  auto striped = [&](uint32_t threads_needed, uint32_t block) {
+    uint32_t blocks = (threads_needed + block - 1) / block;
+    if (accum_rounds > 1) blocks = (blocks + accum_rounds - 1) / accum_rounds;
+    return blocks ? blocks : 1u;
+  };
   if (nocall && (e = hipMemsetAsync(redo, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
@@ -629,9 +657,12 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     else if (accum_mode == 2)
       hipLaunchKernelGGL(k_accum_g2_nc<2>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk,
                          tot_b, pl.heavy_thr, redo);
+    else if (accum_block == 64)
+      hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases, sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
     else
-      hipLaunchKernelGGL(k_accum_g2_split<0>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
-                         bk, tot_b, pl.heavy_thr);
+      hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases, sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   } else {
     const dim3 grid((tot_b + T - 1) / T);
     if (accum_mode == 3)
@@ -643,9 +674,12 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     else if (accum_mode == 1)
       hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
                          pl.heavy_thr);
+    else if (accum_block == 64)
+      hipLaunchKernelGGL((k_accum_g1_glds<F, 1>), dim3(striped(tot_b, 64)), dim3(64), 0, st, d_bases, sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
     else
-      hipLaunchKernelGGL(k_accum_g1_glds<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
-                         bk, tot_b, pl.heavy_thr);
+      hipLaunchKernelGGL((k_accum_g1_glds<F, 4>), dim3(striped(tot_b, 256)), dim3(256), 0, st, d_bases, sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
   const hipStream_t sh = side ? st_heavy : st;

@@ -277,42 +277,79 @@ k_bucket_bases(uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ be
   blockhist[g] += begin[w * nb + b];
 }
 
-// Pass 2d: one workgroup per window orders its buckets by descending load so that
-// the 64 lanes of a wave in k_accum own buckets of (nearly) equal size (a
-// thread-per-bucket loop otherwise runs at the pace of the fullest bucket:
-// Poisson(32) loads give ~65 % lane utilisation).  Buckets above MSM_HEAVY
-// points (repeated scalars: booleans, small values) go to a separate list that
-// k_accum_heavy reduces with a whole workgroup each.
+// Pass 2d: ALL buckets (every window / partition) ordered by descending load, so that
+//   * the 64 lanes of a wave in k_accum own buckets of (nearly) equal size (a thread-per-bucket loop
+//     otherwise runs at the pace of the fullest bucket: Poisson(32) loads give ~65 % lane utilisation);
+//   * the dispatcher hands out the longest waves first (LPT).  Ordering each window on its own left a
+//     saw-tooth: the chip holds a quarter of the waves at a time, and with heavy groups arriving in the
+//     last quarter the accumulation ended on a long, thinly occupied tail (resident waves per SIMD 1.27 of
+//     2 measured; a scheduling model of the same loads gives 0.79 -> 0.94 slot occupancy for the global order).
+// Counting sort by the key (load >> shift) in three small kernels: per-block LDS histogram -> global bins,
+// scan of the 258 bins, scatter with per-block reserved ranges.  Buckets above the heavy threshold go to a
+// separate list that k_accum_heavy reduces with whole workgroups; they sort last (the accumulation skips them).
+constexpr uint32_t ORDER_BINS = MSM_HEAVY + 2;
+__device__ __forceinline__ uint32_t order_key(uint32_t cnt, uint32_t thr, int shift) {
+  // 0 = heaviest light bucket ... MSM_HEAVY = empty; heavy buckets sort last (key MSM_HEAVY + 1)
+  return cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
+}
 __global__ void __launch_bounds__(1024)
-k_bucket_order(const uint32_t* __restrict__ count, uint32_t* __restrict__ perm, uint32_t* __restrict__ heavy,
-               uint32_t* __restrict__ n_heavy, uint32_t nb, uint32_t thr, int shift) {
-  __shared__ uint32_t bins[MSM_HEAVY + 2];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
-  for (uint32_t i = tid; i < MSM_HEAVY + 2; i += 1024) bins[i] = 0;
+k_order_hist(const uint32_t* __restrict__ count, uint32_t* __restrict__ gbins, uint32_t total, uint32_t thr, int shift) {
+  __shared__ uint32_t bins[ORDER_BINS];
+  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024) bins[i] = 0;
   __syncthreads();
-  // key: 0 = heaviest light bucket ... MSM_HEAVY = empty; heavy buckets sort last (key MSM_HEAVY + 1)
-  for (uint32_t b = tid; b < nb; b += 1024) {
-    const uint32_t cnt = count[w * nb + b];
-    const uint32_t key = cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
-    atomicAdd(&bins[key], 1u);
-  }
+  for (uint32_t b = blockIdx.x * 1024 + threadIdx.x; b < total; b += gridDim.x * 1024) atomicAdd(&bins[order_key(count[b], thr, shift)], 1u);
   __syncthreads();
-  if (tid == 0) {
+  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024)
+    if (bins[i]) atomicAdd(&gbins[i], bins[i]);
+}
+__global__ void __launch_bounds__(64)
+k_order_scan(uint32_t* __restrict__ gbins) {
+  if (threadIdx.x == 0) {
     uint32_t run = 0;
-    for (uint32_t i = 0; i < MSM_HEAVY + 2; i++) {
-      const uint32_t v = bins[i];
-      bins[i] = run;
+    for (uint32_t i = 0; i < ORDER_BINS; i++) {
+      const uint32_t v = gbins[i];
+      gbins[i] = run;
       run += v;
     }
   }
+}
+__global__ void __launch_bounds__(1024)
+k_order_scatter(const uint32_t* __restrict__ count, uint32_t* __restrict__ gbins, uint32_t* __restrict__ perm,
+                uint32_t* __restrict__ heavy, uint32_t* __restrict__ n_heavy, uint32_t total, uint32_t thr, int shift) {
+  __shared__ uint32_t bins[ORDER_BINS];
+  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024) bins[i] = 0;
   __syncthreads();
-  for (uint32_t b = tid; b < nb; b += 1024) {
-    const uint32_t cnt = count[w * nb + b];
-    const uint32_t key = cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
-    const uint32_t pos = atomicAdd(&bins[key], 1u);
-    perm[w * nb + pos] = w * nb + b;
-    if (cnt > thr) heavy[atomicAdd(n_heavy, 1u)] = w * nb + b;
+  // every block owns one contiguous slice of the bucket array: count its keys, reserve a range per key, scatter
+  const uint32_t per = (total + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = (lo + per < total) ? lo + per : total;
+  for (uint32_t b = lo + threadIdx.x; b < hi; b += 1024) atomicAdd(&bins[order_key(count[b], thr, shift)], 1u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024) {
+    const uint32_t c = bins[i];
+    bins[i] = c ? atomicAdd(&gbins[i], c) : 0u;
   }
+  __syncthreads();
+  for (uint32_t b = lo + threadIdx.x; b < hi; b += 1024) {
+    const uint32_t cnt = count[b];
+    const uint32_t pos = atomicAdd(&bins[order_key(cnt, thr, shift)], 1u);
+    perm[pos] = b;
+    if (cnt > thr) heavy[atomicAdd(n_heavy, 1u)] = b;
+  }
+}
+
+// records the launches of the three ordering kernels on `st`
+static hipError_t bucket_order(const uint32_t* count, uint32_t* perm, uint32_t* heavy, uint32_t* order_bins, uint32_t total,
+                               uint32_t thr, int shift, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(order_bins, 0, sizeof(uint32_t) * ORDER_BINS, st)) != hipSuccess) return e;
+  uint32_t blocks = (total + 16383) / 16384;
+  if (blocks > 256) blocks = 256;
+  if (!blocks) blocks = 1;
+  hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(1024), 0, st, count, order_bins, total, thr, shift);
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, order_bins);
+  hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(1024), 0, st, count, order_bins, perm, heavy + 1, heavy, total, thr, shift);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -441,13 +478,14 @@ void MsmSort::release() {
   if (perm) (void)hipFree(perm);
   if (heavy) (void)hipFree(heavy);
   if (part_total) (void)hipFree(part_total);
+  if (order_bins) (void)hipFree(order_bins);
   if (blkcnt) (void)hipFree(blkcnt);
   if (rec_entry) (void)hipFree(rec_entry);
   if (rec_bkt) (void)hipFree(rec_bkt);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = order_bins = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
   has_shared = false;
 }
@@ -477,6 +515,7 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
+  if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
   if (shared_too) {
     if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
@@ -553,10 +592,8 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
                      (const uint32_t*)nullptr);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
-  hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
+  hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
   if (e0 != hipSuccess) return e0;
-  hipLaunchKernelGGL(k_bucket_order, dim3(nwin), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb, plan.heavy_thr,
-                     plan.heavy_shift);
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);
@@ -617,10 +654,8 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                      (const uint32_t*)part_total);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
-  hipError_t e0 = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
+  hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
   if (e0 != hipSuccess) return e0;
-  hipLaunchKernelGGL(k_bucket_order, dim3(P), dim3(1024), 0, st, count, perm, heavy + 1, heavy, nb, plan.heavy_thr,
-                     plan.heavy_shift);
   if (records) {
     hipLaunchKernelGGL(k_bucket_pass_rec<true>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist,
                        sorted);
