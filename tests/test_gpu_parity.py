@@ -1255,3 +1255,41 @@ def test_arkworks_fixture_if_present(ctx, zk):
     assert zk.groth16_verify(vk, wit[32 : 32 * n_pub], proof) is True
     pk.free()
     r1.free()
+
+
+def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
+    """Small domains (the relation's natural size, BASELINE config 0): the batch entry point proves up to 64 proofs as
+    ONE group (one digit sort, one accumulation launch per query, batched NTT passes).  70 proofs at N = 2^13 (two
+    groups, the second partial) must equal, byte for byte, a key that never groups (ZKMI_GROUP=1) and verify."""
+    import os
+
+    import torch
+    from test_cpu_host import _note_update_case
+
+    lg, count = 13, 70
+    r1 = zk.update_note_r1cs(lg, 1)
+    rng = ec.SplitMix64(1313)
+    toxic = frs([rng.fr() for _ in range(5)])
+    cases = [_note_update_case(zk, 4000 + i, 1, amount=1 + i % 7, balances=(100 + i, 9)) for i in range(count)]
+    bufs = [torch.zeros(32 << lg, dtype=torch.uint8, device="cuda") for _ in cases]
+    torch.cuda.synchronize()
+    for k in range(0, count, 32):
+        chunk = list(range(k, min(count, k + 32)))
+        assert ctx.update_note_witness_batch_dev(lg, 1, [cases[i][0] for i in chunk], [bufs[i].data_ptr() for i in chunk]) == [0] * len(chunk)
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(count)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(count)]
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    grouped = ctx.groth16_prove_batch_dev(pk, [b.data_ptr() for b in bufs], rs, ss)
+    pk.free()
+    os.environ["ZKMI_GROUP"] = "1"
+    try:
+        pk1, vk1 = ctx.groth16_setup(r1, toxic)
+    finally:
+        del os.environ["ZKMI_GROUP"]
+    assert vk1 == vk
+    single = ctx.groth16_prove_batch_dev(pk1, [b.data_ptr() for b in bufs], rs, ss)
+    pk1.free()
+    assert grouped == single
+    for (_, publics), pf in zip(cases, grouped):
+        assert zk.groth16_verify(vk, frs(publics), pf) is True
+    r1.free()

@@ -212,16 +212,17 @@ struct Fp28 {
   // columns (56 registers for Fq): what lets the bucket-accumulation kernels keep a third wave per SIMD.
   // Column bound: <= 2 NL products of < 2^56 (+ lazy operands, see header) + carry < 2^62.
   // sum_{i+j=k} (a1[i] b1[j] + a2[i] b2[j]) with the second pair optional (lazy a b + c d under one reduction)
-  template <bool TWO>
-  ZK_HD static Fp28 fips(const Fp28& a1, const Fp28& b1, const Fp28& a2, const Fp28& b2) {
+  // NP = number of product pairs summed under the one reduction (1, 2 or 4)
+  template <int NP>
+  ZK_HD static Fp28 fipsn(const Fp28* const* a, const Fp28* const* b) {
     int32_t m[NL];
     int64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
 #pragma unroll
       for (int i = 0; i <= k; i++) {
-        acc += (int64_t)a1.l[i] * b1.l[k - i];
-        if (TWO) acc += (int64_t)a2.l[i] * b2.l[k - i];
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc += (int64_t)a[q]->l[i] * b[q]->l[k - i];
       }
 #pragma unroll
       for (int i = 0; i < k; i++) acc += (int64_t)m[i] * P::MOD[k - i];
@@ -234,8 +235,8 @@ struct Fp28 {
     for (int k = NL; k < 2 * NL; k++) {
 #pragma unroll
       for (int i = k - NL + 1; i < NL; i++) {
-        acc += (int64_t)a1.l[i] * b1.l[k - i];
-        if (TWO) acc += (int64_t)a2.l[i] * b2.l[k - i];
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc += (int64_t)a[q]->l[i] * b[q]->l[k - i];
       }
 #pragma unroll
       for (int i = k - NL + 1; i < NL; i++) acc += (int64_t)m[i] * P::MOD[k - i];
@@ -247,6 +248,12 @@ struct Fp28 {
       }
     }
     return r;
+  }
+  template <bool TWO>
+  ZK_HD static Fp28 fips(const Fp28& a1, const Fp28& b1, const Fp28& a2, const Fp28& b2) {
+    const Fp28* a[2] = {&a1, &a2};
+    const Fp28* b[2] = {&b1, &b2};
+    return fipsn<TWO ? 2 : 1>(a, b);
   }
   ZK_HD static Fp28 mul_fips(const Fp28& a, const Fp28& b) { return fips<false>(a, b, a, b); }
   ZK_HD Fp28 sqr_fips() const {
@@ -581,7 +588,27 @@ struct Fq2P {
         for (int j = 0; j < NL; j++) T[i + j] += (int64_t)pa.l[i] * Y.l[j];
     }
   }
+  // product-scanning form of the same component: operands of the two (four) products first, then one
+  // accumulator walks the columns (field28.hpp fipsn) -- no 2 NL 64-bit columns live
+  __device__ __forceinline__ static void operands(const Fq2P& a, const Fq2P& b, bool negate, Fq28& X, Fq28& pa, Fq28& Y) {
+    const bool o = odd();
+    const Fq28 pb = partner(b.v);
+    X = sel(o, pb, b.v);
+    Y = sel(o, b.v, negl(pb));
+    if (negate) {
+      X = negl(X);
+      Y = negl(Y);
+    }
+    pa = partner(a.v);
+  }
   __device__ __forceinline__ friend Fq2P operator*(const Fq2P& a, const Fq2P& b) {
+#if defined(ZK_FIPS28)
+    {
+      Fq28 X, pa, Y;
+      operands(a, b, false, X, pa, Y);
+      return {Fq28::fips<true>(a.v, X, pa, Y)};
+    }
+#endif
     int64_t T[2 * Fq28::NL];
 #pragma unroll
     for (int i = 0; i < 2 * Fq28::NL; i++) T[i] = 0;
@@ -599,6 +626,16 @@ struct Fq2P {
 };
 // a b - c d, one reduction per lane (4 x 14 products of < 2^56 per column)
 __device__ __forceinline__ Fq2P f_mul_sub_mul(const Fq2P& a, const Fq2P& b, const Fq2P& c, const Fq2P& d) {
+#if defined(ZK_FIPS28)
+  {
+    Fq28 X1, pa, Y1, X2, pc, Y2;
+    Fq2P::operands(a, b, false, X1, pa, Y1);
+    Fq2P::operands(c, d, true, X2, pc, Y2);
+    const Fq28* A[4] = {&a.v, &pa, &c.v, &pc};
+    const Fq28* B[4] = {&X1, &Y1, &X2, &Y2};
+    return {Fq28::fipsn<4>(A, B)};
+  }
+#endif
   int64_t T[2 * Fq28::NL];
 #pragma unroll
   for (int i = 0; i < 2 * Fq28::NL; i++) T[i] = 0;

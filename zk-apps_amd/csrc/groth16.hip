@@ -21,6 +21,7 @@
 #include <string.h>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ctx.hpp"
 #include "pairing.hpp"
@@ -48,7 +49,11 @@ __device__ __forceinline__ void stv(T* p, const T& v) {
 // out[i] = <M_i, z> for i < nc; rows [nc, nc+n_pub) = z_j if is_a else 0; rest 0
 __global__ void __launch_bounds__(256)
 k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr28* __restrict__ val,
-         const Fr28* __restrict__ z, Fr28* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a) {
+         const Fr28* __restrict__ z, Fr28* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a,
+         uint32_t n_vars) {
+  // blockIdx.y = proof of a group: assignments of n_vars elements and outputs of n elements back to back
+  z += (size_t)blockIdx.y * n_vars;
+  out += (size_t)blockIdx.y * n;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr28 acc = Fr28::zero();
@@ -66,7 +71,11 @@ k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, 
 // from an assignment that fails this cannot verify; the prover reports ZKMI_ERR_UNSATISFIED instead.
 __global__ void __launch_bounds__(256)
 k_check_sat(const Fr28* __restrict__ a, const Fr28* __restrict__ b, const Fr28* __restrict__ c,
-            const Fr28* __restrict__ z, uint32_t nc, uint32_t* __restrict__ flag) {
+            const Fr28* __restrict__ z, uint32_t nc, uint32_t* __restrict__ flag, uint32_t n, uint32_t n_vars) {
+  a += (size_t)blockIdx.y * n;
+  b += (size_t)blockIdx.y * n;
+  c += (size_t)blockIdx.y * n;
+  z += (size_t)blockIdx.y * n_vars;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool bad = false;
   if (i < nc) {
@@ -144,6 +153,9 @@ using namespace zkmi;
 struct zkmi_pk {
   zkmi_ctx* ctx = nullptr;
   uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
+  // small domains: up to `gmax` proofs travel through the pipeline as ONE group (one sort, one accumulation launch
+  // per query, batched NTT passes); every per-proof buffer below holds gmax vectors back to back
+  uint32_t gmax = 1;
   uint32_t* d_rowptr[3] = {nullptr, nullptr, nullptr};
   uint32_t* d_col[3] = {nullptr, nullptr, nullptr};
   Fr28* d_val[3] = {nullptr, nullptr, nullptr};
@@ -218,14 +230,24 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->l28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28_rev, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
-  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) {
-    if ((e = hipMalloc(&pk->d_z[i], sizeof(Fr) * r->n_vars)) != hipSuccess) return e;
-    if ((e = hipMalloc(&pk->d_h[i], 32ull * N)) != hipSuccess) return e;
+  // group size: about 2^20 constraints in flight per group, at most 64 proofs; domains above 2^16 have
+  // several bucket partitions per proof and go one by one.  ZKMI_GROUP overrides (1 = never group).
+  {
+    uint32_t g = r->log_n <= 16 ? (1u << (r->log_n >= 14 ? 20 - r->log_n : 6)) : 1u;
+    if (g > 64) g = 64;
+    const char* env = getenv("ZKMI_GROUP");
+    if (env && atoi(env) >= 1 && atoi(env) <= 64 && (r->log_n <= 16 || atoi(env) == 1)) g = (uint32_t)atoi(env);
+    pk->gmax = g;
   }
-  if ((e = hipMalloc(&pk->d_zm, sizeof(Fr28) * r->n_vars)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_b, sizeof(Fr28) * N)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N)) != hipSuccess) return e;
+  const uint64_t G = pk->gmax;
+  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) {
+    if ((e = hipMalloc(&pk->d_z[i], sizeof(Fr) * r->n_vars * G)) != hipSuccess) return e;
+    if ((e = hipMalloc(&pk->d_h[i], 32ull * N * G)) != hipSuccess) return e;
+  }
+  if ((e = hipMalloc(&pk->d_zm, sizeof(Fr28) * r->n_vars * G)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * N * G)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_b, sizeof(Fr28) * N * G)) != hipSuccess) return e;
+  if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N * G)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
@@ -234,6 +256,14 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = ctx->sort_h.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
+  if (G > 1) {
+    const MsmPlan sp = msm_make_plan_shared(cap);
+    if (sp.nwin != 1) return hipErrorInvalidValue;
+    if ((e = ctx->sort.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
+    if ((e = ctx->sort_h.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
+    if ((e = ctx->g1.reserve_buckets((uint64_t)sp.nb * G)) != hipSuccess) return e;
+    if ((e = ctx->g2.reserve_buckets((uint64_t)sp.nb * G)) != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -257,6 +287,7 @@ static hipError_t pk_convert_queries(zkmi_pk* pk) {
   // and the host no longer walks a 255-doubling Horner chain.  ZKMI_MSM_SHARED=0 disables.
   const char* env = getenv("ZKMI_MSM_SHARED");
   pk->shared = !(env && env[0] == '0');
+  if (!pk->shared) pk->gmax = 1;  // groups need the digit tables (their sort emits table indices)
   if (pk->shared) {
     const uint64_t nz = pk->n_vars - 1;
     const MsmPlan pz = msm_make_plan_shared(nz), ph = msm_make_plan_shared(N);
@@ -522,29 +553,32 @@ int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, ui
 // The witness lands in pk->d_z on the main stream (the digit sort of the A/B/L MSMs reads it
 // there); everything downstream of it (limb conversion, mat-vec, NTTs -> d_h) runs on `st`,
 // which the prover points at its front stream so that it overlaps the z-MSMs.
-static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z_in,
+// A group of G >= 1 witnesses (src[b]: host pointers if `host`, device pointers otherwise) goes through the map
+// together: the vectors lie back to back in the ring buffers, every kernel takes the group as a batch dimension.
+static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G,
                                hipStream_t st, int par = 0) {
   const uint32_t N = 1u << pk->log_n, nv = pk->n_vars;
   PhaseTimer* t = ctx->timer();
   // The copy runs on the copy stream: with a pinned host witness the upload of proof i+1 (32 B per variable
   // over PCIe) proceeds while the compute streams still work on proofs i-1 and i; the ring of witness
   // buffers makes that safe.  Canonicity (< r) is checked on the device, not in a host loop.
-  ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par], z ? static_cast<const void*>(z) : d_z_in, 32ull * nv,
-                             z ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream_copy));
+  for (uint32_t b = 0; b < G; b++)
+    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par] + (size_t)b * nv, src[b], 32ull * nv,
+                               host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream_copy));
   ZK_HIP(ctx, hipEventRecord(ctx->ev_z[par], ctx->stream_copy));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_z[par], 0));
   if (st != ctx->stream) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z[par], 0));
   if (t) t->begin(PH_WITNESS, st);
   ZK_HIP(ctx, hipMemsetAsync(pk->d_unsat + par, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(k_check_canonical, dim3((nv + 255) / 256), dim3(256), 0, st,
-                     reinterpret_cast<const uint32_t*>(pk->d_z[par]), nv, pk->d_unsat + par);
-  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, nv, st));
+  hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const uint32_t*>(pk->d_z[par]), G * nv, pk->d_unsat + par);
+  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, G * nv, st));
   Fr28* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
   for (int m = 0; m < 3; m++)
-    hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
-                       pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0);
-  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, pk->d_zm, pk->nc,
-                     pk->d_unsat + par);
+    hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256, G), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
+                       pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0, nv);
+  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256, G), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, pk->d_zm, pk->nc,
+                     pk->d_unsat + par, N, nv);
   ZK_HIP(ctx, hipMemcpyAsync(pk->h_unsat + par, pk->d_unsat + par, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   if (t) t->end(PH_WITNESS, st);
   hipError_t e;
@@ -553,17 +587,17 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   if (t) t->begin(PH_NTT, st);
   // evaluations -> coefficients (bit-reversed, scaled by g^i / N) -> evaluations on the coset
   for (int m = 0; m < 3; m++) {
-    ZK_HIP(ctx, dom->inverse_to_rev(outv[m], dom->rev_coset_n, nullptr, st));
-    ZK_HIP(ctx, dom->forward_from_rev(outv[m], st));
+    ZK_HIP(ctx, dom->inverse_to_rev(outv[m], dom->rev_coset_n, nullptr, st, G));
+    ZK_HIP(ctx, dom->forward_from_rev(outv[m], st, G));
   }
   // 1 / Z(g) with Z(g) = g^N - 1, g = 7
   Fr gn = fr_from_u64(7);
   for (uint32_t i = 0; i < pk->log_n; i++) gn = gn.sqr();
   const Fr zinv = (gn - Fr::one()).inv().from_mont();
   const Fr28 zinv28 = Fr28::from_canonical(zinv.l);
-  hipLaunchKernelGGL(k_quotient, dim3((N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv28, N);
+  hipLaunchKernelGGL(k_quotient, dim3((G * N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv28, G * N);
   // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
-  ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h[par], st));
+  ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h[par], st, G));
   if (t) t->end(PH_NTT, st);
   if (st != ctx->stream) ZK_HIP(ctx, hipEventRecord(ctx->ev_h[par], st));
   ZK_HIP(ctx, hipGetLastError());
@@ -573,7 +607,8 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h) {
   ZK_ENTER(ctx);
   if (!ctx || !pk || !z || !out_h) return ZKMI_ERR_BAD_ARG;
-  int32_t rc = witness_map_dev(ctx, pk, z, nullptr, ctx->stream);
+  const void* src[1] = {z};
+  int32_t rc = witness_map_dev(ctx, pk, src, true, 1, ctx->stream);
   if (rc != ZKMI_OK) return rc;
   const uint32_t N = 1u << pk->log_n;
   std::vector<uint8_t> rev(32ull * N);
@@ -596,11 +631,11 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
 // consumer of the NTTs, and the NTT kernels (1024-thread blocks, 100 KB of LDS) only get workgroup
 // slots in the gaps the accumulation kernels leave, so h arrives late; with the halves interleaved the
 // main stream always has a full accumulation to run instead of waiting for it.
-static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const void* d_z, int par) {
+static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par) {
   const uint32_t nv = pk->n_vars;
   hipStream_t st = ctx->stream;
   // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the MSMs over z
-  int32_t rc = witness_map_dev(ctx, pk, z, d_z, ctx->stream_front, par);
+  int32_t rc = witness_map_dev(ctx, pk, src, host, G, ctx->stream_front, par);
   if (rc != ZKMI_OK) return rc;
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
@@ -612,7 +647,9 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z[par] + 1);
   const bool sh = pk->shared;
-  if (sh)
+  if (G > 1)  // one digit sort for the whole group: bucket set b belongs to witness b (msm_sort.hip run_shared_batch)
+    ZK_HIP(ctx, ctx->sort.run_shared_batch(zs, nv - 1, 8ull * nv, G, st, t));
+  else if (sh)
     ZK_HIP(ctx, ctx->sort.run_shared(zs, nv - 1, st, t));
   else
     ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
@@ -633,7 +670,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* 
   return ZKMI_OK;
 }
 
-static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, int par) {
+static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int par) {
   const uint32_t N = 1u << pk->log_n;
   hipStream_t st = ctx->stream;
   PhaseTimer* t = ctx->timer();
@@ -644,7 +681,9 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, int par) {
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
   // infinity.  Own sort buffers (ctx->sort_h): the G2 accumulation of the NEXT proof may still be reading
   // the z sort when this runs.
-  if (sh)
+  if (G > 1)
+    ZK_HIP(ctx, ctx->sort_h.run_shared_batch(pk->d_h[par], N, 8ull * N, G, st, t));
+  else if (sh)
     ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], N, st, t));
   else
     ZK_HIP(ctx, ctx->sort_h.run(pk->d_h[par], N, st, t));
@@ -655,19 +694,9 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, int par) {
 
 // Host part: wait for the slot set's partials, combine windows, assemble A, B, C
 //  and compress.  The GPU may already be running the next proof.
-static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t r_bytes[32], const uint8_t s_bytes[32],
-                            int par, uint8_t out_proof[192]) {
-  const int s0 = 4 * par, g2s = par;
-  G1XYZZ acc_a, acc_b1, acc_l, acc_h;
-  G2XYZZ acc_b2;
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_a, s0 + 0));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1, s0 + 1));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_l, s0 + 2));
-  ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2, g2s));
-  ZK_HIP(ctx, ctx->g1.finish_host(&acc_h, s0 + 3));
-  // the flag copy precedes the h coefficients on the front stream, which the H MSM waited for
-  if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
-  if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+// A, B, C of one proof from its five MSM results + compression; pure host arithmetic
+static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G1XYZZ& acc_l, const G1XYZZ& acc_h,
+                           const G2XYZZ& acc_b2, const uint8_t r_bytes[32], const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   uint32_t rk[8], sk[8], rsk[8];
   memcpy(rk, r_bytes, 32);
   memcpy(sk, s_bytes, 32);
@@ -696,6 +725,49 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t r_by
   g1_compress(g_a.to_affine(), out_proof);
   g2_compress(g2_b.to_affine(), out_proof + 48);
   g1_compress(g_c.to_affine(), out_proof + 144);
+}
+
+// Host part: wait for the slot set's partials, combine windows, assemble and compress the G proofs of the group
+// (on several host threads when G > 1).  The GPU may already be running the next group.
+static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_bytes, const uint8_t* s_bytes, uint32_t G,
+                            int par, uint8_t* out_proofs) {
+  const int s0 = 4 * par, g2s = par;
+  std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
+  std::vector<G2XYZZ> acc_b2(G);
+  if (G == 1) {
+    ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
+    ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
+    ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
+    ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+    ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3));
+  } else {
+    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
+    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
+    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_l.data(), s0 + 2));
+    ZK_HIP(ctx, ctx->g2.finish_host_batch(acc_b2.data(), g2s));
+    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_h.data(), s0 + 3));
+  }
+  // the flag copy precedes the h coefficients on the front stream, which the H MSM waited for
+  if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+  if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+  auto one = [&](uint32_t b) {
+    assemble_proof(pk, acc_a[b], acc_b1[b], acc_l[b], acc_h[b], acc_b2[b], r_bytes + 32ull * b, s_bytes + 32ull * b,
+                   out_proofs + 192ull * b);
+  };
+  if (G == 1) {
+    one(0);
+  } else {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if (nt > G) nt = G;
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++)
+      th.emplace_back([&, k]() {
+        for (uint32_t b = k; b < G; b += nt) one(b);
+      });
+    for (auto& x : th) x.join();
+  }
   return ZKMI_OK;
 }
 
@@ -703,10 +775,11 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
                           const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
   if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
-  int32_t rc = prove_enqueue_z(ctx, pk, z, d_z, 0);
-  if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 0);
+  const void* src[1] = {z ? static_cast<const void*>(z) : d_z};
+  int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0);
+  if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0);
   if (rc != ZKMI_OK) return rc;
-  return prove_finish(ctx, pk, r_bytes, s_bytes, 0, out_proof);
+  return prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
 }
 
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
@@ -745,25 +818,28 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
     ctx->err = msg;
     return code;
   };
-  auto finish = [&](uint32_t i) {
-    return prove_finish(ctx, pk, r_bytes + 32ull * i, s_bytes + 32ull * i, (int)(i % RING), out_proofs + 192ull * i);
+  // units of the pipeline = groups of up to pk->gmax proofs (1 above 2^16 constraints)
+  const uint32_t gsz = pk->gmax;
+  const uint32_t n_groups = (n_proofs + gsz - 1) / gsz;
+  auto first = [&](uint32_t g) { return g * gsz; };
+  auto count = [&](uint32_t g) { return (first(g) + gsz <= n_proofs) ? gsz : n_proofs - first(g); };
+  auto finish = [&](uint32_t g) {
+    return prove_finish(ctx, pk, r_bytes + 32ull * first(g), s_bytes + 32ull * first(g), count(g), (int)(g % RING),
+                        out_proofs + 192ull * first(g));
   };
-  auto enqueue_z = [&](uint32_t i) {
-    return host ? prove_enqueue_z(ctx, pk, static_cast<const uint8_t*>(d_z[i]), nullptr, (int)(i % RING))
-                : prove_enqueue_z(ctx, pk, nullptr, d_z[i], (int)(i % RING));
-  };
+  auto enqueue_z = [&](uint32_t g) { return prove_enqueue_z(ctx, pk, d_z + first(g), host, count(g), (int)(g % RING)); };
   int32_t rc = enqueue_z(0);
   if (rc != ZKMI_OK) return bail(rc);
-  for (uint32_t i = 0; i < n_proofs; i++) {
-    if (i + 1 < n_proofs) {
-      rc = enqueue_z(i + 1);
+  for (uint32_t g = 0; g < n_groups; g++) {
+    if (g + 1 < n_groups) {
+      rc = enqueue_z(g + 1);
       if (rc != ZKMI_OK) return bail(rc);
     }
-    rc = prove_enqueue_h(ctx, pk, (int)(i % RING));
+    rc = prove_enqueue_h(ctx, pk, count(g), (int)(g % RING));
     if (rc != ZKMI_OK) return bail(rc);
-    if (i >= 1 && (rc = finish(i - 1)) != ZKMI_OK) return bail(rc);  // frees slot set (i - 1) % RING = (i + 2) % RING
+    if (g >= 1 && (rc = finish(g - 1)) != ZKMI_OK) return bail(rc);  // frees slot set (g - 1) % RING = (g + 2) % RING
   }
-  if ((rc = finish(n_proofs - 1)) != ZKMI_OK) return bail(rc);
+  if ((rc = finish(n_groups - 1)) != ZKMI_OK) return bail(rc);
   return ZKMI_OK;
 }
 

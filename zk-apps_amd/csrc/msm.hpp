@@ -90,6 +90,10 @@ struct MsmSort {
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
   // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
   hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
+  // `batch` scalar vectors over the same bases, one bucket set each (small domains: msm_sort.hip)
+  hipError_t run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint64_t stride_words, uint32_t batch, hipStream_t st,
+                              PhaseTimer* prof);
+  hipError_t reserve_batch(uint64_t n, uint32_t batch);
 };
 
 hipError_t msm_sort_enable_big_lds();  // per device, see msm_sort.hip
@@ -120,10 +124,12 @@ struct MsmEngine {
   uint32_t* redo = nullptr;           // [0] = count, [1..] = buckets a call-free accumulation kernel left to k_accum_redo
   MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
+  uint64_t min_buckets = 0;  // floor set by reserve_buckets
   ~MsmEngine() { release(); }
   void release();
   bool has_shared = false;
   hipError_t reserve(uint64_t n, bool shared_too = false);
+  hipError_t reserve_buckets(uint64_t buckets);  // at least this many buckets per slot
   // device part: bucket accumulation + reduction down to per-window partials,
   // async copy of the partials to the host and an event; does not block
   // accumulation runs on `st`; the (low-occupancy, latency-bound) reduction runs on
@@ -137,6 +143,8 @@ struct MsmEngine {
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
   hipError_t finish_host_windows(XYZZ<HF>* out_windows, int slot = 0);
+  // batched shared sort (MsmSort::run_shared_batch): one result per scalar vector
+  hipError_t finish_host_batch(XYZZ<HF>* out, int slot = 0);
 };
 
 // host-format affine points (Montgomery, R = 2^384) -> device format (R = 2^392 limbs)

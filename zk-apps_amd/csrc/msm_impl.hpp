@@ -39,7 +39,10 @@ namespace zkmi {
 static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
 #ifndef ZKMI_ACCUM_DEFAULT
-#define ZKMI_ACCUM_DEFAULT 0
+#define ZKMI_ACCUM_DEFAULT 3
+#endif
+#ifndef ZKMI_ACCUM_G2_DEFAULT
+#define ZKMI_ACCUM_G2_DEFAULT 2
 #endif
 #ifndef ZKMI_ACCUM_BLOCK_DEFAULT
 #define ZKMI_ACCUM_BLOCK_DEFAULT 64
@@ -222,27 +225,15 @@ k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __res
 // listed buckets with the complete addition afterwards.  The list holds bucket ids, so it cannot
 // overflow (capacity = number of buckets).
 // ---------------------------------------------------------------------------------------------
-// returns false when acc + p is a doubling (acc left untouched)
+// acc += p for acc != O, p != O; returns false when the sum needs the complete group law (p = +-acc):
+// the caller hands the bucket to k_accum_redo.  No state besides acc: the loop around it has one path.
 template <class F>
-__device__ __forceinline__ bool madd_nocall(XYZZ<F>& acc, bool& inf, const Affine<F>& p) {
-  if (p.is_inf()) return true;
-  if (inf) {
-    acc.x = p.x;
-    acc.y = p.y;
-    acc.zz = F::one();
-    acc.zzz = F::one();
-    inf = false;
-    return true;
-  }
+__device__ __forceinline__ bool madd_generic(XYZZ<F>& acc, const Affine<F>& p) {
   F pp_ = f_sub_lazy(p.x * acc.zz, acc.x);
   F r = f_sub_lazy(p.y * acc.zzz, acc.y);
   F pp = pp_.sqr();
   F rr = r.sqr();
-  if (pp.is_zero()) {
-    if (rr.is_zero()) return false;
-    inf = true;  // P + (-P)
-    return true;
-  }
+  if (pp.is_zero()) return false;
   F ppp = pp_ * pp;
   acc.zz = acc.zz * pp;
   acc.zzz = acc.zzz * ppp;
@@ -251,18 +242,26 @@ __device__ __forceinline__ bool madd_nocall(XYZZ<F>& acc, bool& inf, const Affin
   acc.y = f_mul_sub_mul(r, f_sub_lazy(q, acc.x), acc.y, ppp);
   return true;
 }
+// device table entries at infinity are exact zeros (k_bases_convert, k_build_table)
+template <class P>
+__device__ __forceinline__ bool affine_is_zero_words(const Affine<Fp28<P>>& p) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < P::NL; i++) o |= (uint32_t)p.x.l[i] | (uint32_t)p.y.l[i];
+  return o == 0;
+}
 
 // G1 (and BN254 G1): thread per bucket, next table entry prefetched through ONE LDS buffer per wave
 // (the entry is read into registers at the top of the iteration, so the buffer is free for the next
-// direct-to-LDS load straight away): 28 KB per 256-thread block.
-template <class F, int W>
-__global__ void __launch_bounds__(256, W)
+// direct-to-LDS load straight away): 7 KB per wave.
+template <class F, int W, int BW>
+__global__ void __launch_bounds__(64 * BW, W)
 k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
               const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
               uint32_t heavy_thr, uint32_t* __restrict__ redo) {
   constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
-  __shared__ uint4 tile[4][CHUNKS][64];           // [wave][chunk][lane]
+  __shared__ uint4 tile[BW][CHUNKS][64];          // [wave][chunk][lane]
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (t >= total_buckets) return;
@@ -270,48 +269,65 @@ k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
   const uint32_t cnt = count[b];
   if (cnt > heavy_thr) return;  // k_accum_heavy owns it
   const uint32_t beg = begin[b], end = beg + cnt;
-  XYZZ<F> acc = XYZZ<F>::infinity();
-  bool inf = true;
   auto fetch = [&](uint32_t v) {
     const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
 #pragma unroll
     for (int q = 0; q < CHUNKS; q++)
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[wave][q][0], 16, 0, 0);
   };
-  uint32_t v_cur = 0, v_next = 0;
-  if (cnt) {
-    v_cur = sorted[beg];
-    fetch(v_cur);
-    if (cnt > 1) v_next = sorted[beg + 1];
-  }
-  for (uint32_t j = beg; j < end; j++) {
-    // the compiler waits for the outstanding LDS-DMA (vmcnt) before these LDS reads
-    Affine<F> p;
+  auto take = [&](Affine<F>& p) {  // LDS -> registers; the compiler waits for the outstanding LDS-DMA first
     uint4* d = reinterpret_cast<uint4*>(&p);
 #pragma unroll
     for (int q = 0; q < CHUNKS; q++) d[q] = tile[wave][q][lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have left the LDS: the buffer may be refilled
+  };
+  XYZZ<F> acc;
+  uint32_t j = beg;
+  // first entry that is not the point at infinity starts the accumulator (plain loads: runs once per bucket)
+  for (;; j++) {
+    if (j >= end) {
+      store_vec(buckets + b, XYZZ<F>::infinity());
+      return;
+    }
+    const uint32_t v = sorted[j];
+    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+    if (affine_is_zero_words(p)) continue;
+    if (v >> 31) p.y = p.y.neg();
+    acc.x = p.x;
+    acc.y = p.y;
+    acc.zz = F::one();
+    acc.zzz = F::one();
+    j++;
+    break;
+  }
+  uint32_t v_cur = 0, v_next = 0;
+  if (j < end) {
+    v_cur = sorted[j];
+    fetch(v_cur);
+    if (j + 1 < end) v_next = sorted[j + 1];
+  }
+  for (; j < end; j++) {
+    Affine<F> p;
+    take(p);
     const uint32_t v = v_cur;
     if (j + 1 < end) {
-      // the reads above must have left the LDS before the buffer is refilled
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       fetch(v_next);
       v_cur = v_next;
       if (j + 2 < end) v_next = sorted[j + 2];
     }
+    if (affine_is_zero_words(p)) continue;
     if (v >> 31) p.y = p.y.neg();
-    if (!madd_nocall(acc, inf, p)) {
-      redo[1 + atomicAdd(redo, 1u)] = b;
-      return;  // the bucket is recomputed by k_accum_redo
+    if (!madd_generic(acc, p)) {
+      redo[1 + atomicAdd(redo, 1u)] = b;  // doubling or cancellation: k_accum_redo recomputes the bucket
+      return;
     }
   }
-  if (inf) acc = XYZZ<F>::infinity();
   store_vec(buckets + b, acc);
 }
 
 // G2, lane pair per bucket (see k_accum_g2_split)
-template <int W>
-__global__ void __launch_bounds__(256, W)
+template <int W, int BW>
+__global__ void __launch_bounds__(64 * BW, W)
 k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
               const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets, uint32_t total_buckets,
@@ -323,22 +339,44 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
   const uint32_t cnt = count[b];
   if (cnt > heavy_thr) return;
   const uint32_t beg = begin[b], end = beg + cnt;
-  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-  bool inf = true;
-  for (uint32_t j = beg; j < end; j++) {
-    const uint32_t v = sorted[j];
+  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+  auto load_point = [&](uint32_t v, Affine<Fq2P>& p) {
     const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
-    Affine<Fq2P> p;
     p.x.v = ld_comp(src + comp);
     p.y.v = ld_comp(src + 2 + comp);
+    // infinity = all four components exact zeros: OR of this lane's words, combined with the partner's
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) o |= (uint32_t)p.x.v.l[i] | (uint32_t)p.y.v.l[i];
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
     if (v >> 31) p.y = p.y.neg();
-    if (!madd_nocall(acc, inf, p)) {  // pair-uniform (Fq2P::is_zero exchanges the halves)
+    return o == 0;
+  };
+  XYZZ<Fq2P> acc;
+  uint32_t j = beg;
+  for (;; j++) {
+    if (j >= end) {
+      const Fq28 z = Fq28::zero();
+      for (int k = 0; k < 4; k++) st_comp(dst + 2 * k + comp, z);
+      return;
+    }
+    Affine<Fq2P> p;
+    if (load_point(sorted[j], p)) continue;
+    acc.x = p.x;
+    acc.y = p.y;
+    acc.zz = Fq2P::one();
+    acc.zzz = Fq2P::one();
+    j++;
+    break;
+  }
+  for (; j < end; j++) {
+    Affine<Fq2P> p;
+    if (load_point(sorted[j], p)) continue;
+    if (!madd_generic(acc, p)) {  // pair-uniform (Fq2P::is_zero exchanges the halves)
       if (comp == 0) redo[1 + atomicAdd(redo, 1u)] = b;
       return;
     }
   }
-  if (inf) acc = XYZZ<Fq2P>::infinity();
-  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);
   st_comp(dst + comp, acc.x.v);
   st_comp(dst + 2 + comp, acc.y.v);
   st_comp(dst + 4 + comp, acc.zz.v);
@@ -569,8 +607,19 @@ void MsmEngine<F>::release() {
 uint64_t msm_max_buckets(uint64_t n);
 
 template <class F>
+hipError_t MsmEngine<F>::reserve_buckets(uint64_t buckets) {
+  if (buckets <= cap_buckets) return hipSuccess;
+  const bool sh = has_shared;
+  release();
+  has_shared = sh;
+  min_buckets = buckets;
+  return reserve(1, sh);
+}
+
+template <class F>
 hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   uint64_t need = msm_max_buckets(n);
+  if (need < min_buckets) need = min_buckets;
   const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);  // plan_override = 16 for any n
   if (need < forced) need = forced;
   shared_too = shared_too || has_shared;
@@ -631,7 +680,13 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     const char* e = getenv("ZKMI_ACCUM");
     return e ? atoi(e) : ZKMI_ACCUM_DEFAULT;
   }();
-  const bool nocall = accum_mode == 2 || accum_mode == 3;
+  // the G2 kernel has its own switch (its lane-split additions need more registers per lane than G1's)
+  static const int accum_mode_g2 = [] {
+    const char* e = getenv("ZKMI_ACCUM_G2");
+    return e ? atoi(e) : ZKMI_ACCUM_G2_DEFAULT;
+  }();
+  const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
+  const bool nocall = mode == 2 || mode == 3;
   // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
   // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
   static const int accum_block = [] {
@@ -651,12 +706,12 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     const dim3 grid((2 * tot_b + T - 1) / T);
-    if (accum_mode == 3)
-      hipLaunchKernelGGL(k_accum_g2_nc<3>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk,
-                         tot_b, pl.heavy_thr, redo);
-    else if (accum_mode == 2)
-      hipLaunchKernelGGL(k_accum_g2_nc<2>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk,
-                         tot_b, pl.heavy_thr, redo);
+    if (mode == 3)
+      hipLaunchKernelGGL((k_accum_g2_nc<3, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
+                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
+    else if (mode == 2)
+      hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
+                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
     else if (accum_block == 64)
       hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases, sort.begin, sort.count,
                          sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
@@ -666,11 +721,11 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   } else {
     const dim3 grid((tot_b + T - 1) / T);
     if (accum_mode == 3)
-      hipLaunchKernelGGL((k_accum_g1_nc<F, 3>), grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
-                         bk, tot_b, pl.heavy_thr, redo);
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
+                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
     else if (accum_mode == 2)
-      hipLaunchKernelGGL((k_accum_g1_nc<F, 2>), grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted,
-                         bk, tot_b, pl.heavy_thr, redo);
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
+                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
     else if (accum_mode == 1)
       hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
                          pl.heavy_thr);
@@ -745,6 +800,13 @@ hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
     out_windows[w] = u;
   }
   return hipSuccess;
+}
+
+template <class F>
+hipError_t MsmEngine<F>::finish_host_batch(XYZZ<HF>* out, int slot) {
+  // every "window" of the batched plan is the complete single-partition bucket set of one scalar vector:
+  // sum_b (b + 1) B_b is that vector's MSM
+  return finish_host_windows(out, slot);
 }
 
 template <class HF>

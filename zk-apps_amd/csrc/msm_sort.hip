@@ -82,9 +82,14 @@ k_bucket_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, uint32_t 
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024)
 k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log,
-                     uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted) {
+                     uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted,
+                     uint64_t batch_stride_words) {
   extern __shared__ uint32_t hist[];
   const uint32_t ch = blockIdx.x, q = blockIdx.y, nch = gridDim.x;
+  // batch mode (batch_stride_words != 0): blockIdx.y is the index of an independent scalar vector whose whole
+  // (single-partition) bucket set is "partition" q of the combined bucket array; table indices are per vector
+  const bool batched = batch_stride_words != 0;
+  if (batched) scalars += (size_t)q * batch_stride_words;
   uint32_t* gh = blockhist + ((size_t)q * nch + ch) * nb;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
   __syncthreads();
@@ -98,7 +103,7 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
       const uint32_t d = digit_of(k, w, c, neg);
       if (d == 0) continue;
       const uint32_t bkt = d - 1;
-      if ((bkt >> nb_log) != q) continue;
+      if (!batched && (bkt >> nb_log) != q) continue;
       const uint32_t local = bkt & (nb - 1u);
       if (SCATTER) {
         const uint32_t pos = atomicAdd(&hist[local], 1u);
@@ -646,7 +651,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                        sorted);
   } else {
     hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
-                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted);
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0);
   }
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
   if (!records) hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
@@ -661,10 +666,102 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                        sorted);
   } else {
     hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
-                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted);
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0);
   }
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
+}
+
+// Shared-bucket sort of `batch` independent scalar vectors of n elements each (vector b starts at
+// d_scalars + b * stride_words) over the SAME bases: one bucket set per vector, laid out as the partitions of one
+// combined plan (plan.nwin = batch), so that a single accumulation / reduction launch serves the whole batch.
+// Only for vectors whose own plan has one partition (n <= 2^16).  Buffers must have been reserved for it.
+hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint64_t stride_words, uint32_t batch, hipStream_t st,
+                                     PhaseTimer* prof) {
+  {
+    const hipError_t er = wait_readers(st);
+    if (er != hipSuccess) return er;
+  }
+  plan = msm_make_plan_shared(n);
+  if (plan.nwin != 1 || batch == 0 || batch > 64) return hipErrorInvalidValue;
+  plan.nwin = (int)batch;
+  plan_set_heavy(plan, n * (uint64_t)plan.ndigits * batch);
+  const uint32_t nb = plan.nb, P = batch;
+  int nb_log = 0;
+  while ((1u << nb_log) < nb) nb_log++;
+  const uint32_t tot_b = P * nb;
+  uint32_t nch = (512 + P - 1) / P;  // ~2 tiles per CU over the whole batch
+  const uint64_t max_by_n = (n + 1023) / 1024;
+  if (nch > max_by_n) nch = (uint32_t)(max_by_n ? max_by_n : 1);
+  const uint32_t chunk = (uint32_t)((n + nch - 1) / nch);
+  if ((uint64_t)plan.ndigits * n * batch > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist)
+    return hipErrorInvalidValue;
+  RecodeConst rc;
+  for (int j = 0; j < 9; j++) rc.m[j] = 0;
+  for (int w = 0; w < plan.ndigits; w++) {
+    const uint64_t v = (1ull << (plan.c - 1)) - 1;
+    const int bit = w * plan.c, limb = bit >> 5, sh = bit & 31;
+    if (limb < 9) {
+      uint64_t carry = v << sh;
+      for (int j = limb; j < 9 && carry; j++) {
+        const uint64_t sum = (uint64_t)rc.m[j] + (uint32_t)carry;
+        rc.m[j] = (uint32_t)sum;
+        carry = (carry >> 32) + (sum >> 32);
+      }
+    }
+  }
+  if (prof) prof->begin(PH_MSM_SORT, st);
+  const size_t lds = sizeof(uint32_t) * nb;
+  const dim3 grid(nch, P);
+  hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
+                     nb_log, chunk, rc, blockhist, sorted, stride_words);
+  hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
+  hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
+  hipLaunchKernelGGL(k_window_scan, dim3(P), dim3(1024), 0, st, count, begin, nb, (uint32_t)n, (const uint32_t*)part_total);
+  const uint32_t tot_h = tot_b * nch;
+  hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
+  hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
+  if (e0 != hipSuccess) return e0;
+  hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
+                     nb_log, chunk, rc, blockhist, sorted, stride_words);
+  if (prof) prof->end(PH_MSM_SORT, st);
+  return hipGetLastError();
+}
+
+// room for run_shared_batch(n, batch) on top of what reserve() provides
+hipError_t MsmSort::reserve_batch(uint64_t n, uint32_t batch) {
+  const MsmPlan sp = msm_make_plan_shared(n);
+  if (sp.nwin != 1) return hipErrorInvalidValue;
+  const uint64_t ne = (uint64_t)sp.ndigits * n * batch, nbk = (uint64_t)sp.nb * batch;
+  uint64_t nch = (512 + batch - 1) / batch;
+  const uint64_t mx = (n + 1023) / 1024;
+  if (nch > mx) nch = mx ? mx : 1;
+  const uint64_t nh = nbk * nch;
+  if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
+  // grow: re-run reserve with synthetic sizes (keeps the record buffers of the shared plan)
+  const uint64_t want_e = ne > cap_entries ? ne : cap_entries, want_b = nbk > cap_buckets ? nbk : cap_buckets,
+                 want_h = nh > cap_hist ? nh : cap_hist;
+  const bool shared = has_shared;
+  release();
+  hipError_t e;
+  if ((e = hipMalloc(&count, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
+  if ((e = hipMalloc(&begin, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
+  if ((e = hipMalloc(&perm, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
+  if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
+  if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
+  if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
+  if (shared) {
+    if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
+    if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
+  }
+  has_shared = shared;
+  if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (want_b + 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * want_h)) != hipSuccess) return e;
+  if ((e = hipMalloc(&sorted, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
+  cap_entries = want_e;
+  cap_buckets = want_b;
+  cap_hist = want_h;
+  return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------

@@ -59,6 +59,9 @@ template <class F, bool DIF, bool LOCAL_TW, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
            const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
+  // blockIdx.y = transform of a batch: vectors of 2^log_n elements laid out back to back (same for canon_out)
+  data += (size_t)blockIdx.y << log_n;
+  if (canon_out) canon_out += ((size_t)blockIdx.y << log_n) * 8;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   F* tile = reinterpret_cast<F*>(lds_raw);
   const uint32_t tile_n = 1u << (S + Q);
@@ -276,7 +279,7 @@ hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
 // covers the low stages first, of a DIF transform the high stages first
 template <class F, bool DIF>
 static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
-                             hipStream_t stream) {
+                             hipStream_t stream, uint32_t batch = 1) {
   const uint32_t n = 1u << log_n;
   struct Pass {
     int t0, S, Q;
@@ -302,16 +305,16 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     uint32_t* co = last ? canon_out : nullptr;
     if (tile_n >= 1024) {
       if (local_tw)
-        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), dim3(nblk, batch), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
                            p.Q, pp, co);
       else
-        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 1024>), dim3(nblk), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 1024>), dim3(nblk, batch), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
                            p.S, p.Q, pp, co);
     } else if (local_tw) {
-      hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 64>), dim3(nblk, batch), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     } else {
-      hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 64>), dim3(nblk), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 64>), dim3(nblk, batch), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     }
   }
@@ -319,20 +322,21 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
 }
 
 template <class F>
-hipError_t NttDomainT<F>::inverse_to_rev(F* d, const F* post_table, uint32_t* canon_out, hipStream_t st) {
+hipError_t NttDomainT<F>::inverse_to_rev(F* d, const F* post_table, uint32_t* canon_out, hipStream_t st, uint32_t batch) {
   if (log_n == 0) {
+    if (batch != 1) return hipErrorInvalidValue;
     // single element: only the post factor / output format applies
     if (post_table) hipLaunchKernelGGL(k_mul_table<F>, dim3(1), dim3(256), 0, st, d, post_table, 1u);
     if (canon_out) hipLaunchKernelGGL(k_to_canonical<F>, dim3(1), dim3(256), 0, st, d, canon_out, 1u);
     return hipGetLastError();
   }
-  return run_passes<F, true>(d, tw_inv, log_n, post_table, canon_out, st);
+  return run_passes<F, true>(d, tw_inv, log_n, post_table, canon_out, st, batch);
 }
 
 template <class F>
-hipError_t NttDomainT<F>::forward_from_rev(F* d, hipStream_t st) {
+hipError_t NttDomainT<F>::forward_from_rev(F* d, hipStream_t st, uint32_t batch) {
   if (log_n == 0) return hipSuccess;
-  return run_passes<F, false>(d, tw_fwd, log_n, nullptr, nullptr, st);
+  return run_passes<F, false>(d, tw_fwd, log_n, nullptr, nullptr, st, batch);
 }
 
 // natural order in and out (public entry point)

@@ -58,8 +58,9 @@ struct NttDomainT {
   //   inverse_to_rev : evaluations (natural) -> coefficients in bit-reversed order, each
   //                    multiplied by post_table[position]; optionally written as canonical words
   //   forward_from_rev: coefficients in bit-reversed order -> evaluations (natural)
-  hipError_t inverse_to_rev(F* d, const F* post_table, uint32_t* canon_out, hipStream_t st);
-  hipError_t forward_from_rev(F* d, hipStream_t st);
+  // batch > 1: `batch` vectors of 2^log_n elements back to back in d (and in canon_out), one launch per pass
+  hipError_t inverse_to_rev(F* d, const F* post_table, uint32_t* canon_out, hipStream_t st, uint32_t batch = 1);
+  hipError_t forward_from_rev(F* d, hipStream_t st, uint32_t batch = 1);
 };
 
 using NttDomain = NttDomainT<Fr28>;      // the prover's domain
