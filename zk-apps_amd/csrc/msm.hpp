@@ -125,8 +125,12 @@ struct MsmEngine {
   MsmPlan slot_plan[SLOTS];
   uint64_t cap_buckets = 0;
   uint64_t min_buckets = 0;  // floor set by reserve_buckets
-  ~MsmEngine() { release(); }
-  void release();
+  ~MsmEngine() {
+    release();
+    destroy_events();
+  }
+  void release();         // frees the buffers (a re-allocation may follow); events stay valid
+  void destroy_events();
   bool has_shared = false;
   hipError_t reserve(uint64_t n, bool shared_too = false);
   hipError_t reserve_buckets(uint64_t buckets);  // at least this many buckets per slot

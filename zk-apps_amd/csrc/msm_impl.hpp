@@ -591,20 +591,25 @@ void MsmEngine<F>::release() {
   if (redo) (void)hipFree(redo);
   redo = nullptr;
   if (h_partial) (void)hipHostFree(h_partial);
-  for (int i = 0; i < SLOTS; i++) {
-    if (done[i]) (void)hipEventDestroy(done[i]);
-    if (acc_done[i]) (void)hipEventDestroy(acc_done[i]);
-    if (pre[i]) (void)hipEventDestroy(pre[i]);
-    if (heavy_done[i]) (void)hipEventDestroy(heavy_done[i]);
-    if (redo_done[i]) (void)hipEventDestroy(redo_done[i]);
-    done[i] = acc_done[i] = pre[i] = heavy_done[i] = redo_done[i] = nullptr;
-  }
+  // the events outlive a re-allocation: MsmSort::readers may still hold some of them (destroy_events() runs
+  // from the destructor only)
   buckets = segsum = segw = nullptr;
   partial = h_partial = nullptr;
   cap_buckets = 0;
 }
 
 uint64_t msm_max_buckets(uint64_t n);
+
+template <class F>
+void MsmEngine<F>::destroy_events() {
+  for (int i = 0; i < SLOTS; i++) {
+    hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
+    for (hipEvent_t* e : evs) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
+  }
+}
 
 template <class F>
 hipError_t MsmEngine<F>::reserve_buckets(uint64_t buckets) {
@@ -637,14 +642,12 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT)) != hipSuccess) return e;
-  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * SLOTS)) != hipSuccess) return e;  // one list per slot
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
-    if ((e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&acc_done[i], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&pre[i], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&heavy_done[i], hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&redo_done[i], hipEventDisableTiming)) != hipSuccess) return e;
+    hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
+    for (hipEvent_t* ev : evs)
+      if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return e;
   }
   cap_buckets = need;
   return hipSuccess;
@@ -687,6 +690,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   }();
   const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
   const bool nocall = mode == 2 || mode == 3;
+  uint32_t* const redo = this->redo + (size_t)slot * (cap_buckets + 1);  // the reduce stream reads it later
   // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
   // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
   static const int accum_block = [] {

@@ -1,6 +1,7 @@
 // zkmi — bucket scatter for the Pippenger MSM: signed-digit decomposition of
 // the scalars and a counting sort of point indices by (window, bucket).
 // See msm_impl.hpp for the full kernel chain and HBM layout.
+#include <stdio.h>
 #include <stdlib.h>
 #include "msm_impl.hpp"
 
@@ -415,9 +416,29 @@ MsmPlan msm_make_plan_shared(uint64_t n) {
   // n = 2^22: c = 22, 12 digits)
   int lg = 0;
   while ((1ull << lg) < n) lg++;
-  int c = lg;
-  if (c < 6) c = 6;
-  if (c > 22) c = 22;  // <= 64 partitions of 2^15 buckets
+  // Digit width c: all ndigits = floor(255 / c) + 1 digits of a scalar land in one set of 2^(c-1) buckets.
+  // Cost model: (digits that can be non-zero) x n insertions + 2^(c-1) buckets x ~3.5 insertion-equivalents of
+  // reduction work.  The LAST digit only covers top = 255 - (ndigits - 1) c bits of the (< 0.45 x 2^255) scalars:
+  //   top = 0  : it is always zero (only the recoding bias lives there) -- a free digit;
+  //   top small: every scalar's last digit falls into ~0.45 x 2^top buckets, each holding
+  //              2^(c-1) / (ndigits x 0.45 x 2^top) times the mean load -- a few hundred oversized buckets that the
+  //              thread-per-bucket kernel cannot take and the workgroup-per-bucket path handles badly (measured at
+  //              c = 14: 19 digits, top = 3 -> groups of 2^14-constraint proofs 3x slower than 2^15 ones;
+  //              c = 19, top = 8 -> 2^18 proofs 6x slower).  Such widths are skipped (ratio > 4).
+  int c = 0;
+  double best = 0;
+  for (int cand = (lg > 9 ? (lg - 3 < 17 ? lg - 3 : 17) : 6); cand <= 22 && cand <= lg + 2; cand++) {
+    if (cand < 6) continue;
+    const int nd = 255 / cand + 1, top = 255 - (nd - 1) * cand;
+    const double ratio = top == 0 ? 0.0 : (double)(1ull << (cand - 1)) / (nd * 0.45 * (double)(1ull << top));
+    if (ratio > 4.0) continue;
+    const double cost = (double)(top == 0 ? nd - 1 : nd) * (double)(n ? n : 1) + 3.5 * (double)(1ull << (cand - 1));
+    if (c == 0 || cost < best) {
+      c = cand;
+      best = cost;
+    }
+  }
+  if (c == 0) c = lg < 6 ? 6 : (lg > 22 ? 22 : lg);
   MsmPlan p;
   p.c = c;
   p.shared = true;
@@ -710,16 +731,26 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
       }
     }
   }
+  static const bool dbg = getenv("ZKMI_DEBUG") != nullptr;
+  auto chk = [&](const char* what) {
+    if (!dbg) return;
+    const hipError_t le = hipGetLastError();
+    fprintf(stderr, "[zkmi] run_shared_batch %s: %s (n=%llu batch=%u nb=%u nch=%u chunk=%u c=%d nd=%d)\n", what, hipGetErrorString(le),
+            (unsigned long long)n, batch, nb, nch, chunk, plan.c, plan.ndigits);
+  };
+  chk("entry");
   if (prof) prof->begin(PH_MSM_SORT, st);
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
   hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
                      nb_log, chunk, rc, blockhist, sorted, stride_words);
+  chk("pass1");
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
   hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
   hipLaunchKernelGGL(k_window_scan, dim3(P), dim3(1024), 0, st, count, begin, nb, (uint32_t)n, (const uint32_t*)part_total);
   const uint32_t tot_h = tot_b * nch;
   hipLaunchKernelGGL(k_bucket_bases, dim3((tot_h + 255) / 256), dim3(256), 0, st, blockhist, begin, nb, nch, tot_h);
+  chk("scans");
   hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
   if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
@@ -733,10 +764,11 @@ hipError_t MsmSort::reserve_batch(uint64_t n, uint32_t batch) {
   const MsmPlan sp = msm_make_plan_shared(n);
   if (sp.nwin != 1) return hipErrorInvalidValue;
   const uint64_t ne = (uint64_t)sp.ndigits * n * batch, nbk = (uint64_t)sp.nb * batch;
-  uint64_t nch = (512 + batch - 1) / batch;
-  const uint64_t mx = (n + 1023) / 1024;
-  if (nch > mx) nch = mx ? mx : 1;
-  const uint64_t nh = nbk * nch;
+  // tiles = (group size G) x (chunks per vector = min(ceil(512 / G), ceil(n / 1024))) for any G <= batch:
+  // G x ceil(512 / G) <= 512 + G
+  const uint64_t mx = (n + 1023) / 1024 ? (n + 1023) / 1024 : 1;
+  const uint64_t tiles = (512 + batch) < (uint64_t)batch * mx ? (512 + batch) : (uint64_t)batch * mx;
+  const uint64_t nh = (uint64_t)sp.nb * tiles;
   if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
   // grow: re-run reserve with synthetic sizes (keeps the record buffers of the shared plan)
   const uint64_t want_e = ne > cap_entries ? ne : cap_entries, want_b = nbk > cap_buckets ? nbk : cap_buckets,
