@@ -1293,3 +1293,28 @@ def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     for (_, publics), pf in zip(cases, grouped):
         assert zk.groth16_verify(vk, frs(publics), pf) is True
     r1.free()
+
+
+@pytest.mark.parametrize("lg,count", [(14, 48), (15, 21), (16, 9)])
+def test_grouped_prover_partial_groups(ctx, zk, lg, count):
+    """Groups smaller than the key's capacity (they use more histogram tiles per proof) at every grouped size:
+    each proof verifies and equals the single-proof entry point."""
+    import torch
+    from test_cpu_host import _note_update_case
+
+    r1 = zk.update_note_r1cs(lg, 1)
+    rng = ec.SplitMix64(500 + lg)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    cases = [_note_update_case(zk, 70 * lg + i, 1) for i in range(3)]
+    wits = [zk.update_note_witness(lg, 1, c[0])[0] for c in cases]
+    d = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
+    torch.cuda.synchronize()
+    idx = [i % 3 for i in range(count)]
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(count)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(count)]
+    proofs = ctx.groth16_prove_batch_dev(pk, [d[j].data_ptr() for j in idx], rs, ss)
+    for i in (0, count // 2, count - 1):
+        assert zk.groth16_verify(vk, frs(cases[idx[i]][1]), proofs[i]) is True
+        assert ctx.groth16_prove_dev(pk, d[idx[i]].data_ptr(), rs[i], ss[i]) == proofs[i]
+    pk.free()
+    r1.free()
