@@ -91,9 +91,11 @@ def cpu_kernel_twins(z, ctx, log_n):
     t_msm = time.time() - t0
     ok = ctx.msm_g1(raw, b) == want
     b.free()
-    t0 = time.time()
-    ocpp.ntt(raw, log_n)
-    t_ntt = time.time() - t0
+    t_ntt = None
+    for _ in range(2):  # the first call also pays for the 32 MiB ctypes staging buffers
+        t0 = time.time()
+        ocpp.ntt(raw, log_n)
+        t_ntt = min(t_ntt or 1e9, time.time() - t0)
     return {"msm_g1_cpu": {"n": n, "seconds": t_msm, "GBps": 128.0 * n / t_msm / 1e9, "equals_gpu_result": ok},
             "ntt_fr_cpu": {"n": n, "seconds": t_ntt, "GBps": 64.0 * n / t_ntt / 1e9}}
 
@@ -166,7 +168,9 @@ def pmc_traffic(path, kernel):
             tot += r["SQ_INSTS_VALU_avg_per_dispatch"] * r["SQ_INSTS_VALU_dispatches"] / meta["proofs"]
         pmc_traffic.total_valu = tot
     for r in rows:
-        if r.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
+        # `kernel` is a name prefix: the accumulation kernel's template arguments depend on the build's defaults
+        if r.get("kernel", "").replace(" ", "").startswith(kernel.replace(" ", "")) and "SQ_INSTS_VALU_avg_per_dispatch" in r:
+            pmc_traffic.name = r["kernel"]
             fetch = r.get("FETCH_SIZE_avg_per_dispatch")
             write = r.get("WRITE_SIZE_avg_per_dispatch")
             if fetch is None or write is None:
@@ -180,6 +184,7 @@ def pmc_traffic(path, kernel):
 
 
 pmc_traffic.valu = None
+pmc_traffic.name = None
 pmc_traffic.total_valu = None
 # 1024 SIMDs x 2.4 GHz / 4 cycles: v_mad_u64_u32 / v_mad_i64_i32 (78 % of the kernel's instructions) issue once per
 # 4 cycles per SIMD (scripts/ubench.hip); under this load the chip holds ~1.95 GHz, so ~500 G/s is what is attainable
@@ -329,10 +334,10 @@ def main():
     ms_tot, launches = phases[dom]
     avg_ms = ms_tot / max(1, launches)
     achieved = kernels[dom]["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    kname = "k_accum_g1_glds<Fq28 >" if dom == "msm_accum_g1" else "k_accum_g2_split<0>"
+    kname = "k_accum_g1_" if dom == "msm_accum_g1" else "k_accum_g2_"
     traffic, traffic_note = pmc_traffic(args.pmc_summary, kname)
     roofline = {
-        "kernel": kname,
+        "kernel": pmc_traffic.name or kname,
         # the kernel is bound by the integer multiply-add issue rate (valu_issue below), not by HBM; achieved /
         # peak / frac stay the HBM figures BASELINE.json's metric asks for (algorithmic bytes / launch time)
         "bound": "valu",

@@ -270,43 +270,40 @@ static Fr root_of_unity(int log_n) {
 
 static void ntt_inplace(std::vector<Fr>& a, int log_n, bool inverse, int threads) {
   const size_t n = size_t(1) << log_n;
-  for (size_t i = 0; i < n; i++) {
-    size_t r = 0;
-    for (int b = 0; b < log_n; b++) if (i >> b & 1) r |= size_t(1) << (log_n - 1 - b);
-    if (i < r) std::swap(a[i], a[r]);
-  }
+  const size_t par = n >= 8192 ? (size_t)threads : 1;
+  parallel_for(par, (int)par, [&](size_t t) {  // bit-reversal: pairs (i, rev i) are disjoint
+    for (size_t i = n * t / par; i < n * (t + 1) / par; i++) {
+      size_t r = 0;
+      for (int b = 0; b < log_n; b++) if (i >> b & 1) r |= size_t(1) << (log_n - 1 - b);
+      if (i < r) std::swap(a[i], a[r]);
+    }
+  });
   Fr wn = root_of_unity(log_n);
   if (inverse) wn = wn.inv();
   std::vector<Fr> tw(n / 2 ? n / 2 : 1);
-  tw[0] = Fr::one();
-  for (size_t i = 1; i < n / 2; i++) tw[i] = tw[i - 1] * wn;
+  parallel_for(par, (int)par, [&](size_t t) {
+    const size_t lo = (n / 2) * t / par, hi = (n / 2) * (t + 1) / par;
+    if (lo >= hi && !(t == 0)) return;
+    uint64_t ex[1] = {lo};
+    Fr x = wn.pow(ex, 1);
+    if (t == 0) tw[0] = Fr::one();
+    for (size_t i = lo; i < hi; i++) { tw[i] = x; x = x * wn; }
+  });
+  // every stage: the n/2 butterflies in contiguous per-thread ranges (one fork/join per stage)
+  const size_t half = n / 2;
+  const size_t parts = half >= 4096 ? (size_t)threads : 1;
   for (int s = 0; s < log_n; s++) {
     const size_t m = size_t(1) << s, step = n / (2 * m);
-    const size_t groups = n / (2 * m);
-    auto body = [&](size_t gidx) {
-      const size_t k = gidx * 2 * m;
-      for (size_t j = 0; j < m; j++) {
-        Fr t = a[k + j + m] * tw[j * step];
+    parallel_for(parts, (int)parts, [&](size_t t) {
+      const size_t lo = half * t / parts, hi = half * (t + 1) / parts;
+      for (size_t bf = lo; bf < hi; bf++) {
+        const size_t j = bf & (m - 1), k = (bf >> s) * 2 * m;
+        Fr x = a[k + j + m] * tw[j * step];
         Fr u = a[k + j];
-        a[k + j] = u + t;
-        a[k + j + m] = u - t;
+        a[k + j] = u + x;
+        a[k + j + m] = u - x;
       }
-    };
-    if (groups >= (size_t)threads * 4) parallel_for(groups, threads, body);
-    else if (threads > 1 && m >= 1024) {
-      // few large groups: split inside the group
-      for (size_t gidx = 0; gidx < groups; gidx++) {
-        const size_t k = gidx * 2 * m;
-        parallel_for((size_t)threads, threads, [&](size_t t) {
-          for (size_t j = t; j < m; j += threads) {
-            Fr x = a[k + j + m] * tw[j * step];
-            Fr u = a[k + j];
-            a[k + j] = u + x;
-            a[k + j + m] = u - x;
-          }
-        });
-      }
-    } else for (size_t gidx = 0; gidx < groups; gidx++) body(gidx);
+    });
   }
   if (inverse) {
     Fr ninv = Fr::from_u64(n).inv();
@@ -363,9 +360,10 @@ int oracle_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset, int thr
   if (threads <= 0) threads = n_threads();
   const size_t n = size_t(1) << log_n;
   std::vector<Fr> a(n);
-  for (size_t i = 0; i < n; i++) a[i] = Fr::from_bytes(data + 32 * i);
+  const size_t par = n >= 8192 ? (size_t)threads : 1;
+  parallel_for(par, (int)par, [&](size_t t) { for (size_t i = n * t / par; i < n * (t + 1) / par; i++) a[i] = Fr::from_bytes(data + 32 * i); });
   transform(a, (int)log_n, inverse != 0, coset != 0, threads);
-  for (size_t i = 0; i < n; i++) a[i].to_bytes(data + 32 * i);
+  parallel_for(par, (int)par, [&](size_t t) { for (size_t i = n * t / par; i < n * (t + 1) / par; i++) a[i].to_bytes(data + 32 * i); });
   return 0;
 }
 
