@@ -1257,6 +1257,32 @@ def test_arkworks_fixture_if_present(ctx, zk):
     r1.free()
 
 
+def test_library_before_torch_shares_one_hip_runtime():
+    """Import order must not matter: a fresh process that creates a zkmi context BEFORE importing torch still gets a
+    working torch.cuda (the wheel bundles its own HIP runtime; binding.py makes both resolve to one copy), and
+    the library can consume a torch allocation afterwards."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from zkmi_loader import load_pkg\n"
+        "z = load_pkg().Zkmi(); c = z.context(0)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "t = torch.arange(64, dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
+        "d = torch.zeros(32 << 10, dtype=torch.uint8, device='cuda')\n"
+        "d[0] = 1; torch.cuda.synchronize()\n"
+        "c.ntt_dev(d.data_ptr(), 10); c.sync(); torch.cuda.synchronize()\n"
+        "assert bytes(d[32:64].cpu().numpy()) == bytes(d[0:32].cpu().numpy())  # NTT of (1, 0, 0, ...) is all ones\n"
+        "print('ok', int(t.sum()))\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok 2016" in r.stdout, r.stdout + r.stderr
+
+
 def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     """Small domains (the relation's natural size, BASELINE config 0): the batch entry point proves up to 64 proofs as
     ONE group (one digit sort, one accumulation launch per query, batched NTT passes).  70 proofs at N = 2^13 (two
@@ -1295,9 +1321,10 @@ def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     r1.free()
 
 
-@pytest.mark.parametrize("lg,count", [(14, 48), (15, 21), (16, 9)])
+@pytest.mark.parametrize("lg,count", [(14, 48), (15, 21), (16, 9), (17, 11), (18, 7), (19, 5)])
 def test_grouped_prover_partial_groups(ctx, zk, lg, count):
-    """Groups smaller than the key's capacity (they use more histogram tiles per proof) at every grouped size:
+    """Groups smaller than the key's capacity (they use more histogram tiles per proof) at every grouped size
+    (from 2^17 on a proof owns several 2^15-bucket partitions of the group's bucket array):
     each proof verifies and equals the single-proof entry point."""
     import torch
     from test_cpu_host import _note_update_case

@@ -123,6 +123,28 @@ def _buf(b):
     return (C.c_uint8 * len(b)).from_buffer_copy(bytes(b)) if len(b) else (C.c_uint8 * 1)()
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so / libhsa-runtime64.so (RPATH $ORIGIN) and ask for them by
+    the unversioned name, so a process that loads libzkmi.so (NEEDED libamdhip64.so.7 -> /opt/rocm) BEFORE importing
+    torch ends up with two HIP runtimes, and the second one to initialise finds no GPU.  Loading torch's copy first
+    (its SONAME is libamdhip64.so.7 too) makes both sides resolve to the same runtime whatever the import order.
+    No torch installed, or torch already imported: nothing to do."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 class Zkmi:
     """Loads libzkmi.so.  Fails loudly if it is missing (no fallback path)."""
 
@@ -130,6 +152,7 @@ class Zkmi:
         path = path or os.environ.get("ZKMI_LIB") or lib_path()
         if not os.path.exists(path):
             raise ZkmiError(-4, f"{path} not built; run __graft_entry__.build()")
+        _share_hip_runtime_with_torch()
         self.lib = C.CDLL(path)
         self.lib.zkmi_version.restype = C.c_char_p
         self.lib.zkmi_last_error.restype = C.c_char_p

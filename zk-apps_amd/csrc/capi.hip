@@ -4,6 +4,9 @@
 #include <new>
 #include <type_traits>
 #include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "ctx.hpp"
 #include "msm_impl.hpp"  // msm_combine_windows (host)
 
@@ -66,9 +69,24 @@ int32_t zkmi_device_count(int32_t* out_count) {
   return (e == hipSuccess && n > 0) ? ZKMI_OK : ZKMI_ERR_NO_DEVICE;
 }
 
+// ZKMI_BACKTRACE=1: print the native stack on SIGSEGV / SIGABRT (debugging aid; the default handlers stay otherwise)
+static void zkmi_crash_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[zkmi] fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
 int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   if (!out_ctx) return ZKMI_ERR_BAD_ARG;
   *out_ctx = nullptr;
+  if (getenv("ZKMI_BACKTRACE")) {
+    signal(SIGSEGV, zkmi_crash_handler);
+    signal(SIGABRT, zkmi_crash_handler);
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZKMI_ERR_NO_DEVICE;
   if (device < 0 || device >= n) return ZKMI_ERR_BAD_ARG;
@@ -84,14 +102,15 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
-      false) {
+      hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     delete c;
     return ZKMI_ERR_HIP;
   }
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++)
     if (hipEventCreateWithFlags(&c->ev_sort[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_z[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sorth[i], hipEventDisableTiming) != hipSuccess) {
       delete c;
       return ZKMI_ERR_HIP;
     }
@@ -110,11 +129,12 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (hipStream_t s : {ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
+  for (hipStream_t s : {ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
     if (s) (void)hipStreamSynchronize(s);
   ctx->domains.clear();
   ctx->domains_bn.clear();
   ctx->sort.release();
+  ctx->sort_z2.release();
   ctx->sort_h.release();
   ctx->g1.release();
   ctx->g2.release();
@@ -130,10 +150,12 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
     if (ctx->ev_sort[i]) (void)hipEventDestroy(ctx->ev_sort[i]);
     if (ctx->ev_z[i]) (void)hipEventDestroy(ctx->ev_z[i]);
     if (ctx->ev_h[i]) (void)hipEventDestroy(ctx->ev_h[i]);
+    if (ctx->ev_sorth[i]) (void)hipEventDestroy(ctx->ev_sorth[i]);
   }
   if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
   if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
   if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
+  if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
   delete ctx;
   return ZKMI_OK;
 }
@@ -149,6 +171,7 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_heavy));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_sort));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -173,6 +196,7 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   (void)hipStreamSynchronize(ctx->stream_g2);
   (void)hipStreamSynchronize(ctx->stream_front);
   (void)hipStreamSynchronize(ctx->stream_heavy);
+  (void)hipStreamSynchronize(ctx->stream_sort);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];

@@ -18,12 +18,15 @@ struct zkmi_ctx {
   hipStream_t stream_front = nullptr;  // witness map + NTTs beside the MSMs over z
   hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof
   hipStream_t stream_heavy = nullptr;  // heavy-bucket kernels beside the accumulations (msm.hpp run_device)
+  hipStream_t stream_sort = nullptr;   // the prover's digit sorts, beside the previous proof's accumulations
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
-  hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {};
+  hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
+  unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;
   zkmi::MsmSort sort;    // every MSM entry point; in the prover: the digit sort of z (A, B1, B2, L MSMs)
+  zkmi::MsmSort sort_z2;  // second set of z-sort buffers: proof i+1 is sorted while proof i's accumulations read `sort`
   zkmi::MsmSort sort_h;  // the prover's digit sort of the h coefficients (own buffers: see prove_enqueue_h)
   zkmi::MsmEngine<zkmi::Fq28> g1;
   zkmi::MsmEngine<zkmi::Fq2_28> g2;

@@ -164,6 +164,60 @@ __host__ __device__ inline XYZZ<F> scalar_mul(const XYZZ<F>& p, const uint32_t* 
   return acc;
 }
 
+// ---- host-side helpers of proof assembly (groth16.hip assemble_proof) ----------------------------------
+// 4-bit window of a little-endian 32-bit-limb scalar
+inline uint32_t scalar_nibble(const uint32_t* k, int w) { return (k[w >> 3] >> ((w & 7) * 4)) & 15u; }
+
+// k * P for a point fixed at key-load time (delta in G1 and G2): 64 windows x 15 multiples, no doublings.
+template <class F>
+struct FixedBase4 {
+  XYZZ<F> tab[64][15];  // tab[w][d-1] = d * 16^w * P
+  bool built = false;
+  void build(const Affine<F>& p) {
+    XYZZ<F> base = XYZZ<F>::from_affine(p);
+    for (int w = 0; w < 64; w++) {
+      tab[w][0] = base;
+      for (int d = 1; d < 15; d++) {
+        tab[w][d] = tab[w][d - 1];
+        tab[w][d].add(base);
+      }
+      base = tab[w][14];
+      base.add(tab[w][0]);  // 16 * (16^w P)
+    }
+    built = true;
+  }
+  XYZZ<F> mul(const uint32_t* k /* 8 limbs */) const {
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (int w = 0; w < 64; w++) {
+      const uint32_t d = scalar_nibble(k, w);
+      if (d) acc.add(tab[w][d - 1]);
+    }
+    return acc;
+  }
+};
+
+// a * P + b * Q for 256-bit scalars: one doubling chain, 4-bit windows (Straus)
+template <class F>
+inline XYZZ<F> scalar_mul2(const XYZZ<F>& p, const uint32_t* a, const XYZZ<F>& q, const uint32_t* b) {
+  XYZZ<F> tp[15], tq[15];
+  tp[0] = p;
+  tq[0] = q;
+  for (int d = 1; d < 15; d++) {
+    tp[d] = tp[d - 1];
+    tp[d].add(p);
+    tq[d] = tq[d - 1];
+    tq[d].add(q);
+  }
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int w = 63; w >= 0; w--) {
+    for (int i = 0; i < 4; i++) acc.dbl_inplace();
+    const uint32_t da = scalar_nibble(a, w), db = scalar_nibble(b, w);
+    if (da) acc.add(tp[da - 1]);
+    if (db) acc.add(tq[db - 1]);
+  }
+  return acc;
+}
+
 using G1Affine = Affine<Fq>;
 using G2Affine = Affine<Fq2>;
 using G1XYZZ = XYZZ<Fq>;

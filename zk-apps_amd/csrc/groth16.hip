@@ -21,6 +21,7 @@
 #include <string.h>
 #include <new>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
@@ -170,6 +171,9 @@ struct zkmi_pk {
   Affine<Fq2_28>* b2_tab = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
+  // host tables for r * delta, s * delta, rs * delta of proof assembly (built once per key)
+  std::unique_ptr<FixedBase4<Fq>> delta1_tab;
+  std::unique_ptr<FixedBase4<Fq2>> delta2_tab;
   // per proof in flight (ring of zkmi_ctx::PROOF_RING): witness in canonical words (digit source of the
   // A/B/L MSMs) and h coefficients in canonical words, bit-reversed order (digit source of the H MSM)
   Fr* d_z[zkmi_ctx::PROOF_RING] = {};
@@ -230,13 +234,16 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->l28, sizeof(Affine<Fq28>) * r->n_vars)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28_rev, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
-  // group size: about 2^20 constraints in flight per group, at most 64 proofs; domains above 2^16 have
-  // several bucket partitions per proof and go one by one.  ZKMI_GROUP overrides (1 = never group).
+  // group size: about 2^20 constraints in flight per group, at most 64 proofs (and at most 64 bucket partitions:
+  // a proof above 2^16 constraints has several).  ZKMI_GROUP overrides (1 = never group).
   {
-    uint32_t g = r->log_n <= 16 ? (1u << (r->log_n >= 14 ? 20 - r->log_n : 6)) : 1u;
+    uint32_t g = r->log_n <= 19 ? (1u << (r->log_n >= 14 ? 20 - r->log_n : 6)) : 1u;
     if (g > 64) g = 64;
     const char* env = getenv("ZKMI_GROUP");
-    if (env && atoi(env) >= 1 && atoi(env) <= 64 && (r->log_n <= 16 || atoi(env) == 1)) g = (uint32_t)atoi(env);
+    if (env && atoi(env) >= 1 && atoi(env) <= 64 && (r->log_n <= 19 || atoi(env) == 1)) g = (uint32_t)atoi(env);
+    const uint64_t capv = (1ull << r->log_n) > r->n_vars ? (1ull << r->log_n) : r->n_vars;
+    const uint32_t parts = (uint32_t)msm_make_plan_shared(capv).nwin;
+    while (g > 1 && g * parts > 64) g >>= 1;
     pk->gmax = g;
   }
   const uint64_t G = pk->gmax;
@@ -253,18 +260,27 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
+  if ((e = ctx->sort_z2.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->sort_h.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
   if (G > 1) {
     const MsmPlan sp = msm_make_plan_shared(cap);
-    if (sp.nwin != 1) return hipErrorInvalidValue;
     if ((e = ctx->sort.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
+    if ((e = ctx->sort_z2.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
     if ((e = ctx->sort_h.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
-    if ((e = ctx->g1.reserve_buckets((uint64_t)sp.nb * G)) != hipSuccess) return e;
-    if ((e = ctx->g2.reserve_buckets((uint64_t)sp.nb * G)) != hipSuccess) return e;
+    if ((e = ctx->g1.reserve_buckets((uint64_t)sp.nb * sp.nwin * G)) != hipSuccess) return e;
+    if ((e = ctx->g2.reserve_buckets((uint64_t)sp.nb * sp.nwin * G)) != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+// delta_g1 / delta_g2 are final -> fixed-base tables of proof assembly
+static void pk_build_delta_tables(zkmi_pk* pk) {
+  pk->delta1_tab.reset(new FixedBase4<Fq>());
+  pk->delta1_tab->build(pk->delta_g1);
+  pk->delta2_tab.reset(new FixedBase4<Fq2>());
+  pk->delta2_tab->build(pk->delta_g2);
 }
 
 // queries are final in the host representation -> build the device MSM copies
@@ -452,6 +468,7 @@ int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t toxi
   pk->delta_g1 = mul1(delta);
   pk->beta_g2 = mul2(beta);
   pk->delta_g2 = mul2(delta);
+  pk_build_delta_tables(pk);
   g1_to_wire(pk->alpha_g1, vk_out);
   g2_to_wire(pk->beta_g2, vk_out + 96);
   g2_to_wire(mul2(gamma), vk_out + 288);
@@ -499,6 +516,7 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t alpha_g1[9
     e = hipMemcpy(pk->b_g2_query, h2.data(), sizeof(G2Affine) * nv, hipMemcpyHostToDevice);
   }
   if (ok && e == hipSuccess) e = pk_convert_queries(pk);
+  if (ok && e == hipSuccess) pk_build_delta_tables(pk);
   if (!ok || e != hipSuccess) {
     delete pk;
     return ok ? ctx->hip_fail(e, "pk upload") : ctx->fail(ZKMI_ERR_NON_CANONICAL, "proving key point invalid");
@@ -647,26 +665,32 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z[par] + 1);
   const bool sh = pk->shared;
+  // The digit sort runs on its own (high-priority) stream into one of two buffer sets, so the sort of proof i+1
+  // overlaps the accumulations of proof i instead of standing between two accumulations on the main stream.
+  // ZKMI_SORT_SIDE=0: sorts back on the main stream (A/B runs).
+  static const bool sort_side = !(getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '0');
+  MsmSort& sz = (sort_side && (ctx->z_flip++ & 1u)) ? ctx->sort_z2 : ctx->sort;
+  const hipStream_t ss = sort_side ? ctx->stream_sort : st;
+  if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_z[par], 0));  // the witness is in d_z
   if (G > 1)  // one digit sort for the whole group: bucket set b belongs to witness b (msm_sort.hip run_shared_batch)
-    ZK_HIP(ctx, ctx->sort.run_shared_batch(zs, nv - 1, 8ull * nv, G, st, t));
+    ZK_HIP(ctx, sz.run_shared_batch(zs, nv - 1, 8ull * nv, G, ss, t));
   else if (sh)
-    ZK_HIP(ctx, ctx->sort.run_shared(zs, nv - 1, st, t));
+    ZK_HIP(ctx, sz.run_shared(zs, nv - 1, ss, t));
   else
-    ZK_HIP(ctx, ctx->sort.run(zs, nv - 1, st, t));
+    ZK_HIP(ctx, sz.run(zs, nv - 1, ss, t));
   // the G2 accumulation runs on its own stream beside the three G1 ones (same sort, disjoint
   // outputs): the kernels' drain tails overlap instead of adding up
-  ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], st));
+  ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], ss));
+  if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sort[par], 0));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t,
+  ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->a_tab : pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 0, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->b1_tab : pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 1, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 2, sth));
-  // the next sort over z re-uses these sort buffers: it must also wait for this G2 accumulation
-  ctx->sort.readers.push_back(ctx->g2.acc_done[g2s]);
   return ZKMI_OK;
 }
 
@@ -677,16 +701,21 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   const bool sh = pk->shared;
   static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
-  ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_h[par], 0));  // h coefficients from the front stream
+  static const bool sort_side = !(getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '0');
+  const hipStream_t ss = sort_side ? ctx->stream_sort : st;
+  ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_h[par], 0));  // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
-  // infinity.  Own sort buffers (ctx->sort_h): the G2 accumulation of the NEXT proof may still be reading
-  // the z sort when this runs.
+  // infinity.  Own sort buffers (ctx->sort_h), written on the sort stream behind the previous H accumulation.
   if (G > 1)
-    ZK_HIP(ctx, ctx->sort_h.run_shared_batch(pk->d_h[par], N, 8ull * N, G, st, t));
+    ZK_HIP(ctx, ctx->sort_h.run_shared_batch(pk->d_h[par], N, 8ull * N, G, ss, t));
   else if (sh)
-    ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], N, st, t));
+    ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], N, ss, t));
   else
-    ZK_HIP(ctx, ctx->sort_h.run(pk->d_h[par], N, st, t));
+    ZK_HIP(ctx, ctx->sort_h.run(pk->d_h[par], N, ss, t));
+  if (sort_side) {
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_sorth[par], ss));
+    ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
+  }
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, 4 * par + 3, sth));
   return ZKMI_OK;
@@ -704,22 +733,21 @@ static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ&
   fr_from_wire(r_bytes, &rm);
   fr_from_wire(s_bytes, &sm);
   fr_limbs(rm * sm, rsk);
-  const G1XYZZ d1 = G1XYZZ::from_affine(pk->delta_g1);
-  G1XYZZ g_a = scalar_mul(d1, rk, 8);
+  // r * delta, s * delta, rs * delta from the key's fixed-base tables; s * A + r * B1 over one doubling chain
+  G1XYZZ g_a = pk->delta1_tab->mul(rk);
   g_a.madd(pk->a0);
   g_a.add(acc_a);
   g_a.madd(pk->alpha_g1);
-  G1XYZZ g1_b = scalar_mul(d1, sk, 8);
+  G1XYZZ g1_b = pk->delta1_tab->mul(sk);
   g1_b.madd(pk->b1_0);
   g1_b.add(acc_b1);
   g1_b.madd(pk->beta_g1);
-  G2XYZZ g2_b = scalar_mul(G2XYZZ::from_affine(pk->delta_g2), sk, 8);
+  G2XYZZ g2_b = pk->delta2_tab->mul(sk);
   g2_b.madd(pk->b2_0);
   g2_b.add(acc_b2);
   g2_b.madd(pk->beta_g2);
-  G1XYZZ g_c = scalar_mul(g_a, sk, 8);
-  g_c.add(scalar_mul(g1_b, rk, 8));
-  g_c.add(scalar_mul(d1, rsk, 8).neg());
+  G1XYZZ g_c = scalar_mul2(g_a, sk, g1_b, rk);
+  g_c.add(pk->delta1_tab->mul(rsk).neg());
   g_c.add(acc_l);
   g_c.add(acc_h);
   g1_compress(g_a.to_affine(), out_proof);
@@ -757,8 +785,14 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
   if (G == 1) {
     one(0);
   } else {
+    // host threads for the assembly of a group: ZKMI_HOST_THREADS, default min(16, hardware threads)
+    static const unsigned cap = []() {
+      const char* env = getenv("ZKMI_HOST_THREADS");
+      const int v = env ? atoi(env) : 0;
+      return (unsigned)(v >= 1 && v <= 256 ? v : 16);
+    }();
     unsigned nt = std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
+    if (nt > cap) nt = cap;
     if (nt < 1) nt = 1;
     if (nt > G) nt = G;
     std::vector<std::thread> th;
@@ -813,7 +847,7 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
-    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
+    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
       (void)hipStreamSynchronize(q);
     ctx->err = msg;
     return code;

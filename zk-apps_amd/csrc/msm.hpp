@@ -57,6 +57,9 @@ struct MsmPlan {
   // k_segreduce walks 2^seg_log buckets per thread (a dependent chain of 2 * 2^seg_log additions):
   // 16 buckets when the chip is full anyway, 4 for small problems whose reduction is pure latency
   int seg_log = 4;
+  // batched shared sort (MsmSort::run_shared_batch): nwin = vectors x vec_parts, vector v owns partitions
+  // [v * vec_parts, (v + 1) * vec_parts)
+  int vec_parts = 1;
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);

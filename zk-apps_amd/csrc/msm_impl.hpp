@@ -747,6 +747,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   hipLaunchKernelGGL(k_heavy_combine<F>, dim3(64), dim3(MSM_HSPLIT), sizeof(XYZZ<F>) * MSM_HSPLIT, sh, sort.heavy,
                      heavy_partial, bk);
   if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
+  sort.readers.push_back(acc_done[slot]);  // the next sort into these buffers may be queued on another stream
   if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
   if (side) {
     if ((e = hipEventRecord(heavy_done[slot], st_heavy)) != hipSuccess) return e;
@@ -806,11 +807,35 @@ hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
   return hipSuccess;
 }
 
+// shared buckets: partition q of a vector holds buckets q*nb + j (digit value q*nb + j + 1):
+//   sum_b (b+1) B_b = sum_q U_q + nb * sum_q q * S_q,   U_q = weighted sum, S_q = plain sum of partition q
+template <class HF>
+static XYZZ<HF> msm_combine_partitions(const XYZZ<HF>* win, const XYZZ<HF>* h, int parts, int njobs, uint32_t nb) {
+  XYZZ<HF> run = XYZZ<HF>::infinity(), t = XYZZ<HF>::infinity(), total = XYZZ<HF>::infinity();
+  for (int q = parts - 1; q >= 1; q--) {
+    run.add(h[(size_t)q * njobs + (njobs - 1)]);
+    t.add(run);
+  }
+  for (uint32_t b = nb; b > 1; b >>= 1) t.dbl_inplace();
+  for (int q = 0; q < parts; q++) total.add(win[q]);
+  total.add(t);
+  return total;
+}
+
 template <class F>
 hipError_t MsmEngine<F>::finish_host_batch(XYZZ<HF>* out, int slot) {
-  // every "window" of the batched plan is the complete single-partition bucket set of one scalar vector:
-  // sum_b (b + 1) B_b is that vector's MSM
-  return finish_host_windows(out, slot);
+  // the batched plan holds, per scalar vector, the vec_parts partitions of that vector's own bucket set
+  const MsmPlan& pl = slot_plan[slot];
+  if (pl.vec_parts <= 1) return finish_host_windows(out, slot);
+  std::vector<XYZZ<HF>> win(pl.nwin);
+  hipError_t e = finish_host_windows(win.data(), slot);
+  if (e != hipSuccess) return e;
+  const int njobs = 2 + msm_seg_bits(pl);
+  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
+  for (int v = 0; v * pl.vec_parts < pl.nwin; v++)
+    out[v] = msm_combine_partitions<HF>(win.data() + (size_t)v * pl.vec_parts, h + (size_t)v * pl.vec_parts * njobs, pl.vec_parts,
+                                        njobs, pl.nb);
+  return hipSuccess;
 }
 
 template <class HF>
@@ -833,19 +858,7 @@ hipError_t MsmEngine<F>::finish_host(XYZZ<HF>* out, int slot) {
     *out = msm_combine_windows(win.data(), pl.nwin, pl.c);
     return hipSuccess;
   }
-  // shared buckets: partition q holds buckets q*nb + j (digit value q*nb + j + 1):
-  //   sum_b (b+1) B_b = sum_q U_q + nb * sum_q q * S_q,   S_q = plain sum of partition q
-  const int njobs = 2 + msm_seg_bits(pl);
-  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
-  XYZZ<HF> run = XYZZ<HF>::infinity(), t = XYZZ<HF>::infinity(), total = XYZZ<HF>::infinity();
-  for (int q = pl.nwin - 1; q >= 1; q--) {
-    run.add(h[(size_t)q * njobs + (njobs - 1)]);
-    t.add(run);
-  }
-  for (uint32_t b = pl.nb; b > 1; b >>= 1) t.dbl_inplace();
-  for (int q = 0; q < pl.nwin; q++) total.add(win[q]);
-  total.add(t);
-  *out = total;
+  *out = msm_combine_partitions<HF>(win.data(), h_partial + (size_t)slot * SLOT_PTS, pl.nwin, 2 + msm_seg_bits(pl), pl.nb);
   return hipSuccess;
 }
 

@@ -84,13 +84,13 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(1024)
 k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log,
                      uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted,
-                     uint64_t batch_stride_words) {
+                     uint64_t batch_stride_words, uint32_t vec_parts) {
   extern __shared__ uint32_t hist[];
   const uint32_t ch = blockIdx.x, q = blockIdx.y, nch = gridDim.x;
-  // batch mode (batch_stride_words != 0): blockIdx.y is the index of an independent scalar vector whose whole
-  // (single-partition) bucket set is "partition" q of the combined bucket array; table indices are per vector
-  const bool batched = batch_stride_words != 0;
-  if (batched) scalars += (size_t)q * batch_stride_words;
+  // batch mode (batch_stride_words != 0): partition q of the combined bucket array is bucket range q % vec_parts of
+  // the independent scalar vector q / vec_parts; table indices are per vector
+  const uint32_t vec = q / vec_parts, range = q - vec * vec_parts;
+  scalars += (size_t)vec * batch_stride_words;
   uint32_t* gh = blockhist + ((size_t)q * nch + ch) * nb;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
   __syncthreads();
@@ -104,7 +104,7 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
       const uint32_t d = digit_of(k, w, c, neg);
       if (d == 0) continue;
       const uint32_t bkt = d - 1;
-      if (!batched && (bkt >> nb_log) != q) continue;
+      if ((bkt >> nb_log) != range) continue;
       const uint32_t local = bkt & (nb - 1u);
       if (SCATTER) {
         const uint32_t pos = atomicAdd(&hist[local], 1u);
@@ -672,7 +672,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                        sorted);
   } else {
     hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
-                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0);
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0, P);
   }
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
   if (!records) hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
@@ -687,7 +687,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                        sorted);
   } else {
     hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c,
-                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0);
+                       plan.ndigits, nb, nb_log, chunk, rc, blockhist, sorted, (uint64_t)0, P);
   }
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
@@ -696,7 +696,8 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
 // Shared-bucket sort of `batch` independent scalar vectors of n elements each (vector b starts at
 // d_scalars + b * stride_words) over the SAME bases: one bucket set per vector, laid out as the partitions of one
 // combined plan (plan.nwin = batch), so that a single accumulation / reduction launch serves the whole batch.
-// Only for vectors whose own plan has one partition (n <= 2^16).  Buffers must have been reserved for it.
+// A vector whose own plan has several partitions (2^15-bucket ranges, n > 2^16) keeps them: partition q of the
+// combined plan = range q % vec_parts of vector q / vec_parts.  Buffers must have been reserved for it.
 hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint64_t stride_words, uint32_t batch, hipStream_t st,
                                      PhaseTimer* prof) {
   {
@@ -704,10 +705,12 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
     if (er != hipSuccess) return er;
   }
   plan = msm_make_plan_shared(n);
-  if (plan.nwin != 1 || batch == 0 || batch > 64) return hipErrorInvalidValue;
-  plan.nwin = (int)batch;
+  const uint32_t vparts = (uint32_t)plan.nwin;
+  if (batch == 0 || (uint64_t)batch * vparts > 64) return hipErrorInvalidValue;
+  plan.vec_parts = (int)vparts;
+  plan.nwin = (int)(batch * vparts);
   plan_set_heavy(plan, n * (uint64_t)plan.ndigits * batch);
-  const uint32_t nb = plan.nb, P = batch;
+  const uint32_t nb = plan.nb, P = batch * vparts;
   int nb_log = 0;
   while ((1u << nb_log) < nb) nb_log++;
   const uint32_t tot_b = P * nb;
@@ -743,7 +746,7 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
   hipLaunchKernelGGL(k_bucket_pass_shared<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
-                     nb_log, chunk, rc, blockhist, sorted, stride_words);
+                     nb_log, chunk, rc, blockhist, sorted, stride_words, vparts);
   chk("pass1");
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
   hipLaunchKernelGGL(k_part_totals, dim3(P), dim3(1024), 0, st, count, part_total, nb);
@@ -754,7 +757,7 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
   hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
   if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(k_bucket_pass_shared<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, nb,
-                     nb_log, chunk, rc, blockhist, sorted, stride_words);
+                     nb_log, chunk, rc, blockhist, sorted, stride_words, vparts);
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
@@ -762,12 +765,13 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
 // room for run_shared_batch(n, batch) on top of what reserve() provides
 hipError_t MsmSort::reserve_batch(uint64_t n, uint32_t batch) {
   const MsmPlan sp = msm_make_plan_shared(n);
-  if (sp.nwin != 1) return hipErrorInvalidValue;
-  const uint64_t ne = (uint64_t)sp.ndigits * n * batch, nbk = (uint64_t)sp.nb * batch;
-  // tiles = (group size G) x (chunks per vector = min(ceil(512 / G), ceil(n / 1024))) for any G <= batch:
-  // G x ceil(512 / G) <= 512 + G
+  const uint64_t pmax = (uint64_t)batch * sp.nwin;  // partitions of a full group
+  if (pmax > 64) return hipErrorInvalidValue;
+  const uint64_t ne = (uint64_t)sp.ndigits * n * batch, nbk = (uint64_t)sp.nb * pmax;
+  // tiles = (partitions P) x (chunks per vector = min(ceil(512 / P), ceil(n / 1024))) for any P <= pmax:
+  // P x ceil(512 / P) <= 512 + P
   const uint64_t mx = (n + 1023) / 1024 ? (n + 1023) / 1024 : 1;
-  const uint64_t tiles = (512 + batch) < (uint64_t)batch * mx ? (512 + batch) : (uint64_t)batch * mx;
+  const uint64_t tiles = (512 + pmax) < pmax * mx ? (512 + pmax) : pmax * mx;
   const uint64_t nh = (uint64_t)sp.nb * tiles;
   if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
   // grow: re-run reserve with synthetic sizes (keeps the record buffers of the shared plan)
