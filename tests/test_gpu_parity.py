@@ -21,6 +21,37 @@ def unfrs(b):
     return [int.from_bytes(b[i : i + 32], "little") for i in range(0, len(b), 32)]
 
 
+def test_library_before_torch_shares_one_hip_runtime():
+    """Import order must not matter: a fresh process that creates a zkmi context BEFORE importing torch still gets a
+    working torch.cuda (the wheel bundles its own HIP runtime; binding.py makes both resolve to one copy), and
+    the library can consume a torch allocation afterwards.  First GPU test of the file on purpose: this process
+    does not hold a context yet."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import faulthandler, sys; faulthandler.dump_traceback_later(150, exit=True)\n"
+        "sys.path.insert(0, %r)\n"
+        "from zkmi_loader import load_pkg\n"
+        "z = load_pkg().Zkmi(); c = z.context(0)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "t = torch.arange(64, dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
+        "d = torch.zeros(32 << 10, dtype=torch.uint8, device='cuda')\n"
+        "d[0] = 1; torch.cuda.synchronize()\n"
+        "c.ntt_dev(d.data_ptr(), 10); c.sync(); torch.cuda.synchronize()\n"
+        "assert bytes(d[32:64].cpu().numpy()) == bytes(d[0:32].cpu().numpy())  # NTT of (1, 0, 0, ...) is all ones\n"
+        "print('ok', int(t.sum()))\n"
+    ) % ROOT
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:  # a second process on a busy device: not the property under test
+        pytest.skip("child process did not finish in 240 s: %r" % ((e.stderr or b"")[-2000:],))
+    assert r.returncode == 0 and "ok 2016" in r.stdout, r.stdout + r.stderr
+
+
 # ---------------------------------------------------------------- NTT (row a6)
 @pytest.mark.parametrize("case", golden("ntt_small.json"), ids=lambda c: f"log{c['log_n']}")
 def test_ntt_golden(ctx, case):
@@ -1255,32 +1286,6 @@ def test_arkworks_fixture_if_present(ctx, zk):
     assert zk.groth16_verify(vk, wit[32 : 32 * n_pub], proof) is True
     pk.free()
     r1.free()
-
-
-def test_library_before_torch_shares_one_hip_runtime():
-    """Import order must not matter: a fresh process that creates a zkmi context BEFORE importing torch still gets a
-    working torch.cuda (the wheel bundles its own HIP runtime; binding.py makes both resolve to one copy), and
-    the library can consume a torch allocation afterwards."""
-    import subprocess
-    import sys
-
-    from conftest import ROOT
-
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "from zkmi_loader import load_pkg\n"
-        "z = load_pkg().Zkmi(); c = z.context(0)\n"
-        "assert 'torch' not in sys.modules\n"
-        "import torch\n"
-        "t = torch.arange(64, dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
-        "d = torch.zeros(32 << 10, dtype=torch.uint8, device='cuda')\n"
-        "d[0] = 1; torch.cuda.synchronize()\n"
-        "c.ntt_dev(d.data_ptr(), 10); c.sync(); torch.cuda.synchronize()\n"
-        "assert bytes(d[32:64].cpu().numpy()) == bytes(d[0:32].cpu().numpy())  # NTT of (1, 0, 0, ...) is all ones\n"
-        "print('ok', int(t.sum()))\n"
-    ) % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok 2016" in r.stdout, r.stdout + r.stderr
 
 
 def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):

@@ -98,8 +98,11 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreate(&c->stream) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream_aux2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream_aux3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream_front, hipStreamNonBlocking,
+                                  (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '1') ? prio_hi : 0) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, prio_hi) != hipSuccess) {
@@ -129,7 +132,7 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (hipStream_t s : {ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
+  for (hipStream_t s : {ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
     if (s) (void)hipStreamSynchronize(s);
   ctx->domains.clear();
   ctx->domains_bn.clear();
@@ -145,6 +148,8 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
     if (p) (void)hipFree(p);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
+  if (ctx->stream_aux2) (void)hipStreamDestroy(ctx->stream_aux2);
+  if (ctx->stream_aux3) (void)hipStreamDestroy(ctx->stream_aux3);
   if (ctx->stream_g2) (void)hipStreamDestroy(ctx->stream_g2);
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) {
     if (ctx->ev_sort[i]) (void)hipEventDestroy(ctx->ev_sort[i]);
@@ -167,6 +172,8 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux2));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux3));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_g2));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_heavy));
@@ -193,6 +200,8 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream_aux);
+  (void)hipStreamSynchronize(ctx->stream_aux2);
+  (void)hipStreamSynchronize(ctx->stream_aux3);
   (void)hipStreamSynchronize(ctx->stream_g2);
   (void)hipStreamSynchronize(ctx->stream_front);
   (void)hipStreamSynchronize(ctx->stream_heavy);

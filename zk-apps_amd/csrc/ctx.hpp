@@ -14,6 +14,7 @@ struct zkmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_aux = nullptr;  // MSM reductions: overlap the next accumulation
+  hipStream_t stream_aux2 = nullptr, stream_aux3 = nullptr;  // the prover spreads its five reductions over three streams
   hipStream_t stream_g2 = nullptr;   // G2 accumulation beside the G1 ones
   hipStream_t stream_front = nullptr;  // witness map + NTTs beside the MSMs over z
   hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof

@@ -151,6 +151,18 @@ k_fixed_base(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__
 
 using namespace zkmi;
 
+// Scheduling switches of the prover (measured in DESIGN.md 4.4; both are within noise of each other at N = 2^20):
+//   ZKMI_SORT_SIDE=1  digit sorts on their own high-priority stream into ping-pong z buffers (default: main stream)
+//   ZKMI_AUX_SPLIT=0  all five reductions of a proof on one stream (default: three streams, A L | B1 H | B2)
+static bool prover_sort_side() {
+  static const bool v = getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '1';
+  return v;
+}
+static bool prover_aux_split() {
+  static const bool v = !(getenv("ZKMI_AUX_SPLIT") && getenv("ZKMI_AUX_SPLIT")[0] == '0');
+  return v;
+}
+
 struct zkmi_pk {
   zkmi_ctx* ctx = nullptr;
   uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
@@ -260,14 +272,14 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
-  if ((e = ctx->sort_z2.reserve(cap, true)) != hipSuccess) return e;
+  if (prover_sort_side() && (e = ctx->sort_z2.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->sort_h.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
   if (G > 1) {
     const MsmPlan sp = msm_make_plan_shared(cap);
     if ((e = ctx->sort.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
-    if ((e = ctx->sort_z2.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
+    if (prover_sort_side() && (e = ctx->sort_z2.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
     if ((e = ctx->sort_h.reserve_batch(cap, (uint32_t)G)) != hipSuccess) return e;
     if ((e = ctx->g1.reserve_buckets((uint64_t)sp.nb * sp.nwin * G)) != hipSuccess) return e;
     if ((e = ctx->g2.reserve_buckets((uint64_t)sp.nb * sp.nwin * G)) != hipSuccess) return e;
@@ -665,11 +677,16 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // per-window partials in a pinned host slot + an event.
   const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z[par] + 1);
   const bool sh = pk->shared;
-  // The digit sort runs on its own (high-priority) stream into one of two buffer sets, so the sort of proof i+1
-  // overlaps the accumulations of proof i instead of standing between two accumulations on the main stream.
-  // ZKMI_SORT_SIDE=0: sorts back on the main stream (A/B runs).
-  static const bool sort_side = !(getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '0');
+  // ZKMI_SORT_SIDE=1: the digit sort runs on its own (high-priority) stream into one of two buffer sets, so the sort
+  // of proof i+1 overlaps the accumulations of proof i instead of standing between two accumulations on the main
+  // stream.  Measured: no gain over sorting on the main stream once the reductions are spread over three streams.
+  const bool sort_side = prover_sort_side();
   MsmSort& sz = (sort_side && (ctx->z_flip++ & 1u)) ? ctx->sort_z2 : ctx->sort;
+  // the five reductions of a proof on three streams (A, L | B1, H | B2): one stream is ~90 % busy with their
+  // latency chains and becomes the critical path (48.5 -> 50.0 proofs/s)
+  const bool aux_split = prover_aux_split();
+  const hipStream_t ra = ctx->stream_aux, rb = aux_split ? ctx->stream_aux2 : ctx->stream_aux,
+                    rc2 = aux_split ? ctx->stream_aux3 : ctx->stream_aux;
   const hipStream_t ss = sort_side ? ctx->stream_sort : st;
   if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_z[par], 0));  // the witness is in d_z
   if (G > 1)  // one digit sort for the whole group: bucket set b belongs to witness b (msm_sort.hip run_shared_batch)
@@ -683,13 +700,13 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], ss));
   if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sort[par], 0));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
-  ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, ctx->stream_aux, t,
+  ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 0, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, st, rb, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 1, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 2, sth));
   return ZKMI_OK;
 }
@@ -701,7 +718,7 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   const bool sh = pk->shared;
   static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
-  static const bool sort_side = !(getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '0');
+  const bool sort_side = prover_sort_side();
   const hipStream_t ss = sort_side ? ctx->stream_sort : st;
   ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_h[par], 0));  // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
@@ -716,8 +733,9 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
     ZK_HIP(ctx, hipEventRecord(ctx->ev_sorth[par], ss));
     ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
   }
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, ctx->stream_aux, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, 4 * par + 3, sth));
+  const bool aux_split = prover_aux_split();
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, aux_split ? ctx->stream_aux2 : ctx->stream_aux, t,
+                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth));
   return ZKMI_OK;
 }
 
@@ -847,7 +865,7 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
-    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
+    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
       (void)hipStreamSynchronize(q);
     ctx->err = msg;
     return code;

@@ -112,8 +112,9 @@ struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
   enum { SLOTS = 12, SLOT_PTS = 64 * 32 };  // three proofs in flight (groth16.hip PROOF_RING) x four G1 MSMs
   XYZZ<F>* buckets = nullptr;  // SLOTS x cap_buckets: one bucket array per MSM in flight
-  XYZZ<F>* segsum = nullptr;
+  XYZZ<F>* segsum = nullptr;  // SLOTS x seg_cap: reductions of different slots may run on different streams
   XYZZ<F>* segw = nullptr;
+  uint64_t seg_cap = 0;
   XYZZ<F>* heavy_partial = nullptr;  // MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event

@@ -638,8 +638,9 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   release();
   hipError_t e;
   if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need * SLOTS)) != hipSuccess) return e;
-  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
-  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * msm_max_segments(need))) != hipSuccess) return e;
+  seg_cap = msm_max_segments(need);
+  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
+  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT)) != hipSuccess) return e;
   if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * SLOTS)) != hipSuccess) return e;  // one list per slot
@@ -767,17 +768,19 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
   const int seg = 1 << pl.seg_log;
+  XYZZ<F>* const ssum = segsum + (size_t)slot * seg_cap;
+  XYZZ<F>* const sw = segw + (size_t)slot * seg_cap;
   if constexpr (std::is_same<F, Fq2_28>::value) {
-    hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw,
+    hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
                        tot_segs, seg);
   } else {
-    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, segsum, segw, tot_segs, seg);
+    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg);
   }
   const int plain_job = pl.shared ? 1 + msm_seg_bits(pl) : -1;
   const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
   XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
   hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                     segsum, segw, segs_per_win, dp, plain_job);
+                     ssum, sw, segs_per_win, dp, plain_job);
   if (prof) prof->end(ph_reduce, st_reduce);
   e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
                      hipMemcpyDeviceToHost, st_reduce);
