@@ -102,7 +102,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithPriority(&c->stream_aux3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_front, hipStreamNonBlocking,
-                                  (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '1') ? prio_hi : 0) != hipSuccess ||
+                                  (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '0') ? 0 : prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, prio_hi) != hipSuccess) {

@@ -544,8 +544,16 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
   const int w = blockIdx.y;
   const XYZZ<F>* src = (job == 0 ? segw : segsum) + (size_t)w * segs_per_win;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  for (uint32_t t = threadIdx.x; t < segs_per_win; t += blockDim.x) {
-    if (job == 0 || job == plain_job || ((t >> (job - 1)) & 1u)) {
+  if (job == 0 || job == plain_job) {
+    for (uint32_t t = threadIdx.x; t < segs_per_win; t += blockDim.x) {
+      XYZZ<F> v = load_vec(src + t);
+      acc.add(v);
+    }
+  } else {
+    // bit job: enumerate only the segments whose bit (job - 1) is set, so that no lane idles through an addition
+    const uint32_t b = (uint32_t)(job - 1), lowmask = (1u << b) - 1u;
+    for (uint32_t u = threadIdx.x; u < segs_per_win / 2; u += blockDim.x) {
+      const uint32_t t = ((u & ~lowmask) << 1) | (1u << b) | (u & lowmask);
       XYZZ<F> v = load_vec(src + t);
       acc.add(v);
     }
