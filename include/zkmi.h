@@ -128,6 +128,10 @@ int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* con
  * against the 32-bit-limb host arithmetic; *out_mismatches must be 0. */
 int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
 
+/* Host-executed self-test of the scalar multiplications of proof assembly (fixed-base tables for delta, joint
+ * two-scalar multiplication) against plain double-and-add in G1 and G2; *out_mismatches must be 0. */
+int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
+
 /* ---- group / encoding helpers (host) -------------------------------------- */
 int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]);
 int32_t zkmi_g1_decompress(const uint8_t in[48], uint8_t out_affine[96]);

@@ -176,6 +176,7 @@ int main(int argc, char** argv) {
   }
   uint32_t mism = 1;
   EXPECT(zkmi_selftest_fq28(3, 50, &mism) == 0 && mism == 0);
+  EXPECT(zkmi_selftest_assembly(9, 6, &mism) == 0 && mism == 0);
   EXPECT(zkmi_selftest_poseidon(ZKMI_FIELD_BLS12_381_FR, 5, 10, &mism) == 0 && mism == 0);
 
   // --- the C++ oracle: small NTT round trip and MSMs over the product's generator multiples

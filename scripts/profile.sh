@@ -26,6 +26,13 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_icache" -- $BENCH --steps "$STEPS_PMC" \
   > "$OUT/pmc_icache.log" 2>&1
 
+# 2b. every kernel alone on the chip (counter collection serialises dispatches): clock, waves per SIMD, issue rate
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$OUT/alone" -- $BENCH --steps "$STEPS_PMC" \
+  > "$OUT/alone.log" 2>&1
+python3 scripts/kernel_alone_report.py "$OUT/alone" > "$DST/kernels_alone_bench_steps${STEPS_PMC}.txt" 2>> "$OUT/alone.log"
+# 2c. not under the profiler: the complete default bench line and the proof rate per domain size
+python3 scripts/domain_sweep.py 12 21 > "$DST/domain_sweep.txt" 2> "$OUT/domain_sweep.err"
+
 # 3. summaries that are small enough to commit
 STATS=$(find "$OUT/trace" -name '*_kernel_stats.csv' | head -1)
 TRACE=$(find "$OUT/trace" -name '*_kernel_trace.csv' | head -1)
@@ -33,4 +40,8 @@ TRACE=$(find "$OUT/trace" -name '*_kernel_trace.csv' | head -1)
 [ -n "$TRACE" ] && python3 scripts/trace_timeline.py "$TRACE" "$DST/timeline_bench_steps${STEPS_TRACE}.txt"
 python3 scripts/pmc_summary.py "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" $((STEPS_PMC + 1)) "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_icache"
 grep -h '^{' "$OUT/trace.log" | tail -1 > "$DST/bench_line_under_trace.json"
+# the complete line again, now with traffic / instruction counts from the fresh PMC summary
+python3 bench.py --pmc-summary "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" > "$DST/bench_line_full.json" 2> "$OUT/bench_full.err"
+# gpurun only brings gpurun_out/ back: leave a copy of the summaries there
+mkdir -p "gpurun_out/profiles_$ROUND" && cp -r "$DST/." "gpurun_out/profiles_$ROUND/"
 ls -la "$DST"

@@ -111,6 +111,16 @@ def test_shielder_relation_shape_at_config0_size(zk):
     r.free()
 
 
+def test_assembly_scalar_multiplications_selftest(zk):
+    """Host arithmetic of proof assembly: fixed-base delta tables and the joint s*A + r*B1 multiplication equal
+    plain double-and-add in G1 and G2 (scalars 0, 1, r - 1 and random; P + P and P - P in the joint form)."""
+    import ctypes as C
+
+    bad = C.c_uint32(99)
+    assert zk.lib.zkmi_selftest_assembly(C.c_uint64(21), C.c_uint32(12), C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_host_verifier_on_golden_proof(zk):
     gd = golden("groth16_n128.json")
     wit = H(gd["witness"])

@@ -834,6 +834,74 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   return prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
 }
 
+// Host self-test of the scalar multiplications of proof assembly (curve.hpp FixedBase4, scalar_mul2) against the plain
+// double-and-add, in G1 and G2, on seeded scalars including 0, 1 and r - 1.  No GPU involved.
+int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
+  if (!out_mismatches) return ZKMI_ERR_BAD_ARG;
+  uint64_t st = seed;
+  auto next = [&]() {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto scalar = [&](uint32_t it, uint32_t k[8]) {
+    for (int i = 0; i < 8; i += 2) {
+      const uint64_t v = next();
+      k[i] = (uint32_t)v;
+      k[i + 1] = (uint32_t)(v >> 32);
+    }
+    k[7] &= 0x3fffffffu;  // < 2^254 < r
+    if (it % 5 == 1) memset(k, 0, 32);
+    if (it % 5 == 2) {
+      memset(k, 0, 32);
+      k[0] = 1;
+    }
+    if (it % 5 == 3) {
+      memcpy(k, FrParams::MOD, 32);
+      k[0] -= 1;  // r - 1
+    }
+  };
+  auto same1 = [](const G1XYZZ& a, const G1XYZZ& b) {
+    const G1Affine x = a.to_affine(), y = b.to_affine();
+    return x.x == y.x && x.y == y.y;
+  };
+  auto same2 = [](const G2XYZZ& a, const G2XYZZ& b) {
+    const G2Affine x = a.to_affine(), y = b.to_affine();
+    return x.x == y.x && x.y == y.y;
+  };
+  uint32_t bad = 0;
+  uint32_t k[8], k2[8];
+  scalar(0, k);
+  const G1Affine p1 = scalar_mul(G1XYZZ::from_affine(g1_generator()), k, 8).to_affine();
+  scalar(0, k);
+  const G2Affine p2 = scalar_mul(G2XYZZ::from_affine(g2_generator()), k, 8).to_affine();
+  std::unique_ptr<FixedBase4<Fq>> t1(new FixedBase4<Fq>());
+  std::unique_ptr<FixedBase4<Fq2>> t2(new FixedBase4<Fq2>());
+  t1->build(p1);
+  t2->build(p2);
+  const G1XYZZ q1 = scalar_mul(G1XYZZ::from_affine(p1), k, 8);  // a second, unrelated G1 point
+  for (uint32_t it = 0; it < iters; it++) {
+    scalar(it, k);
+    scalar(it + 2, k2);
+    if (!same1(t1->mul(k), scalar_mul(G1XYZZ::from_affine(p1), k, 8))) bad++;
+    if (!same2(t2->mul(k), scalar_mul(G2XYZZ::from_affine(p2), k, 8))) bad++;
+    G1XYZZ want = scalar_mul(G1XYZZ::from_affine(p1), k, 8);
+    want.add(scalar_mul(q1, k2, 8));
+    if (!same1(scalar_mul2(G1XYZZ::from_affine(p1), k, q1, k2), want)) bad++;
+    // equal and opposite points: the shared doubling chain must survive P + P and P - P
+    G1XYZZ dbl = scalar_mul(G1XYZZ::from_affine(p1), k, 8);
+    dbl.add(scalar_mul(G1XYZZ::from_affine(p1), k2, 8));
+    if (!same1(scalar_mul2(G1XYZZ::from_affine(p1), k, G1XYZZ::from_affine(p1), k2), dbl)) bad++;
+    G1XYZZ opp = scalar_mul(G1XYZZ::from_affine(p1), k, 8);
+    opp.add(scalar_mul(G1XYZZ::from_affine(p1).neg(), k, 8));
+    if (!opp.is_inf() || !scalar_mul2(G1XYZZ::from_affine(p1), k, G1XYZZ::from_affine(p1).neg(), k).is_inf()) bad++;
+  }
+  *out_mismatches = bad;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
                            const uint8_t s_bytes[32], uint8_t out_proof[192]) {
   ZK_ENTER(ctx);

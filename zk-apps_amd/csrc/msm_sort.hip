@@ -385,6 +385,10 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
     if (thr < 48) thr = 48;
   }
   p.seg_log = buckets <= (1u << 13) ? 2 : 4;  // 4-bucket segments only where the reduction is pure latency
+  {
+    static const int seg_env = getenv("ZKMI_SEG_LOG") ? atoi(getenv("ZKMI_SEG_LOG")) : 0;  // A/B: segment length of big plans
+    if (seg_env >= 2 && seg_env <= 7 && buckets > (1u << 13)) p.seg_log = seg_env;
+  }
   if ((1u << p.seg_log) > p.nb) p.seg_log = 0;
   p.heavy_thr = (uint32_t)thr;
   p.heavy_shift = 0;
