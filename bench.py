@@ -409,6 +409,16 @@ def main():
                                  "note": "witnesses in pinned host memory (32 MiB each at 2^20), uploaded on a copy stream "
                                          "overlapped with the previous proofs; rank 0 only"}
     if rank == 0 and world == 1 and not args.no_secondary:
+        # latency of ONE proof on an otherwise idle GPU (nothing to overlap with): witness resident -> 192 bytes on the host
+        lat = []
+        for i in range(5):
+            ctx.sync()
+            t0 = time.perf_counter()
+            one = ctx.groth16_prove_dev(pk, d_wits[i % 2].data_ptr(), rs[i % 2][0], rs[i % 2][1])
+            lat.append(time.perf_counter() - t0)
+        out["single_proof_latency_ms"] = {"median": 1e3 * sorted(lat)[2], "min": 1e3 * min(lat),
+                                          "same_bytes_as_batch": one == proofs[0] if args.steps >= 1 else None,
+                                          "note": "zkmi_groth16_prove_dev, one proof in flight, wall clock incl. host assembly"}
         pk.free()
         pk = None
         out["msm_g1_end_to_end"] = secondary_measurements(z, ctx, log_n)
