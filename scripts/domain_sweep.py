@@ -15,11 +15,11 @@ def main():
     hi = int(sys.argv[2]) if len(sys.argv) > 2 else 21
     z = bench.load_pkg().Zkmi()
     ctx = z.context(0)
-    print(f"{'log_n':>5} {'proofs':>7} {'proofs/s':>10} {'ms/proof':>9}  verified")
+    print(f"{'log_n':>5} {'proofs':>7} {'proofs/s':>10} {'ms/proof':>9} {'1-proof latency ms':>19}  verified")
     for lg in range(lo, hi + 1):
         count = max(12, min(1024, (1 << 24) >> lg))
         r = bench.small_domain_rate(z, ctx, "poseidon" if lg >= 13 else "chain", lg, count)
-        print(f"{lg:>5} {r['proofs']:>7} {r['proofs_per_s']:>10.1f} {r['ms_per_proof']:>9.3f}  {r['verified_by_pairing']}", flush=True)
+        print(f"{lg:>5} {r['proofs']:>7} {r['proofs_per_s']:>10.1f} {r['ms_per_proof']:>9.3f} {r['single_proof_latency_ms']:>19.2f}  {r['verified_by_pairing']}", flush=True)
         torch.cuda.empty_cache()
 
 
