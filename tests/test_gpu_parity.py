@@ -1348,5 +1348,8 @@ def test_grouped_prover_partial_groups(ctx, zk, lg, count):
     for i in (0, count // 2, count - 1):
         assert zk.groth16_verify(vk, frs(cases[idx[i]][1]), proofs[i]) is True
         assert ctx.groth16_prove_dev(pk, d[idx[i]].data_ptr(), rs[i], ss[i]) == proofs[i]
+    # the host-witness entry point (uploads on the copy stream, group by group) gives the same bytes
+    hw = [torch.frombuffer(bytearray(w), dtype=torch.uint8).pin_memory() for w in wits]
+    assert ctx.groth16_prove_batch_host(pk, [hw[j].data_ptr() for j in idx], rs, ss) == proofs
     pk.free()
     r1.free()

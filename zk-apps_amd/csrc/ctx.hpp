@@ -20,6 +20,7 @@ struct zkmi_ctx {
   hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof
   hipStream_t stream_heavy = nullptr;  // heavy-bucket kernels beside the accumulations (msm.hpp run_device)
   hipStream_t stream_sort = nullptr;   // the prover's digit sorts, beside the previous proof's accumulations
+  hipStream_t stream_acc2 = nullptr, stream_acc3 = nullptr;  // B1 / L accumulations of a single small proof (groth16.hip)
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
   hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
   unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes

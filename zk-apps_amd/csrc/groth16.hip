@@ -700,13 +700,21 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], ss));
   if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sort[par], 0));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
+  // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
+  // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
+  const bool spread = G == 1 && pk->log_n <= 16;
+  const hipStream_t sb1 = spread ? ctx->stream_acc2 : st, sl = spread ? ctx->stream_acc3 : st;
+  if (spread) {
+    ZK_HIP(ctx, hipStreamWaitEvent(sb1, ctx->ev_sort[par], 0));
+    ZK_HIP(ctx, hipStreamWaitEvent(sl, ctx->ev_sort[par], 0));
+  }
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
   ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 0, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, st, rb, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, sb1, rb, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 1, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, sl, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 2, sth));
   return ZKMI_OK;
 }
@@ -742,8 +750,13 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
 // Host part: wait for the slot set's partials, combine windows, assemble A, B, C
 //  and compress.  The GPU may already be running the next proof.
 // A, B, C of one proof from its five MSM results + compression; pure host arithmetic
-static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G1XYZZ& acc_l, const G1XYZZ& acc_h,
-                           const G2XYZZ& acc_b2, const uint8_t r_bytes[32], const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+// Stage 1 needs only the MSMs over z that finish first (A, B1, B2): A, B (in G1 and G2) and s*A + r*B1 - rs*delta.
+struct AssemblyHead {
+  G1XYZZ g_a, g_c;
+  G2XYZZ g2_b;
+};
+static AssemblyHead assemble_head(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G2XYZZ& acc_b2,
+                                  const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
   uint32_t rk[8], sk[8], rsk[8];
   memcpy(rk, r_bytes, 32);
   memcpy(sk, s_bytes, 32);
@@ -751,26 +764,37 @@ static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ&
   fr_from_wire(r_bytes, &rm);
   fr_from_wire(s_bytes, &sm);
   fr_limbs(rm * sm, rsk);
+  AssemblyHead h;
   // r * delta, s * delta, rs * delta from the key's fixed-base tables; s * A + r * B1 over one doubling chain
-  G1XYZZ g_a = pk->delta1_tab->mul(rk);
-  g_a.madd(pk->a0);
-  g_a.add(acc_a);
-  g_a.madd(pk->alpha_g1);
+  h.g_a = pk->delta1_tab->mul(rk);
+  h.g_a.madd(pk->a0);
+  h.g_a.add(acc_a);
+  h.g_a.madd(pk->alpha_g1);
   G1XYZZ g1_b = pk->delta1_tab->mul(sk);
   g1_b.madd(pk->b1_0);
   g1_b.add(acc_b1);
   g1_b.madd(pk->beta_g1);
-  G2XYZZ g2_b = pk->delta2_tab->mul(sk);
-  g2_b.madd(pk->b2_0);
-  g2_b.add(acc_b2);
-  g2_b.madd(pk->beta_g2);
-  G1XYZZ g_c = scalar_mul2(g_a, sk, g1_b, rk);
-  g_c.add(pk->delta1_tab->mul(rsk).neg());
-  g_c.add(acc_l);
-  g_c.add(acc_h);
-  g1_compress(g_a.to_affine(), out_proof);
-  g2_compress(g2_b.to_affine(), out_proof + 48);
-  g1_compress(g_c.to_affine(), out_proof + 144);
+  h.g2_b = pk->delta2_tab->mul(sk);
+  h.g2_b.madd(pk->b2_0);
+  h.g2_b.add(acc_b2);
+  h.g2_b.madd(pk->beta_g2);
+  h.g_c = scalar_mul2(h.g_a, sk, g1_b, rk);
+  h.g_c.add(pk->delta1_tab->mul(rsk).neg());
+  return h;
+}
+// Stage 2: C += L + H, compression of A, B, C
+static void assemble_tail(AssemblyHead& h, const G1XYZZ& acc_l, const G1XYZZ& acc_h, uint8_t out_proof[192]) {
+  h.g_c.add(acc_l);
+  h.g_c.add(acc_h);
+  g1_compress(h.g_a.to_affine(), out_proof);
+  g2_compress(h.g2_b.to_affine(), out_proof + 48);
+  g1_compress(h.g_c.to_affine(), out_proof + 144);
+}
+// A, B, C of one proof from its five MSM results + compression; pure host arithmetic
+static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G1XYZZ& acc_l, const G1XYZZ& acc_h,
+                           const G2XYZZ& acc_b2, const uint8_t r_bytes[32], const uint8_t s_bytes[32], uint8_t out_proof[192]) {
+  AssemblyHead h = assemble_head(pk, acc_a, acc_b1, acc_b2, r_bytes, s_bytes);
+  assemble_tail(h, acc_l, acc_h, out_proof);
 }
 
 // Host part: wait for the slot set's partials, combine windows, assemble and compress the G proofs of the group
@@ -781,11 +805,17 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
   std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
   std::vector<G2XYZZ> acc_b2(G);
   if (G == 1) {
+    // one proof: the scalar multiplications of assembly (the expensive part) run while the GPU still works on L and H
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
-    ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
     ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+    AssemblyHead head = assemble_head(pk, acc_a[0], acc_b1[0], acc_b2[0], r_bytes, s_bytes);
+    ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3));
+    if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+    if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+    assemble_tail(head, acc_l[0], acc_h[0], out_proofs);
+    return ZKMI_OK;
   } else {
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
@@ -800,9 +830,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     assemble_proof(pk, acc_a[b], acc_b1[b], acc_l[b], acc_h[b], acc_b2[b], r_bytes + 32ull * b, s_bytes + 32ull * b,
                    out_proofs + 192ull * b);
   };
-  if (G == 1) {
-    one(0);
-  } else {
+  {
     // host threads for the assembly of a group: ZKMI_HOST_THREADS, default min(16, hardware threads)
     static const unsigned cap = []() {
       const char* env = getenv("ZKMI_HOST_THREADS");
@@ -933,7 +961,8 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
-    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort})
+    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort,
+                          ctx->stream_acc2, ctx->stream_acc3})
       (void)hipStreamSynchronize(q);
     ctx->err = msg;
     return code;

@@ -115,7 +115,7 @@ struct MsmEngine {
   XYZZ<F>* segsum = nullptr;  // SLOTS x seg_cap: reductions of different slots may run on different streams
   XYZZ<F>* segw = nullptr;
   uint64_t seg_cap = 0;
-  XYZZ<F>* heavy_partial = nullptr;  // MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
+  XYZZ<F>* heavy_partial = nullptr;  // SLOTS x MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event
   XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS

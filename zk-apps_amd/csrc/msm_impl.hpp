@@ -650,7 +650,7 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
-  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT)) != hipSuccess) return e;
+  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * SLOTS)) != hipSuccess) return e;  // per slot
   if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * SLOTS)) != hipSuccess) return e;  // one list per slot
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
@@ -751,10 +751,11 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
   const hipStream_t sh = side ? st_heavy : st;
+  XYZZ<F>* const hp = heavy_partial + (size_t)slot * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, sh, d_bases,
-                     sort.begin, sort.count, sort.heavy, sort.sorted, bk, heavy_partial);
+                     sort.begin, sort.count, sort.heavy, sort.sorted, bk, hp);
   hipLaunchKernelGGL(k_heavy_combine<F>, dim3(64), dim3(MSM_HSPLIT), sizeof(XYZZ<F>) * MSM_HSPLIT, sh, sort.heavy,
-                     heavy_partial, bk);
+                     hp, bk);
   if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
   sort.readers.push_back(acc_done[slot]);  // the next sort into these buffers may be queued on another stream
   if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;

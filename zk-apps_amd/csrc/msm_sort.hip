@@ -384,7 +384,9 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
     thr = 3 * mean;
     if (thr < 48) thr = 48;
   }
-  p.seg_log = buckets <= (1u << 13) ? 2 : 4;  // 4-bucket segments only where the reduction is pure latency
+  // short segments where the reduction is pure latency (one small MSM: a segment is a dependent chain of 2 x length
+  // additions), 16 buckets once there are enough segments to fill the chip
+  p.seg_log = buckets <= (1u << 13) ? 2 : buckets <= (1u << 15) ? 3 : 4;
   {
     static const int seg_env = getenv("ZKMI_SEG_LOG") ? atoi(getenv("ZKMI_SEG_LOG")) : 0;  // A/B: segment length of big plans
     if (seg_env >= 2 && seg_env <= 7 && buckets > (1u << 13)) p.seg_log = seg_env;
