@@ -94,6 +94,12 @@ int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out);
 int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out);
 /* the slice P_first .. P_{first+n-1} of the same sequence (a rank's share of a point-split MSM) */
 int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n, zkmi_bases_g1** out);
+/* Bases used for many MSMs of their full length (an SRS, a proving-key query): build the table 2^(c w) * P_i once
+ * (ceil(255 / c) x n points of HBM).  Afterwards zkmi_msm_g{1,2}[_dev] with n == the number of bases run the prover's
+ * shared-bucket schedule (12-13 insertions per scalar instead of 16); other n, and the *_windows entry points, keep the
+ * windowed schedule.  Same results either way. */
+int32_t zkmi_bases_g1_prepare(zkmi_ctx* ctx, zkmi_bases_g1* b);
+int32_t zkmi_bases_g2_prepare(zkmi_ctx* ctx, zkmi_bases_g2* b);
 int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out_affine);
 int32_t zkmi_bases_g2_read(zkmi_ctx* ctx, const zkmi_bases_g2* b, uint64_t first, uint64_t count, uint8_t* out_affine);
 

@@ -892,6 +892,38 @@ def test_bn254_prepared_srs_matches_plain_msm(ctx):
     b.free()
 
 
+def test_prepared_bases_match_plain_msm(ctx):
+    """zkmi_bases_g{1,2}_prepare (table of 2^(c w) multiples, shared buckets) gives the same MSM as the windowed
+    schedule: small, odd and plan-boundary lengths, edge scalars (0, 1, r - 1, equal scalars on equal points force the
+    P + P redo path), a shorter MSM over prepared bases, and 2^22 terms against the closed form."""
+    from oracle import cpp as ocpp
+
+    rng = ec.SplitMix64(4242)
+    for group in (1, 2):
+        for n in (1, 2, 33, 1000, (1 << 13) + 5, 70000 if group == 1 else 9000):
+            sc = [rng.fr() for _ in range(n)]
+            sc[0] = R - 1
+            if n > 3:
+                sc[1], sc[2], sc[3] = 0, 1, sc[0]
+            raw = frs(sc)
+            b = ctx.bases_g1_synthetic(n) if group == 1 else ctx.bases_g2_synthetic(n)
+            msm = ctx.msm_g1 if group == 1 else ctx.msm_g2
+            plain = msm(raw, b)
+            assert msm(raw, b.prepare()) == plain
+            if n <= 9000:
+                want = (ocpp.msm_g1 if group == 1 else ocpp.msm_g2)(raw, b.read(0, n))
+                assert plain == want
+            if n > 33:  # fewer scalars than bases: windowed schedule again
+                short = (ocpp.msm_g1 if group == 1 else ocpp.msm_g2)(raw[: 32 * 33], b.read(0, 33))
+                assert msm(raw[: 32 * 33], b) == short
+            b.free()
+    n = 1 << 22
+    raw, tot, wtot = _torch_scalars(n, 23)
+    b = ctx.bases_g1_synthetic(n).prepare()
+    assert ctx.msm_g1_dev(raw.data_ptr(), n, b) == _closed_form_g1(tot, wtot)
+    b.free()
+
+
 def test_msm_random_sizes_vs_cpp_oracle(ctx):
     """A sweep over irregular lengths (1 ... 40 000, powers of two and their neighbours included) of G1
     and G2 MSMs against the C++ oracle on the same seeded inputs; every plan boundary of the window /

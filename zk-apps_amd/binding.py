@@ -821,6 +821,12 @@ class Bases:
         self.ctx._chk(fn(self.ctx.h, self.h, C.c_uint64(first), C.c_uint64(count), out))
         return bytes(out)
 
+    def prepare(self):
+        """Table of 2^(c w) multiples for repeated full-length MSMs over these bases (zkmi_bases_g{1,2}_prepare)."""
+        fn = self.ctx.lib.zkmi_bases_g1_prepare if self.group == 1 else self.ctx.lib.zkmi_bases_g2_prepare
+        self.ctx._chk(fn(self.ctx.h, self.h))
+        return self
+
     def free(self):
         if self.h:
             fn = self.ctx.lib.zkmi_bases_g1_free if self.group == 1 else self.ctx.lib.zkmi_bases_g2_free

@@ -29,6 +29,7 @@ template <class B>
 static void bases_destroy(B* b) {
   if (b->d) (void)hipFree(b->d);
   if (b->d28) (void)hipFree(b->d28);
+  if (b->tab) (void)hipFree(b->tab);
   delete b;
 }
 
@@ -53,6 +54,26 @@ static int32_t bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int3
     return ctx->hip_fail(e, "bases upload");
   }
   *out = b;
+  return ZKMI_OK;
+}
+
+// Fixed bases used for many MSMs of their full length (an SRS, a proving-key query): build the table
+// 2^(c w) * P_i once; zkmi_msm_g{1,2}[_dev] then run the shared-bucket schedule of the prover:
+// ceil(255 / c) insertions per scalar with c up to 22 instead of 16 windows of 16 bits.
+template <class F, class B>
+static int32_t bases_prepare(zkmi_ctx* ctx, B* b) {
+  if (!b || b->n == 0) return ZKMI_ERR_BAD_ARG;
+  if (b->tab) return ZKMI_OK;
+  const MsmPlan plan = msm_make_plan_shared(b->n);
+  // table indices (digit * n + point) share a 32-bit word with the sign bit
+  if ((uint64_t)plan.ndigits * b->n >= (1ull << 31)) return ctx->fail(ZKMI_ERR_BAD_ARG, "too many points for a table");
+  hipError_t e = msm_build_table<F>(b->d28, b->n, plan, &b->tab, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (b->tab) (void)hipFree(b->tab);
+    b->tab = nullptr;
+    return ctx->hip_fail(e, "bases table");
+  }
   return ZKMI_OK;
 }
 
@@ -288,6 +309,15 @@ int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
   return ZKMI_OK;
 }
 
+int32_t zkmi_bases_g1_prepare(zkmi_ctx* ctx, zkmi_bases_g1* b) {
+  ZK_ENTER(ctx);
+  return bases_prepare<Fq28>(ctx, b);
+}
+int32_t zkmi_bases_g2_prepare(zkmi_ctx* ctx, zkmi_bases_g2* b) {
+  ZK_ENTER(ctx);
+  return bases_prepare<Fq2_28>(ctx, b);
+}
+
 int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
   return zkmi_bases_g1_synthetic_range(ctx, 0, n, out);
 }
@@ -352,10 +382,15 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
                         uint8_t out_affine[96]) {
   ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
-  ZK_HIP(ctx, ctx->sort.reserve(n));
-  ZK_HIP(ctx, ctx->g1.reserve(n));
-  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  const bool shared = bases->tab != nullptr && n == bases->n && n > 0;  // prepared bases, full length
+  ZK_HIP(ctx, ctx->sort.reserve(n, shared));
+  ZK_HIP(ctx, ctx->g1.reserve(n, shared));
+  if (shared)
+    ZK_HIP(ctx, ctx->sort.run_shared(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  else
+    ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, shared ? bases->tab : bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(),
+                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   G1XYZZ res;
   ZK_HIP(ctx, ctx->g1.finish_host(&res));
   g1_to_wire(res.to_affine(), out_affine);
@@ -366,10 +401,15 @@ int32_t zkmi_msm_g2_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
                         uint8_t out_affine[192]) {
   ZK_ENTER(ctx);
   if (!ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || (n && !d_scalars)) return ZKMI_ERR_BAD_ARG;
-  ZK_HIP(ctx, ctx->sort.reserve(n));
-  ZK_HIP(ctx, ctx->g2.reserve(n));
-  ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
-  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
+  const bool shared = bases->tab != nullptr && n == bases->n && n > 0;
+  ZK_HIP(ctx, ctx->sort.reserve(n, shared));
+  ZK_HIP(ctx, ctx->g2.reserve(n, shared));
+  if (shared)
+    ZK_HIP(ctx, ctx->sort.run_shared(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  else
+    ZK_HIP(ctx, ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
+  ZK_HIP(ctx, ctx->g2.run_device(ctx->sort, shared ? bases->tab : bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(),
+                                 PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2));
   G2XYZZ res;
   ZK_HIP(ctx, ctx->g2.finish_host(&res));
   g2_to_wire(res.to_affine(), out_affine);

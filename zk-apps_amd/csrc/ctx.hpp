@@ -92,12 +92,14 @@ struct zkmi_bases_g1 {
   zkmi_ctx* ctx;
   zkmi::G1Affine* d = nullptr;
   zkmi::Affine<zkmi::Fq28>* d28 = nullptr;
+  zkmi::Affine<zkmi::Fq28>* tab = nullptr;  // optional: 2^(c w) * P_i for every digit position (zkmi_bases_g1_prepare)
   uint64_t n = 0;
 };
 struct zkmi_bases_g2 {
   zkmi_ctx* ctx;
   zkmi::G2Affine* d = nullptr;
   zkmi::Affine<zkmi::Fq2_28>* d28 = nullptr;
+  zkmi::Affine<zkmi::Fq2_28>* tab = nullptr;  // optional table (zkmi_bases_g2_prepare)
   uint64_t n = 0;
 };
 
