@@ -17,17 +17,17 @@ export TMPDIR=/tmp
 BENCH="python3 bench.py --warmup 1 --no-cpu-baseline --no-secondary --pmc-summary none"
 
 # 1. kernel trace + per-kernel statistics (durations of kernels on different streams overlap)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps "$STEPS_TRACE" > "$OUT/trace.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps "$STEPS_TRACE" > "$OUT/trace.log" 2>&1
 # 2. counters, one pass each
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU \
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_fetch.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_write.log" 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps "$STEPS_PMC" > "$OUT/pmc_sq.log" 2>&1
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_icache" -- $BENCH --steps "$STEPS_PMC" \
+timeout 900 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_icache" -- $BENCH --steps "$STEPS_PMC" \
   > "$OUT/pmc_icache.log" 2>&1
 
 # 2b. every kernel alone on the chip (counter collection serialises dispatches): clock, waves per SIMD, issue rate
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$OUT/alone" -- $BENCH --steps "$STEPS_PMC" \
+timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$OUT/alone" -- $BENCH --steps "$STEPS_PMC" \
   > "$OUT/alone.log" 2>&1
 python3 scripts/kernel_alone_report.py "$OUT/alone" > "$DST/kernels_alone_bench_steps${STEPS_PMC}.txt" 2>> "$OUT/alone.log"
 # 2c. not under the profiler: the complete default bench line and the proof rate per domain size

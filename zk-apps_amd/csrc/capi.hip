@@ -125,10 +125,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithPriority(&c->stream_front, hipStreamNonBlocking,
                                   (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '0') ? 0 : prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_acc2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_acc3, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess) {  // stream_sort / acc2 / acc3: lazily
     delete c;
     return ZKMI_ERR_HIP;
   }
@@ -156,7 +153,7 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (hipStream_t s : {ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort,
-                        ctx->stream_acc2, ctx->stream_acc3})
+                        ctx->stream_acc3})
     if (s) (void)hipStreamSynchronize(s);
   ctx->domains.clear();
   ctx->domains_bn.clear();
@@ -185,7 +182,6 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
   if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
   if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
-  if (ctx->stream_acc2) (void)hipStreamDestroy(ctx->stream_acc2);
   if (ctx->stream_acc3) (void)hipStreamDestroy(ctx->stream_acc3);
   delete ctx;
   return ZKMI_OK;
@@ -204,9 +200,8 @@ int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_heavy));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_sort));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_acc2));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_acc3));
+  for (hipStream_t s : {ctx->stream_sort, ctx->stream_acc3})
+    if (s) ZK_HIP(ctx, hipStreamSynchronize(s));
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -233,9 +228,8 @@ int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64
   (void)hipStreamSynchronize(ctx->stream_g2);
   (void)hipStreamSynchronize(ctx->stream_front);
   (void)hipStreamSynchronize(ctx->stream_heavy);
-  (void)hipStreamSynchronize(ctx->stream_sort);
-  (void)hipStreamSynchronize(ctx->stream_acc2);
-  (void)hipStreamSynchronize(ctx->stream_acc3);
+  for (hipStream_t s : {ctx->stream_sort, ctx->stream_acc3})
+    if (s) (void)hipStreamSynchronize(s);
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];

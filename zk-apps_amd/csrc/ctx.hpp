@@ -20,7 +20,7 @@ struct zkmi_ctx {
   hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof
   hipStream_t stream_heavy = nullptr;  // heavy-bucket kernels beside the accumulations (msm.hpp run_device)
   hipStream_t stream_sort = nullptr;   // the prover's digit sorts, beside the previous proof's accumulations
-  hipStream_t stream_acc2 = nullptr, stream_acc3 = nullptr;  // B1 / L accumulations of a single small proof (groth16.hip)
+  hipStream_t stream_acc3 = nullptr;  // L accumulation of a single small proof (groth16.hip); created at first use
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
   hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
   unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes
@@ -40,6 +40,14 @@ struct zkmi_ctx {
   void* d_pos[2] = {nullptr, nullptr};  // Poseidon constants per field (poseidon.hip)
   uint64_t d_work_cap = 0;
 
+  // optional streams are created at first use: every HIP stream of a priority class shares a few hardware queues,
+  // and streams that are never used only add aliasing (and slowed the traced bench down by orders of magnitude)
+  hipError_t lazy_stream(hipStream_t* s, bool high_priority) {
+    if (*s) return hipSuccess;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, high_priority ? hi : 0);
+  }
   zkmi::PhaseTimer* timer() { return prof.enabled ? &prof : nullptr; }
   int32_t fail(int32_t code, const std::string& msg) {
     err = msg;

@@ -687,6 +687,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   const bool aux_split = prover_aux_split();
   const hipStream_t ra = ctx->stream_aux, rb = aux_split ? ctx->stream_aux2 : ctx->stream_aux,
                     rc2 = aux_split ? ctx->stream_aux3 : ctx->stream_aux;
+  if (sort_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_sort, true));
   const hipStream_t ss = sort_side ? ctx->stream_sort : st;
   if (sort_side) ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_z[par], 0));  // the witness is in d_z
   if (G > 1)  // one digit sort for the whole group: bucket set b belongs to witness b (msm_sort.hip run_shared_batch)
@@ -703,7 +704,9 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
   // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
   const bool spread = G == 1 && pk->log_n <= 16;
-  const hipStream_t sb1 = spread ? ctx->stream_acc2 : st, sl = spread ? ctx->stream_acc3 : st;
+  // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
+  if (spread) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
+  const hipStream_t sb1 = spread ? ctx->stream_copy : st, sl = spread ? ctx->stream_acc3 : st;
   if (spread) {
     ZK_HIP(ctx, hipStreamWaitEvent(sb1, ctx->ev_sort[par], 0));
     ZK_HIP(ctx, hipStreamWaitEvent(sl, ctx->ev_sort[par], 0));
@@ -727,6 +730,7 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   const bool sort_side = prover_sort_side();
+  if (sort_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_sort, true));
   const hipStream_t ss = sort_side ? ctx->stream_sort : st;
   ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_h[par], 0));  // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
@@ -961,9 +965,10 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
-    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort,
-                          ctx->stream_acc2, ctx->stream_acc3})
+    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
       (void)hipStreamSynchronize(q);
+    for (hipStream_t q : {ctx->stream_sort, ctx->stream_acc3})
+      if (q) (void)hipStreamSynchronize(q);
     ctx->err = msg;
     return code;
   };
