@@ -130,6 +130,12 @@ int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uin
 int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* const* d_scalars, const uint64_t* counts,
                           const zkmi_bases_g1* const* bases, uint8_t out_affine[96]);
 
+/* The bucket plan the library would use for an MSM of n terms (host logic, no GPU): shared != 0 = the prover's
+ * shared-bucket schedule over precomputed tables, 0 = the windowed schedule.  out[0..5] = digit bits c, digits per
+ * scalar, partitions (shared) or windows (windowed), buckets per partition/window, log2 of the reduction segment
+ * length, heavy-bucket threshold. */
+int32_t zkmi_msm_plan_query(uint64_t n, int32_t shared, uint32_t out[6]);
+
 /* Host-executed self-test of the device limb representation (field28.hpp)
  * against the 32-bit-limb host arithmetic; *out_mismatches must be 0. */
 int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);

@@ -111,6 +111,37 @@ def test_shielder_relation_shape_at_config0_size(zk):
     r.free()
 
 
+def test_msm_plans_are_consistent(zk):
+    """Host logic of the bucket plans for every size the ABI admits: the digits cover 255 bits, the bucket array is
+    2^(c-1) wide, a partition fits the 2^15-counter LDS histogram, the prover's table index (digit * n + point) leaves
+    bit 31 to the sign up to 2^26 terms, a group of proofs has at most 64 partitions, and the digit widths are the
+    ones DESIGN.md 4.1 quotes."""
+    import ctypes as C
+
+    out = (C.c_uint32 * 6)()
+    quoted = {12: 13, 13: 13, 14: 15, 15: 15, 16: 16, 17: 17, 18: 17, 19: 17, 20: 20, 22: 20, 26: 20}
+    for lg in range(0, 28):
+        for n in {1 << lg, (1 << lg) - 1, (1 << lg) + 1} - {0}:
+            for shared in (0, 1):
+                if n > (1 << 28) - 1:
+                    continue
+                assert zk.lib.zkmi_msm_plan_query(C.c_uint64(n), C.c_int32(shared), out) == 0
+                c, nd, parts, nb, seg_log, heavy = list(out)
+                assert 4 <= c <= 22 and nd * c >= 255 and nb <= 1 << 15 and (nb & (nb - 1)) == 0
+                assert (1 << seg_log) <= nb and heavy >= 1
+                if shared:
+                    assert parts * nb == 1 << (c - 1) and parts <= 64
+                    if lg <= 26:
+                        assert nd * n < 1 << 31
+                    if n == 1 << lg and lg in quoted:
+                        assert c == quoted[lg], (lg, c)
+                    if lg <= 19:  # groups of 2^(20 - lg) proofs (at most 64) keep within 64 partitions
+                        assert min(64, 1 << max(0, 20 - lg)) * parts <= 64 or lg < 14
+                else:
+                    assert nb == 1 << (c - 1) and parts == nd and parts * c >= 255
+    assert zk.lib.zkmi_msm_plan_query(C.c_uint64(0), C.c_int32(0), out) != 0
+
+
 def test_assembly_scalar_multiplications_selftest(zk):
     """Host arithmetic of proof assembly: fixed-base delta tables and the joint s*A + r*B1 multiplication equal
     plain double-and-add in G1 and G2 (scalars 0, 1, r - 1 and random; P + P and P - P in the joint form)."""

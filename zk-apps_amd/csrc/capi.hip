@@ -303,6 +303,18 @@ int32_t zkmi_bases_g2_free(zkmi_bases_g2* b) {
   return ZKMI_OK;
 }
 
+int32_t zkmi_msm_plan_query(uint64_t n, int32_t shared, uint32_t out[6]) {
+  if (!out || n == 0 || n > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
+  const MsmPlan p = shared ? msm_make_plan_shared(n) : msm_make_plan(n);
+  out[0] = (uint32_t)p.c;
+  out[1] = (uint32_t)(shared ? p.ndigits : p.nwin);
+  out[2] = (uint32_t)p.nwin;
+  out[3] = p.nb;
+  out[4] = (uint32_t)p.seg_log;
+  out[5] = p.heavy_thr;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_bases_g1_prepare(zkmi_ctx* ctx, zkmi_bases_g1* b) {
   ZK_ENTER(ctx);
   return bases_prepare<Fq28>(ctx, b);
