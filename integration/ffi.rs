@@ -21,6 +21,8 @@ pub const ZKMI_MAX_TREE_HEIGHT: usize = 32;
 #[repr(C)] pub struct zkmi_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct zkmi_pk { _p: [u8; 0] }
 #[repr(C)] pub struct zkmi_r1cs { _p: [u8; 0] }
+#[repr(C)] pub struct zkmi_bases_g1 { _p: [u8; 0] }
+#[repr(C)] pub struct zkmi_bases_g2 { _p: [u8; 0] }
 
 /// = `Scalar { bytes: [u8; 32] }` (mocked_zk/src/scalar.rs:1-6), little-endian
 #[repr(C)] #[derive(Clone, Copy)] pub struct zkmi_scalar { pub bytes: [u8; 32] }
@@ -119,4 +121,23 @@ extern "C" {
     pub fn zkmi_poseidon_merkle_tree_dev(ctx: *mut zkmi_ctx, field: i32, d_nodes: *mut core::ffi::c_void, log_leaves: u32) -> i32;
     pub fn zkmi_poseidon_merkle_paths_dev(ctx: *mut zkmi_ctx, d_nodes: *const core::ffi::c_void, log_leaves: u32, leaf_idx: *const u32, n: u32,
                                           out_shape: *mut u8, out_paths: *mut u8) -> i32;
+
+    // the kernels under the prover, for a caller that keeps its own proof system (rows a6, a8, a9): what
+    // ark_poly's Radix2EvaluationDomain::{fft, ifft, coset_*} and ark_ec's VariableBaseMSM::msm_bigint become
+    pub fn zkmi_ntt_fr(ctx: *mut zkmi_ctx, data: *mut u8, log_n: u32, inverse: i32, coset: i32) -> i32;
+    pub fn zkmi_ntt_fr_dev(ctx: *mut zkmi_ctx, d_data: *mut core::ffi::c_void, log_n: u32, inverse: i32, coset: i32) -> i32;
+    pub fn zkmi_bases_g1_load(ctx: *mut zkmi_ctx, affine: *const u8, n: u64, check: i32, out: *mut *mut zkmi_bases_g1) -> i32;
+    pub fn zkmi_bases_g2_load(ctx: *mut zkmi_ctx, affine: *const u8, n: u64, check: i32, out: *mut *mut zkmi_bases_g2) -> i32;
+    pub fn zkmi_bases_g1_prepare(ctx: *mut zkmi_ctx, b: *mut zkmi_bases_g1) -> i32;
+    pub fn zkmi_bases_g2_prepare(ctx: *mut zkmi_ctx, b: *mut zkmi_bases_g2) -> i32;
+    pub fn zkmi_bases_g1_free(b: *mut zkmi_bases_g1) -> i32;
+    pub fn zkmi_bases_g2_free(b: *mut zkmi_bases_g2) -> i32;
+    pub fn zkmi_msm_g1(ctx: *mut zkmi_ctx, scalars: *const u8, n: u64, bases: *const zkmi_bases_g1, out_affine: *mut u8) -> i32;
+    pub fn zkmi_msm_g2(ctx: *mut zkmi_ctx, scalars: *const u8, n: u64, bases: *const zkmi_bases_g2, out_affine: *mut u8) -> i32;
+    pub fn zkmi_msm_g1_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g1, out_affine: *mut u8) -> i32;
+    pub fn zkmi_msm_g2_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g2, out_affine: *mut u8) -> i32;
+    // one MSM split by points over ranks (BASELINE config 3): per-window partials, all-gathered by the caller, combined anywhere
+    pub fn zkmi_msm_g1_windows_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g1, plan_n: u64,
+                                   out_windows_affine: *mut u8, out_nwin: *mut u32, out_window_bits: *mut u32) -> i32;
+    pub fn zkmi_msm_g1_combine(windows_affine: *const u8, n_ranks: u32, nwin: u32, window_bits: u32, out_affine: *mut u8) -> i32;
 }

@@ -21,6 +21,26 @@ def test_library_exports_every_declared_symbol(zk):
         assert hasattr(zk.lib, n), f"{n} declared in include/zkmi.h but not exported"
 
 
+def test_reference_side_bindings_name_only_exported_functions(zk):
+    """integration/ffi.rs (the extern block a maintainer adds to mocked_zk) and the C example bind nothing the
+    library does not export, and every function they bind is declared in include/zkmi.h with the same argument count."""
+    hdr = open(os.path.join(ROOT, "include", "zkmi.h")).read()
+    decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(zkmi_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, re.S)}
+    rs = open(os.path.join(ROOT, "integration", "ffi.rs")).read()
+    fns = re.findall(r"pub fn (zkmi_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rs, re.S)
+    assert len(fns) >= 50
+    for name, args in fns:
+        assert hasattr(zk.lib, name), f"{name} bound in integration/ffi.rs but not exported"
+        assert name in decl, f"{name} bound in integration/ffi.rs but not declared in include/zkmi.h"
+        n_rs = 0 if not args.strip() else args.count(",") + 1
+        c_args = decl[name].strip()
+        n_c = 0 if c_args in ("", "void") else c_args.count(",") + 1
+        assert n_rs == n_c, f"{name}: {n_rs} arguments in ffi.rs, {n_c} in zkmi.h"
+    ex = open(os.path.join(ROOT, "examples", "prove_withdraw.c")).read()
+    for name in set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", ex)):
+        assert hasattr(zk.lib, name), f"{name} called in examples/prove_withdraw.c but not exported"
+
+
 def test_ctx_create_without_gpu_fails_loudly(zk, pkg):
     if zk.device_count() > 0:
         pytest.skip("a GPU is visible")
