@@ -1320,6 +1320,18 @@ def test_arkworks_fixture_if_present(ctx, zk):
     r1.free()
 
 
+def test_soak_script_short_run():
+    """scripts/soak.py (the same batches proved over and over must give the same bytes; partial groups and single
+    proofs interleaved) in a short configuration; the long run is `python scripts/soak.py`."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    p = subprocess.run([sys.executable, "scripts/soak.py", "8", "3"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0 and "SOAK OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     """Small domains (the relation's natural size, BASELINE config 0): the batch entry point proves up to 64 proofs as
     ONE group (one digit sort, one accumulation launch per query, batched NTT passes).  70 proofs at N = 2^13 (two
