@@ -111,6 +111,7 @@ template <class F>
 struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
   enum { SLOTS = 12, SLOT_PTS = 64 * 32 };  // three proofs in flight (groth16.hip PROOF_RING) x four G1 MSMs
+  int nslots = SLOTS;  // slots the device buffers are sized for (the G2 engine serves one MSM per proof: 3)
   XYZZ<F>* buckets = nullptr;  // SLOTS x cap_buckets: one bucket array per MSM in flight
   XYZZ<F>* segsum = nullptr;  // SLOTS x seg_cap: reductions of different slots may run on different streams
   XYZZ<F>* segw = nullptr;

@@ -645,13 +645,13 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if (need <= cap_buckets) return hipSuccess;
   release();
   hipError_t e;
-  if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need * SLOTS)) != hipSuccess) return e;
+  if ((e = hipMalloc(&buckets, sizeof(XYZZ<F>) * need * nslots)) != hipSuccess) return e;
   seg_cap = msm_max_segments(need);
-  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
-  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * SLOTS)) != hipSuccess) return e;
+  if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
+  if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
-  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * SLOTS)) != hipSuccess) return e;  // per slot
-  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * SLOTS)) != hipSuccess) return e;  // one list per slot
+  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * nslots)) != hipSuccess) return e;  // per slot
+  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * nslots)) != hipSuccess) return e;  // one list per slot
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
     hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
@@ -673,6 +673,7 @@ template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
                                     hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot,
                                     hipStream_t st_heavy) {
+  if (slot < 0 || slot >= nslots) return hipErrorInvalidValue;
   const MsmPlan& pl = sort.plan;
   slot_plan[slot] = pl;
   const uint32_t tot_b = pl.nwin * pl.nb;
