@@ -63,7 +63,14 @@ def _worker(rank, world, port, q):
         wins.append(ec.g1_to_bytes(acc))
     got = par.msm_g1_combine_ranks(zk, b"".join(wins), nwin, c)
     exp = ec.g1_to_bytes(ec.msm_naive(ec.Fq, scalars, bases))
-    q.put((rank, spans, got == exp))
+    # --- the exchange of the prepared-bases form (scripts/run_multigpu.py config 3, second leg): every rank holds the
+    # complete sum over its slice as ONE point; all-gather of 96 bytes per rank, then product-side additions
+    mine = ec.g1_to_bytes(ec.msm_naive(ec.Fq, scalars[a:b], bases[a:b]))
+    parts = par.allgather_bytes(mine)
+    tot = parts[0]
+    for p in parts[1:]:
+        tot = zk.g1_add(tot, p)
+    q.put((rank, spans, got == exp and tot == exp))
     dist.destroy_process_group()
 
 
