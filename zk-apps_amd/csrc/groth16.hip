@@ -165,6 +165,7 @@ static bool prover_aux_split() {
 
 struct zkmi_pk {
   zkmi_ctx* ctx = nullptr;
+  int device = -1;
   uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
   // small domains: up to `gmax` proofs travel through the pipeline as ONE group (one sort, one accumulation launch
   // per query, batched NTT passes); every per-proof buffer below holds gmax vectors back to back
@@ -194,6 +195,7 @@ struct zkmi_pk {
   uint32_t* d_unsat = nullptr;  // per proof in flight: set by k_check_sat
   uint32_t* h_unsat = nullptr;  // pinned host copy, valid once the proof's H MSM has landed
   ~zkmi_pk() {
+    if (device >= 0) (void)hipSetDevice(device);  // the key's buffers live on its context's device (the ctx may be gone)
     for (int m = 0; m < 3; m++) {
       if (d_rowptr[m]) (void)hipFree(d_rowptr[m]);
       if (d_col[m]) (void)hipFree(d_col[m]);
@@ -211,6 +213,7 @@ struct zkmi_pk {
 
 static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   pk->ctx = ctx;
+  pk->device = ctx->device;
   pk->n_vars = r->n_vars;
   pk->n_pub = r->n_pub;
   pk->nc = r->n_constraints;
