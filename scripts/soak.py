@@ -1,8 +1,12 @@
 """Determinism soak: the same batch of proofs, proved again and again, must give the same bytes every time (a race in
 the pipeline shows up as a differing proof long before it shows up as a wrong one), and sampled proofs must verify.
 Usage: python scripts/soak.py [repeats_small [repeats_big]]   (defaults 100 40)"""
+import faulthandler
 import sys
 import time
+
+if __import__("os").environ.get("SOAK_WATCHDOG"):
+    faulthandler.dump_traceback_later(int(__import__("os").environ["SOAK_WATCHDOG"]), exit=True)
 
 sys.path.insert(0, ".")
 import torch
@@ -14,7 +18,12 @@ rs_big = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 z = bench.load_pkg().Zkmi()
 ctx = z.context(0)
 bad = 0
-for lg, count, reps in ((13, 200, rs_small), (14, 130, rs_small), (16, 40, rs_small // 2), (18, 12, rs_big), (20, 12, rs_big)):
+import os
+
+CASES = ((13, 200, rs_small), (14, 130, rs_small), (16, 40, rs_small // 2), (18, 12, rs_big), (20, 12, rs_big))
+if os.environ.get("SOAK_ODD"):  # the sizes in between (other group sizes, two partitions per proof, two-proof groups)
+    CASES = ((15, 70, rs_small // 2), (17, 20, rs_big), (19, 7, rs_big), (21, 4, max(2, rs_big // 4)))
+for lg, count, reps in CASES:
     r1, wits = bench.relation_and_witness(z, "poseidon", lg, [lg, lg + 100, lg + 200])
     rng = bench.SplitMix64(lg)
     pk, vk = ctx.groth16_setup(r1, b"".join(rng.fr_bytes() for _ in range(5)))
@@ -28,6 +37,8 @@ for lg, count, reps in ((13, 200, rs_small), (14, 130, rs_small), (16, 40, rs_sm
     t0 = time.time()
     diff = 0
     for rep in range(reps):
+        if os.environ.get("SOAK_VERBOSE"):
+            print(f"  2^{lg} rep {rep}", file=sys.stderr, flush=True)
         n = count if rep % 3 else count - (rep % 7)  # also partial last groups
         got = ctx.groth16_prove_batch_dev(pk, [d[j].data_ptr() for j in idx[:n]], rs[:n], ss[:n])
         diff += sum(1 for a, b in zip(got, ref) if a != b)

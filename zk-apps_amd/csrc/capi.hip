@@ -92,6 +92,8 @@ int32_t zkmi_device_count(int32_t* out_count) {
 
 // ZKMI_BACKTRACE=1: print the native stack on SIGSEGV / SIGABRT (debugging aid; the default handlers stay otherwise)
 static void zkmi_crash_handler(int sig) {
+  signal(SIGALRM, SIG_DFL);
+  alarm(10);  // backtrace() may need a lock the crashed thread holds: never turn a crash into a hang
   void* frames[64];
   const int n = backtrace(frames, 64);
   const char msg[] = "[zkmi] fatal signal, native backtrace:\n";
@@ -105,6 +107,8 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   if (!out_ctx) return ZKMI_ERR_BAD_ARG;
   *out_ctx = nullptr;
   if (getenv("ZKMI_BACKTRACE")) {
+    void* warm[4];
+    (void)backtrace(warm, 4);  // loads the unwinder now, not inside the signal handler
     signal(SIGSEGV, zkmi_crash_handler);
     signal(SIGABRT, zkmi_crash_handler);
   }

@@ -706,7 +706,8 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
   // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
   // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
-  const bool spread = G == 1 && pk->log_n <= 16;
+  static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
+  const bool spread = spread_on && G == 1 && pk->log_n <= 16;
   // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
   if (spread) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
   const hipStream_t sb1 = spread ? ctx->stream_copy : st, sl = spread ? ctx->stream_acc3 : st;
