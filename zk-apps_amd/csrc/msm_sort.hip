@@ -483,11 +483,21 @@ static uint64_t msm_max_entries(uint64_t n) {
   return best;
 }
 
+// more, smaller (chunk, window) tiles for big inputs: see shared_chunks below (ZKMI_WIN_CHUNKS=m forces the multiplier)
+static uint32_t chunk_multiplier(uint64_t n, const char* env_name, bool windowed) {
+  const char* e = getenv(env_name);
+  const int v = e ? atoi(e) : 0;
+  if (v >= 1 && v <= 64) return (uint32_t)v;
+  if (n < (1ull << 22)) return 1u;
+  if (windowed) return 4u;  // measured: 2^24 sort 8.9 -> 5.8 ms, 2^25 17.6 -> 12.3; no gain beyond 4x
+  return n >= (1ull << 26) ? 16u : n >= (1ull << 25) ? 8u : 4u;
+}
+
 static uint32_t pick_chunks(const MsmPlan& p) {
-  uint32_t nch = (256 + p.nwin - 1) / p.nwin;  // ~1 tile per CU
+  uint64_t nch = (uint64_t)((256 + p.nwin - 1) / p.nwin) * chunk_multiplier(p.n, "ZKMI_WIN_CHUNKS", true);  // ~1 tile per CU x multiplier
   const uint64_t max_by_n = (p.n + 1023) / 1024;
-  if (nch > max_by_n) nch = (uint32_t)(max_by_n ? max_by_n : 1);
-  return nch ? nch : 1;
+  if (nch > max_by_n) nch = max_by_n ? max_by_n : 1;
+  return nch ? (uint32_t)nch : 1;
 }
 
 static uint64_t msm_max_hist(uint64_t n) {
@@ -528,12 +538,7 @@ void MsmSort::release() {
 // (2^24 terms: sort 10.0 -> 6.1 ms with 4x, 2^26: 39.4 -> 26.4 ms with 16x; at 2^20 the extra histogram traffic costs more than it saves: 0.63 -> 1.39 ms
 // with 16x).  ZKMI_REC_CHUNKS=m forces the multiplier.
 static uint32_t shared_chunks(uint32_t P, uint64_t n) {
-  static const uint32_t forced = [] {
-    const char* e = getenv("ZKMI_REC_CHUNKS");
-    const int v = e ? atoi(e) : 0;
-    return (uint32_t)(v >= 1 && v <= 64 ? v : 0);
-  }();
-  const uint32_t mult = forced ? forced : n >= (1ull << 26) ? 16u : n >= (1ull << 25) ? 8u : n >= (1ull << 22) ? 4u : 1u;
+  const uint32_t mult = chunk_multiplier(n, "ZKMI_REC_CHUNKS", false);
   uint64_t nch = (uint64_t)((256 + P - 1) / P) * (P > 1 ? mult : 1);
   const uint64_t max_by_n = (n + 1023) / 1024;
   if (nch > max_by_n) nch = max_by_n ? max_by_n : 1;
