@@ -53,6 +53,8 @@ typedef struct zkmi_pk zkmi_pk;
 
 /* ---- library / context -------------------------------------------------- */
 const char* zkmi_version(void);
+/* HIP_VERSION the library was built with / hipRuntimeGetVersion of the runtime it is bound to (diagnostics) */
+int32_t zkmi_hip_versions(int32_t* out_build, int32_t* out_runtime);
 int32_t zkmi_device_count(int32_t* out_count);
 int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx);
 int32_t zkmi_ctx_destroy(zkmi_ctx* ctx);

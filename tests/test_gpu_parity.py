@@ -46,9 +46,11 @@ def test_library_before_torch_shares_one_hip_runtime():
         "print('ok', int(t.sum()))\n"
     ) % ROOT
     try:
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
-    except subprocess.TimeoutExpired as e:  # a second process on a busy device: not the property under test
-        pytest.skip("child process did not finish in 240 s: %r" % ((e.stderr or b"")[-2000:],))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=400)
+    except subprocess.TimeoutExpired as e:
+        # a hang in context creation is a defect of the product path, never a skip (the child dumps its Python
+        # stacks after 150 s through faulthandler: they are in e.stderr)
+        pytest.fail("child process did not finish in 400 s: %r" % ((e.stderr or b"")[-3000:],))
     assert r.returncode == 0 and "ok 2016" in r.stdout, r.stdout + r.stderr
 
 

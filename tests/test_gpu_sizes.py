@@ -1,0 +1,202 @@
+"""GPU parity at BASELINE.json's full sizes, byte for byte against the C++ oracle (oracle/zkmi_oracle.cpp, the
+multi-threaded restatement: seconds per case on the GPU box's host cores), plus the key-lifecycle churn.
+
+The smaller-size sweeps, golden fixtures and property tests live in test_gpu_parity.py; this file closes the gap the
+round-2 verdict named: NTT at 2^20 / 2^22 in all four modes, G1 MSM at 2^20 (uniform and witness-like), G2 MSM at 2^18
+(oracle) and 2^22 (closed form), full proof bytes at 2^18 and 2^20 over the ORACLE's own trusted setup."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import bls12_381 as ec
+from oracle.bls12_381 import R
+
+pytestmark = pytest.mark.gpu
+
+
+def frs(vals):
+    return b"".join(ec.fr_to_bytes(v) for v in vals)
+
+
+def _canonical_bytes(n, seed):
+    """n uniformly random canonical scalars (< 2^254 < r) as wire bytes."""
+    a = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x3F
+    return a
+
+
+def _witness_like(n, seed):
+    """40 % zero, 20 % one, 10 % below 2^16, 30 % uniform."""
+    rng = np.random.default_rng(seed)
+    a = _canonical_bytes(n, seed + 1)
+    kind = rng.random(n)
+    a[kind < 0.4] = 0
+    one = (kind >= 0.4) & (kind < 0.6)
+    a[one] = 0
+    a[one, 0] = 1
+    small = (kind >= 0.6) & (kind < 0.7)
+    a[small, 2:] = 0
+    return a
+
+
+@pytest.mark.parametrize("lg", [20, 22])
+def test_ntt_full_size_all_modes_vs_cpp_oracle(ctx, lg):
+    """Row a6 at BASELINE's sizes (2^20: configs 1-2, 2^22: config 4): forward, inverse, coset forward, coset inverse,
+    every output byte against the C++ oracle (= ark-poly's Radix2EvaluationDomain as restated in oracle/ntt.py)."""
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    x = _canonical_bytes(1 << lg, 100 + lg).tobytes()
+    for inverse in (False, True):
+        for coset in (False, True):
+            got = ctx.ntt(x, lg, inverse=inverse, coset=coset)
+            want = ocpp.ntt(x, lg, inverse=inverse, coset=coset)
+            assert got == want, (lg, inverse, coset)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "witness_like"])
+def test_msm_g1_2p20_vs_cpp_oracle(ctx, kind):
+    """Row a8 at config 1's size: 2^20 terms, uniform scalars and the witness-like mix (heavy buckets: 20 % of all
+    points share one bucket per window), against the C++ oracle's windowed Pippenger; and the same MSM over prepared
+    bases (the prover's shared-bucket schedule)."""
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    n = 1 << 20
+    sc = (_canonical_bytes(n, 7) if kind == "uniform" else _witness_like(n, 8)).tobytes()
+    b = ctx.bases_g1_synthetic(n)
+    want = ocpp.msm_g1(sc, b.read(0, n))
+    assert ctx.msm_g1(sc, b) == want
+    b.prepare()
+    assert ctx.msm_g1(sc, b) == want
+    b.free()
+
+
+def test_msm_g2_2p18_vs_cpp_oracle(ctx):
+    """Row a9: G2 MSM of 2^18 terms (Fq2 lane-pair kernels) against the C++ oracle, plain and prepared."""
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    n = 1 << 18
+    sc = _canonical_bytes(n, 9).tobytes()
+    b = ctx.bases_g2_synthetic(n)
+    want = ocpp.msm_g2(sc, b.read(0, n))
+    assert ctx.msm_g2(sc, b) == want
+    b.prepare()
+    assert ctx.msm_g2(sc, b) == want
+    b.free()
+
+
+def test_msm_g2_2p22_closed_form(ctx):
+    """Config 4's G2 MSM size on its own (2^22 terms, 896 MiB of algorithmic bytes): with P_i = G2 + i Q the result
+    is (sum s_i) G2 + (sum i s_i) Q, computed by the Python oracle."""
+    import torch
+
+    n = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(422)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x3F
+    idx = torch.arange(n, dtype=torch.int64, device="cuda")
+    s0 = raw.to(torch.int64).sum(dim=0).cpu().tolist()
+    s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0).cpu().tolist()
+    tot = sum(v << (8 * k) for k, v in enumerate(s0)) % R
+    wtot = sum(v << (8 * k) for k, v in enumerate(s1)) % R
+    b = ctx.bases_g2_synthetic(n)
+    torch.cuda.synchronize()
+    got = ctx.msm_g2_dev(raw.data_ptr(), n, b)
+    want = ec.pt_add(ec.Fq2, ec.g2_mul(tot), ec.g2_mul(wtot, ec.g2_mul(0xC0FFEE)))
+    assert got == ec.g2_to_bytes(want)
+    b.free()
+    del raw
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("lg", [18, 20])
+def test_proof_bytes_vs_cpp_oracle_over_the_oracle_side_key(ctx, zk, lg):
+    """Rows a7 + a10 at the headline size: the ORACLE runs its own trusted setup (oracle_groth16_setup, pinned to the
+    Python oracle on the N = 128 golden key) and its own prover; the product runs its setup and its GPU prover from
+    the same toxic waste, witness, r and s.  Verifying keys and the 192 proof bytes must be identical, and the proof
+    must pass the pairing check under the oracle's key."""
+    import torch
+    from oracle import cpp as ocpp
+    from test_cpu_host import _note_update_case
+
+    ocpp.build()
+    r1 = zk.update_note_r1cs(lg, 1)
+    rng = ec.SplitMix64(0x5A4B0000 + lg)
+    toxic = frs([rng.fr() for _ in range(5)])
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    mats = [r1.export(m) for m in range(3)]
+    ovk, okey = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, toxic)
+    assert vk == ovk
+    # spot-check the queries against the oracle's (the 2^16 test compares them in full)
+    n, N = r1.n_vars, 1 << lg
+    for which, name, cnt, w in ((0, "a_query", n, 96), (1, "b_g1_query", n, 96), (2, "b_g2_query", n, 192),
+                                (3, "h_query", N - 1, 96), (4, "l_query", n - r1.n_pub, 96)):
+        for first in (0, cnt // 2, cnt - 64):
+            assert pk.export_query(which, first, 64) == okey[name][w * first: w * (first + 64)], (name, first)
+    inp, publics = _note_update_case(zk, 9000 + lg, 1)
+    wit, _, _ = zk.update_note_witness(lg, 1, inp)
+    r_, s_ = ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr())
+    want = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, okey, wit, r_, s_)
+    d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) == want
+    assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * 3, [r_] * 3, [s_] * 3) == [want] * 3
+    assert zk.groth16_verify(ovk, frs(publics), want) is True
+    pk.free()
+    r1.free()
+
+
+def test_grouped_key_survives_a_bigger_msm_on_the_same_context(ctx, zk):
+    """A small key proves in groups of 64 and owns 2^20 buckets of the shared sort buffers; a 2^21-term MSM on the
+    same context needs more ENTRIES than that key reserved but fewer buckets.  The buffers must only ever grow
+    (round-2 advice: reserve() re-allocated from the new n alone and the next grouped batch failed)."""
+    import torch
+
+    import bench
+
+    lg = 14
+    r1, wits = bench.relation_and_witness(zk, "poseidon", lg, [141, 142])
+    rng = ec.SplitMix64(1414)
+    pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
+    d = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(2)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(2)]
+    torch.cuda.synchronize()
+    idx = [i % 2 for i in range(130)]
+    args = ([d[j].data_ptr() for j in idx], [rs[j] for j in idx], [ss[j] for j in idx])
+    before = ctx.groth16_prove_batch_dev(pk, *args)
+    n = 1 << 21
+    g = torch.Generator(device="cuda").manual_seed(21)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x3F
+    b = ctx.bases_g1_synthetic(n)
+    torch.cuda.synchronize()
+    first = ctx.msm_g1_dev(raw.data_ptr(), n, b)
+    b.prepare()
+    assert ctx.msm_g1_dev(raw.data_ptr(), n, b) == first
+    after = ctx.groth16_prove_batch_dev(pk, *args)
+    assert after == before
+    assert zk.groth16_verify(vk, wits[0][32: 32 * r1.n_pub], after[0]) is True
+    assert ctx.groth16_prove_dev(pk, d[1].data_ptr(), rs[1], ss[1]) == before[1]
+    b.free()
+    pk.free()
+    r1.free()
+    del raw
+    torch.cuda.empty_cache()
+
+
+def test_key_lifecycle_churn_short():
+    """scripts/churn.py for a few hundred operations in a child process (a fatal signal must fail the test, not the
+    session): shuffled key sizes with big -> small transitions, forced group sizes, batch / single / host proofs,
+    error path, generic MSMs up to 2^22 terms, NTTs, a second context; every proof byte-identical to its first
+    occurrence.  The long run (10^4 operations) is recorded in DESIGN.md section 8."""
+    env = dict(os.environ, ZKMI_BACKTRACE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "churn.py"), "--ops", "400", "--seed", "3", "--max-log-n", "20",
+                        "--watchdog", "1500"], capture_output=True, text=True, timeout=1700, cwd=ROOT, env=env)
+    assert p.returncode == 0 and "CHURN OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]

@@ -132,6 +132,8 @@ def _share_hip_runtime_with_torch():
     import importlib.util
     import sys
 
+    if os.environ.get("ZKMI_SHARE_TORCH_HIP", "1") == "0":  # opt-out: a host that never imports torch in this process
+        return
     if "torch" in sys.modules:
         return
     try:
@@ -157,6 +159,12 @@ class Zkmi:
         self.lib.zkmi_version.restype = C.c_char_p
         self.lib.zkmi_last_error.restype = C.c_char_p
         self.lib.zkmi_last_error.argtypes = [C.c_void_p]
+
+    def hip_versions(self):
+        """(HIP_VERSION of the build, version of the HIP runtime this process bound the library to)."""
+        b, r = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.zkmi_hip_versions(C.byref(b), C.byref(r)))
+        return b.value, r.value
 
     def version(self):
         return self.lib.zkmi_version().decode()

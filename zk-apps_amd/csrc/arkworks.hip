@@ -94,9 +94,23 @@ bool read_vk(Reader& r, std::vector<uint8_t>* vk, uint32_t* n_pub) {
   if (!r.g1(vk->data()) || !r.g2(vk->data() + 96) || !r.g2(vk->data() + 288) || !r.g2(vk->data() + 480)) return false;
   uint64_t n = 0;
   if (!r.len(&n) || n == 0 || n > (1ull << 26)) return r.ok = false;
+  // the length prefix is untrusted: it must be covered by the bytes that are actually there before anything is
+  // allocated for it (the library is built without exceptions: a failed allocation would abort the caller)
+  if (n > r.left / (r.compressed ? 48 : 96)) return r.ok = false;
   vk->resize(672 + 96 * n);
   for (uint64_t i = 0; i < n; i++)
     if (!r.g1(vk->data() + 672 + 96 * i)) return false;
+  // arkworks' Validate::Yes also checks the prime-order subgroup; so does this library's verifier.  `check` asks for
+  // it here for the handful of points of a verifying key (the queries of a proving key are checked for curve
+  // membership only: an r-torsion check of 5 x 2^20 points on the host would take minutes)
+  if (r.check) {
+    G1Affine a;
+    G2Affine b;
+    for (uint64_t i = 0; i <= n; i++)
+      if (!g1_from_wire(vk->data() + (i ? 672 + 96 * (i - 1) : 0), &a, true) || !g1_in_subgroup(a)) return r.ok = false;
+    for (int k = 0; k < 3; k++)
+      if (!g2_from_wire(vk->data() + 96 + 192 * k, &b, true) || !g2_in_subgroup(b)) return r.ok = false;
+  }
   *n_pub = (uint32_t)n;
   return true;
 }
@@ -155,6 +169,7 @@ int32_t zkmi_ark_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t* bu
     if (!r.len(&n)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "arkworks key: truncated");
     if (n != want[k]) return ctx->fail(ZKMI_ERR_BAD_ARG, "arkworks key: query length differs from the relation's shape");
     const uint64_t w = is_g2[k] ? 192 : 96;
+    if (n > r.left / (compressed ? w / 2 : w)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "arkworks key: truncated");
     q[k].resize(w * n);
     for (uint64_t i = 0; i < n; i++)
       if (!(is_g2[k] ? r.g2(q[k].data() + w * i) : r.g1(q[k].data() + w * i)))

@@ -82,6 +82,17 @@ extern "C" {
 
 const char* zkmi_version(void) { return "zkmi 0.1 (gfx950)"; }
 
+// HIP version the library was compiled against and the one of the runtime it is bound to in this process (a Python
+// process that also holds PyTorch-ROCm shares the wheel's runtime: zk-apps_amd/binding.py)
+int32_t zkmi_hip_versions(int32_t* out_build, int32_t* out_runtime) {
+  if (!out_build || !out_runtime) return ZKMI_ERR_BAD_ARG;
+  *out_build = HIP_VERSION;
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) return ZKMI_ERR_HIP;
+  *out_runtime = v;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_device_count(int32_t* out_count) {
   if (!out_count) return ZKMI_ERR_BAD_ARG;
   int n = 0;
@@ -157,10 +168,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
 int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   if (!ctx) return ZKMI_ERR_BAD_ARG;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (hipStream_t s : {ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy, ctx->stream_sort,
-                        ctx->stream_acc3})
-    if (s) (void)hipStreamSynchronize(s);
+  (void)ctx->drain();
   ctx->domains.clear();
   ctx->domains_bn.clear();
   ctx->sort.release();
@@ -198,16 +206,7 @@ const char* zkmi_last_error(const zkmi_ctx* ctx) { return ctx ? ctx->err.c_str()
 int32_t zkmi_ctx_sync(zkmi_ctx* ctx) {
   ZK_ENTER(ctx);
   if (!ctx) return ZKMI_ERR_BAD_ARG;
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux2));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux3));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_g2));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_front));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_heavy));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
-  for (hipStream_t s : {ctx->stream_sort, ctx->stream_acc3})
-    if (s) ZK_HIP(ctx, hipStreamSynchronize(s));
+  ZK_HIP(ctx, ctx->drain());
   ctx->prof.collect();
   return ZKMI_OK;
 }
@@ -227,15 +226,7 @@ int32_t zkmi_prof_reset(zkmi_ctx* ctx) {
 int32_t zkmi_prof_get(zkmi_ctx* ctx, int32_t phase, double* out_total_ms, uint64_t* out_launches) {
   ZK_ENTER(ctx);
   if (!ctx || phase < 0 || phase >= 16) return ZKMI_ERR_BAD_ARG;
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream_aux);
-  (void)hipStreamSynchronize(ctx->stream_aux2);
-  (void)hipStreamSynchronize(ctx->stream_aux3);
-  (void)hipStreamSynchronize(ctx->stream_g2);
-  (void)hipStreamSynchronize(ctx->stream_front);
-  (void)hipStreamSynchronize(ctx->stream_heavy);
-  for (hipStream_t s : {ctx->stream_sort, ctx->stream_acc3})
-    if (s) (void)hipStreamSynchronize(s);
+  (void)ctx->drain();  // every stream that may carry timer events, the copy stream included
   ctx->prof.collect();
   if (out_total_ms) *out_total_ms = ctx->prof.total_ms[phase];
   if (out_launches) *out_launches = ctx->prof.count[phase];

@@ -48,6 +48,23 @@ struct zkmi_ctx {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, high_priority ? hi : 0);
   }
+  // every stream of the context, in creation order (lazily created ones included once they exist)
+  std::vector<hipStream_t> all_streams() const {
+    std::vector<hipStream_t> v;
+    for (hipStream_t s : {stream, stream_aux, stream_aux2, stream_aux3, stream_g2, stream_front, stream_copy, stream_heavy,
+                          stream_sort, stream_acc3})
+      if (s) v.push_back(s);
+    return v;
+  }
+  // wait for everything queued on the context (error paths hand the right to free buffers back to the caller)
+  hipError_t drain() const {
+    hipError_t first = hipSuccess;
+    for (hipStream_t s : all_streams()) {
+      const hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
+  }
   zkmi::PhaseTimer* timer() { return prof.enabled ? &prof : nullptr; }
   int32_t fail(int32_t code, const std::string& msg) {
     err = msg;

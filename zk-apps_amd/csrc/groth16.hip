@@ -167,6 +167,7 @@ struct zkmi_pk {
   zkmi_ctx* ctx = nullptr;
   int device = -1;
   uint32_t n_vars = 0, n_pub = 0, nc = 0, log_n = 0;
+  uint32_t tree_height = 0;  // from the zkmi_r1cs the key was made for (0 = not an update_note relation)
   // small domains: up to `gmax` proofs travel through the pipeline as ONE group (one sort, one accumulation launch
   // per query, batched NTT passes); every per-proof buffer below holds gmax vectors back to back
   uint32_t gmax = 1;
@@ -196,6 +197,7 @@ struct zkmi_pk {
   uint32_t* h_unsat = nullptr;  // pinned host copy, valid once the proof's H MSM has landed
   ~zkmi_pk() {
     if (device >= 0) (void)hipSetDevice(device);  // the key's buffers live on its context's device (the ctx may be gone)
+    (void)hipDeviceSynchronize();  // nothing queued by an earlier call may still read the key or write its pinned flags
     for (int m = 0; m < 3; m++) {
       if (d_rowptr[m]) (void)hipFree(d_rowptr[m]);
       if (d_col[m]) (void)hipFree(d_col[m]);
@@ -218,6 +220,7 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   pk->n_pub = r->n_pub;
   pk->nc = r->n_constraints;
   pk->log_n = r->log_n;
+  pk->tree_height = r->tree_height;
   const uint64_t N = 1ull << r->log_n;
   hipError_t e;
   for (int m = 0; m < 3; m++) {
@@ -539,6 +542,10 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t alpha_g1[9
   *out_pk = pk;
   return ZKMI_OK;
 }
+
+}  // extern "C"
+uint32_t zkmi::pk_tree_height(const zkmi_pk* pk) { return pk ? pk->tree_height : 0; }
+extern "C" {
 
 int32_t zkmi_pk_free(zkmi_pk* pk) {
   if (!pk) return ZKMI_ERR_BAD_ARG;
@@ -866,8 +873,14 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   const void* src[1] = {z ? static_cast<const void*>(z) : d_z};
   int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0);
   if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0);
-  if (rc != ZKMI_OK) return rc;
-  return prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
+  if (rc == ZKMI_OK) rc = prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
+  if (rc != ZKMI_OK) {
+    // whatever was queued before the failure still reads the caller's witness and the key: wait for it
+    const std::string msg = ctx->err;
+    (void)ctx->drain();
+    ctx->err = msg;
+  }
+  return rc;
 }
 
 // Host self-test of the scalar multiplications of proof assembly (curve.hpp FixedBase4, scalar_mul2) against the plain
@@ -969,10 +982,7 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
-    for (hipStream_t q : {ctx->stream, ctx->stream_aux, ctx->stream_aux2, ctx->stream_aux3, ctx->stream_g2, ctx->stream_front, ctx->stream_heavy, ctx->stream_copy})
-      (void)hipStreamSynchronize(q);
-    for (hipStream_t q : {ctx->stream_sort, ctx->stream_acc3})
-      if (q) (void)hipStreamSynchronize(q);
+    (void)ctx->drain();
     ctx->err = msg;
     return code;
   };

@@ -90,6 +90,7 @@ struct MsmSort {
   void release();
   bool has_shared = false;  // buffers sized for the shared-bucket plan too
   hipError_t reserve(uint64_t n, bool shared_too = false);
+  hipError_t allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared);
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
   // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
   hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);

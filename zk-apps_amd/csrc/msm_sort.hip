@@ -560,9 +560,23 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
     if (sb > nbk) nbk = sb;
     if (sb * snch > nh) nh = sb * snch;
   }
-  if (shared_too && !has_shared) cap_entries = 0;  // force re-allocation with the record buffers
-  if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
+  const bool need_records = shared_too && !has_shared;  // the record buffers only exist in shared mode
+  if (!need_records && ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
+  // Grow monotonically: a grouped key reserved room through reserve_batch() that the sizes derived from this n alone
+  // do not cover, and that key is still alive (a 2^14 key with 64-proof groups owns 2^20 buckets; a later 2^21-term
+  // MSM on the same context needs more entries but only 2^19 buckets).  No dimension ever shrinks.
+  if (ne < cap_entries) ne = cap_entries;
+  if (nbk < cap_buckets) nbk = cap_buckets;
+  if (nh < cap_hist) nh = cap_hist;
+  return allocate(ne, nbk, nh, shared_too);
+}
+
+// frees everything and allocates for (ne entries, nbk buckets, nh tile-histogram words); callers pass sizes that are
+// at least the current capacities.  Nothing may be in flight on these buffers: every entry point that sorts also
+// waits for its results before it returns, and hipFree waits for the device.
+hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared) {
   release();
+  if (!ne) ne = 1;
   hipError_t e;
   if ((e = hipMalloc(&count, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
@@ -570,14 +584,14 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
   if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
-  if (shared_too) {
-    if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
-    if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
+  if (shared) {
+    if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * ne)) != hipSuccess) return e;
+    if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * ne)) != hipSuccess) return e;
   }
-  has_shared = shared_too;
+  has_shared = shared;
   if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
   if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * nh)) != hipSuccess) return e;
-  if ((e = hipMalloc(&sorted, sizeof(uint32_t) * (ne ? ne : 1))) != hipSuccess) return e;
+  if ((e = hipMalloc(&sorted, sizeof(uint32_t) * ne)) != hipSuccess) return e;
   cap_entries = ne;
   cap_buckets = nbk;
   cap_hist = nh;
@@ -619,6 +633,7 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   const uint32_t tot_b = nwin * nb;
   const uint32_t nch = pick_chunks(plan);
   const uint32_t chunk = (uint32_t)((n + nch - 1) / nch);
+  if ((uint64_t)nwin * n > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist) return hipErrorInvalidValue;
   // M = sum_w (2^(c-1) - 1) 2^(c w), 9 limbs
   RecodeConst rc;
   for (int j = 0; j < 9; j++) rc.m[j] = 0;
@@ -665,6 +680,8 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   const uint32_t tot_b = P * nb;
   const uint32_t nch = shared_chunks(P, n);
   const uint32_t chunk = (uint32_t)((n + nch - 1) / nch);
+  if ((uint64_t)plan.ndigits * n > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist || (P > 1 && !rec_entry))
+    return hipErrorInvalidValue;
   RecodeConst rc;
   for (int j = 0; j < 9; j++) rc.m[j] = 0;
   for (int w = 0; w < plan.ndigits; w++) {
@@ -799,30 +816,9 @@ hipError_t MsmSort::reserve_batch(uint64_t n, uint32_t batch) {
   const uint64_t tiles = (512 + pmax) < pmax * mx ? (512 + pmax) : pmax * mx;
   const uint64_t nh = (uint64_t)sp.nb * tiles;
   if (ne <= cap_entries && nbk <= cap_buckets && nh <= cap_hist) return hipSuccess;
-  // grow: re-run reserve with synthetic sizes (keeps the record buffers of the shared plan)
-  const uint64_t want_e = ne > cap_entries ? ne : cap_entries, want_b = nbk > cap_buckets ? nbk : cap_buckets,
-                 want_h = nh > cap_hist ? nh : cap_hist;
-  const bool shared = has_shared;
-  release();
-  hipError_t e;
-  if ((e = hipMalloc(&count, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
-  if ((e = hipMalloc(&begin, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
-  if ((e = hipMalloc(&perm, sizeof(uint32_t) * want_b)) != hipSuccess) return e;
-  if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
-  if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
-  if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
-  if (shared) {
-    if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
-    if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
-  }
-  has_shared = shared;
-  if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (want_b + 1))) != hipSuccess) return e;
-  if ((e = hipMalloc(&blockhist, sizeof(uint32_t) * want_h)) != hipSuccess) return e;
-  if ((e = hipMalloc(&sorted, sizeof(uint32_t) * want_e)) != hipSuccess) return e;
-  cap_entries = want_e;
-  cap_buckets = want_b;
-  cap_hist = want_h;
-  return hipSuccess;
+  // grow, never shrink (the buffers also serve other keys of this context)
+  return allocate(ne > cap_entries ? ne : cap_entries, nbk > cap_buckets ? nbk : cap_buckets, nh > cap_hist ? nh : cap_hist,
+                  has_shared);
 }
 
 // ---------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 
 struct zkmi_r1cs {
   uint32_t n_vars = 0, n_pub = 0, n_constraints = 0, log_n = 0;
+  uint32_t tree_height = 0;  // update_note relations: Merkle height the shape was built for (0 = not such a relation)
   struct Csr {
     std::vector<uint32_t> rowptr, col;
     std::vector<zkmi::Fr> val;  // Montgomery form
@@ -19,4 +20,5 @@ zkmi_r1cs* build_shielder_r1cs(uint32_t log_n);
 void build_shielder_witness(uint32_t log_n, uint64_t seed, std::vector<Fr>* z_mont);
 bool build_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input& in, std::vector<Fr>* z_mont);
 bool r1cs_satisfied(const zkmi_r1cs& r, const std::vector<Fr>& z_mont);
+uint32_t pk_tree_height(const zkmi_pk* pk);  // groth16.hip: the tree height of the relation the key was made for, or 0
 }  // namespace zkmi

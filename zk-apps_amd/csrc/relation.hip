@@ -572,6 +572,7 @@ int32_t zkmi_update_note_r1cs_h(uint32_t log_n, int32_t op_kind, uint32_t tree_h
     delete r;
     return rc;
   }
+  r->tree_height = tree_height;
   *out = r;
   return ZKMI_OK;
 }
@@ -734,6 +735,13 @@ int32_t zkmi_shielder_prove_update(zkmi_ctx* ctx, const zkmi_pk* pk_deposit, con
   uint32_t n_vars = 0, n_pub = 0, log_n = 0;
   if ((rc = zkmi_pk_shape(pk, &n_vars, &n_pub, &log_n)) != ZKMI_OK || n_pub != N_PUB)
     return ctx->fail(ZKMI_ERR_BAD_ARG, "not an update_note key");
+  // a key made for another Merkle height can only end in ZKMI_ERR_UNSATISFIED after a full GPU proof: say so up front
+  if (pk_tree_height(pk) && pk_tree_height(pk) != tree_height)
+    return ctx->fail(ZKMI_ERR_BAD_ARG, "tree_height differs from the height the proving key's relation was built for");
+  // the returned ZkProof keeps the mock's fixed-depth path (relations.rs:25: [Scalar; MERKLE_TREE_DEPTH]); a deeper
+  // path does not fit it, and a truncated one could never reproduce the root
+  if (out_new && tree_height > ZKMI_MERKLE_TREE_DEPTH)
+    return ctx->fail(ZKMI_ERR_BAD_ARG, "out_new holds a depth-10 path: pass NULL for deeper trees");
   zkmi_note_update in;
   memset(&in, 0, sizeof(in));
   in.amount = fr_of_u128(op_pub->amount);
@@ -773,7 +781,7 @@ int32_t zkmi_shielder_prove_update(zkmi_ctx* ctx, const zkmi_pk* pk_deposit, con
     out_new->acc_new = acc_updated;
     out_new->op_priv = *op_priv;
     memset(out_new->merkle_proof, 0, sizeof(out_new->merkle_proof));
-    for (uint32_t i = 0; i < tree_height && i < ZKMI_MERKLE_TREE_DEPTH; i++) out_new->merkle_proof[i] = merkle_proof[i];
+    for (uint32_t i = 0; i < tree_height; i++) out_new->merkle_proof[i] = merkle_proof[i];  // tree_height <= depth: checked above
     out_new->merkle_proof_leaf_id = leaf_id;
   }
   return ZKMI_OK;
