@@ -9,23 +9,34 @@ HBM.  Independent proofs shard across ranks with no data-path collective
 (weak scaling); the only collectives are the timing barrier and the MAX over
 ranks of the elapsed time.
 
+Started WITHOUT a launcher and with --gpus N > 1, this process never touches the
+GPU: it starts `python -m torch.distributed.run --nproc-per-node N ... bench.py`
+as a child (fresh ranks) and exits with its code, so an N-GPU request can never
+be answered with a one-GPU line.  A world size that differs from --gpus is an error.
+
+`--workload msm26` is BASELINE config 3 instead: ONE G1 MSM of 2^26 points split
+by points over the ranks, per-window partial sums exchanged with an RCCL
+all-gather and combined on every rank (strong scaling: the total work is fixed).
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed
 inside libzkmi on its launch stream) and, at N = 1, `cpu_baseline` (the in-repo
 C++ oracle prover on the host cores, bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 from zkmi_loader import load_pkg  # noqa: E402
+
+torch = None  # imported in main(), after the decision to spawn ranks (the parent of a spawn never loads it)
+dist = None
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -144,18 +155,39 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
     }
 
 
+def _need_torch():
+    global torch, dist
+    if torch is None:
+        import torch as _t
+        import torch.distributed as _d
+
+        torch, dist = _t, _d
+
+
+def git_blob_hash(data):
+    """`git hash-object` of a byte string: ties a figure read from a committed summary to that file's version."""
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def pmc_traffic(path, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary.
 
     PMC counters cannot be read from inside the timed process, so the separate `--pmc FETCH_SIZE` /
-    `--pmc WRITE_SIZE` passes of this same command (profiles/r01/README.md) are summarised into a JSON
+    `--pmc WRITE_SIZE` passes of this same command (scripts/profile.sh) are summarised into a JSON
     file that travels with the repo; this returns (FETCH_SIZE + WRITE_SIZE) * 1024 for one launch.
     The kernel gathers 112/224-byte table entries with per-lane loads (64-byte fabric requests), so the
-    guide's x2 correction for 128-byte coalesced requests is NOT applied."""
+    guide's x2 correction for 128-byte coalesced requests is NOT applied.
+    A missing file or kernel yields traffic = None with a note (the timing above it stays valid)."""
+    pmc_traffic.valu = pmc_traffic.name = pmc_traffic.total_valu = pmc_traffic.source = None
     if path == "none":
         return None, "PMC summary lookup disabled (--pmc-summary none)"
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path)) as f:
-        rows = json.load(f)
+    try:
+        with open(os.path.join(ROOT, path), "rb") as f:
+            raw = f.read()
+        rows = json.loads(raw)
+    except (OSError, ValueError) as e:
+        return None, "PMC summary %s unreadable (%s): traffic not reported" % (path, e)
+    pmc_traffic.source = {"file": path, "git_blob": git_blob_hash(raw)}
     # wave-instructions of one proof = sum over the per-proof kernels of (avg per dispatch x dispatches per proof);
     # the summary's metadata row says how many proofs its passes ran
     meta = next((r for r in rows if r.get("kernel") == "__meta__"), None)
@@ -179,13 +211,14 @@ def pmc_traffic(path, kernel):
             return (fetch + write) * 1024.0, (
                 "bytes/launch = (FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) from %s (separate rocprofv3 --pmc passes of "
                 "this command; uncorrected: per-lane gathers of table entries, 64-B requests)" % (fetch, write, path))
-    raise SystemExit("bench.py: kernel %r is not in %s -- refresh the summary with scripts/profile.sh or pass "
-                     "--pmc-summary none" % (kernel, path))
+    return None, ("kernel %r has no FETCH_SIZE / WRITE_SIZE row in %s (stale summary: refresh with scripts/profile.sh): "
+                  "traffic not reported" % (kernel, path))
 
 
 pmc_traffic.valu = None
 pmc_traffic.name = None
 pmc_traffic.total_valu = None
+pmc_traffic.source = None
 # 1024 SIMDs x 2.4 GHz / 4 cycles: v_mad_u64_u32 / v_mad_i64_i32 (78 % of the kernel's instructions) issue once per
 # 4 cycles per SIMD (scripts/ubench.hip); under this load the chip holds ~1.95 GHz, so ~500 G/s is what is attainable
 VALU_ISSUE_PEAK = 614.4e9
@@ -195,6 +228,7 @@ def secondary_measurements(z, ctx, log_n):
     """SURVEY.md 8d items beside the headline: one whole G1 MSM (digit sort + bucket accumulation + reduction +
     host combine) of 2^log_n terms alone on the chip, with uniform scalars and with the witness-like mix
     (40 % zero, 20 % one, 10 % < 2^16, 30 % uniform)."""
+    _need_torch()
     n = 1 << log_n
     g = torch.Generator(device="cuda").manual_seed(0x5A4B)
     uni = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
@@ -226,6 +260,7 @@ def secondary_measurements(z, ctx, log_n):
 def small_domain_rate(z, ctx, relation, log_n=14, count=512):
     """BASELINE config 0's size (2^14, the relation's natural size): `count` independent proofs through the same batch
     entry point, which at this size moves groups of 64 proofs through one sort / one accumulation launch per query."""
+    _need_torch()
     r1, wits = relation_and_witness(z, relation, log_n, [0x5A4B0100, 0x5A4B0101])
     rng = SplitMix64(0x5A4B0102)
     pk, vk = ctx.groth16_setup(r1, b"".join(rng.fr_bytes() for _ in range(5)))
@@ -255,34 +290,178 @@ def small_domain_rate(z, ctx, relation, log_n=14, count=512):
                     "accumulation launch per query and batched NTT passes"}
 
 
+def spawn_ranks(n_gpus):
+    """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run and pass their exit code on.
+    This process has not touched the GPU (torch is not even imported) and never will."""
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %d ranks: %s" % (n_gpus, n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, cwd=ROOT)
+
+
+def timed_region(ctx, use_dist, fn):
+    """barrier + synchronize on both sides of fn(); returns (result, elapsed seconds = MAX over ranks)."""
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    res = fn()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return res, elapsed
+
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
+    """BASELINE config 3: one G1 MSM of 2^msm_log_n points, split by POINTS over the ranks (SURVEY.md 8e's preferred
+    partition; BASELINE.json words it as a windows split -- see DESIGN.md section 6 for why points).  Every rank sorts and
+    accumulates its n / world points with the window width planned from the global n and emits one partial sum per window;
+    the ranks all-gather those nwin x 96 bytes over RCCL and every rank adds and Horner-combines them (EC addition is
+    not an RCCL reduction op: this IS the all-reduce).  A step = one whole MSM; value = algorithmic GB/s of the job."""
+    par = __import__("zk_apps_amd.parallel", fromlist=["x"])
+    n = 1 << args.msm_log_n
+    a, b = par.shard_units(n, rank, world)
+    m = b - a
+    g = torch.Generator(device="cuda").manual_seed(0x5A4B0003 + rank)
+    raw = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x3F
+    assert args.msm_log_n <= 27  # 255 * i summed over 2^27 terms stays below 2^63
+    idx = torch.arange(a, b, dtype=torch.int64, device="cuda")
+    sums = torch.stack([raw.to(torch.int64).sum(dim=0), (raw.to(torch.int64) * idx[:, None]).sum(dim=0)]).contiguous()
+    del idx
+    if use_dist:
+        allsums = [torch.empty_like(sums) for _ in range(world)]
+        dist.all_gather(allsums, sums)
+    else:
+        allsums = [sums]
+    tot = wtot = 0
+    for t in allsums:
+        v = t.cpu().tolist()
+        tot += sum(x << (8 * k) for k, x in enumerate(v[0]))
+        wtot += sum(x << (8 * k) for k, x in enumerate(v[1]))
+    bases = ctx.bases_g1_synthetic_range(a, m)
+
+    def one():
+        windows, nwin, cbits = ctx.msm_g1_windows_dev(raw.data_ptr(), m, bases, n)
+        parts = par.allgather_bytes(windows) if use_dist else [windows]
+        return z.msm_g1_combine(b"".join(parts), len(parts), nwin, cbits)
+
+    for _ in range(max(1, args.warmup)):  # the first call allocates the workspaces
+        one()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    got, elapsed = timed_region(ctx, use_dist, lambda: [one() for _ in range(args.steps)][-1])
+    ctx.prof_enable(False)
+    G = z.g1_generator()
+    Q = z.g1_mul(G, (0xC0FFEE).to_bytes(32, "little"))
+    want = z.g1_add(z.g1_mul(G, (tot % R_MOD).to_bytes(32, "little")), z.g1_mul(Q, (wtot % R_MOD).to_bytes(32, "little")))
+    ok = got == want
+    if use_dist:
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    phases = {k: ctx.prof_get(k) for k in pkg.PHASES}
+    ms_tot, launches = phases["msm_accum_g1"]
+    avg_ms = ms_tot / max(1, launches)
+    achieved = 128.0 * m / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    sec = elapsed / args.steps
+    out = {
+        "metric": "g1_msm_2^%d_points_algorithmic_GBps" % args.msm_log_n,
+        "value": 128.0 * n / sec / 1e9,
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * sec,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int: signed 28-bit limbs in 32-bit words, 64-bit column accumulators (Fq 381-bit Montgomery)",
+        "data": "synthetic",
+        "config": {"workload": "single G1 MSM of 2^%d points (BASELINE configs[3]), split by points over %d GPU(s), RCCL all-gather of "
+                               "per-window partial sums + local combine" % (args.msm_log_n, world),
+                   "points_per_rank": m, "curve": "BLS12-381", "scalars": "uniform < 2^254", "bases": "P_i = G + i*[0xC0FFEE]G"},
+        "matches_closed_form_on_every_rank": ok,
+        "points_per_s": n / sec,
+        "frac_of_hbm_peak": 128.0 * n / sec / 1e9 / (HBM_PEAK_GBS * world),
+        "phase_ms_per_msm": {k: v[0] / args.steps for k, v in phases.items()},
+        "roofline": {"kernel": "k_accum_g1_nc (rank 0's share: %d points)" % m, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                     "algorithmic_bytes_per_launch": 128 * m,
+                     "limiter": "VALU integer issue (384-bit Montgomery products), see DESIGN.md 4.1"},
+    }
+    bases.free()
+    if not ok:
+        print("bench.py: MSM result differs from the closed form", file=sys.stderr)
+    return out, 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (proofs) / 3 (msm26)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["proofs", "msm26"], default="proofs",
+                    help="proofs = BASELINE configs[1]/[2] (headline); msm26 = configs[3], one 2^26-point G1 MSM split over the ranks")
     ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--msm-log-n", type=int, default=26)
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--no-secondary", action="store_true", help="skip the H2D-inclusive and whole-MSM measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
-    ap.add_argument("--pmc-summary", default="profiles/r02/pmc_summary_bench_steps3.json")
+    ap.add_argument("--pmc-summary", default="profiles/r03/pmc_summary_bench_steps3.json")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.workload == "proofs" else 3
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        return spawn_ranks(args.gpus)  # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a line for another GPU count"
+              % (args.gpus, world), file=sys.stderr)
+        return 2
+    _need_torch()
     torch.cuda.set_device(local_rank)
     # launched by torch.distributed.run (any world size, also 1): RCCL process group, used only for the
     # barriers around the timed region and the max-over-ranks of the elapsed time -- no data-path collective
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    use_dist = launched and "MASTER_ADDR" in os.environ
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_pkg()
     z = pkg.Zkmi()
     ctx = z.context(local_rank)
+    if args.workload == "msm26":
+        out, rc = run_msm26(args, pkg, z, ctx, rank, world, use_dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return rc
     log_n = args.log_n
     N = 1 << log_n
 
@@ -299,7 +478,7 @@ def main():
     torch.cuda.synchronize()
 
     def run(first, count):
-        """`count` proofs as one pipelined batch (two in flight on the GPU)."""
+        """`count` proofs as one pipelined batch (three in flight on the GPU)."""
         idx = [(first + i) % 2 for i in range(count)]
         return ctx.groth16_prove_batch_dev(pk, [d_wits[j].data_ptr() for j in idx], [rs[j][0] for j in idx], [rs[j][1] for j in idx])
 
@@ -308,22 +487,8 @@ def main():
 
     ctx.prof_enable(True)
     ctx.prof_reset()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ctx.sync()
-    t0 = time.perf_counter()
-    proofs = run(0, args.steps)
+    proofs, elapsed = timed_region(ctx, use_dist, lambda: run(0, args.steps))
     proof = proofs[-1] if proofs else None
-    ctx.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     ctx.prof_enable(False)
 
     # correctness of what was timed: the last proof must pass the pairing verifier
@@ -345,18 +510,21 @@ def main():
     traffic, traffic_note = pmc_traffic(args.pmc_summary, kname)
     roofline = {
         "kernel": pmc_traffic.name or kname,
-        # the kernel is bound by the integer multiply-add issue rate (valu_issue below), not by HBM; achieved /
-        # peak / frac stay the HBM figures BASELINE.json's metric asks for (algorithmic bytes / launch time)
-        "bound": "valu",
+        # achieved / peak / frac are the HBM figures BASELINE.json's metric asks for (algorithmic bytes / launch time),
+        # so `bound` names that roofline; what actually limits the kernel is the integer multiply-add issue rate:
+        # `limiter` + `valu_issue` below
+        "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
         "traffic_note": traffic_note,
+        "traffic_source": pmc_traffic.source,
         "avg_launch_ms": avg_ms,
         "launches": launches,
         "algorithmic_bytes_per_launch": kernels[dom]["bytes"],
+        "limiter": "valu-issue",
         "note": "bucket accumulation is VALU-integer bound (384-bit Montgomery products), not HBM bound; see DESIGN.md",
     }
     if pmc_traffic.valu and avg_ms > 0:
@@ -399,8 +567,9 @@ def main():
         "proofs_in_flight": 3,
         "phase_ms_per_proof": {k: v[0] / args.steps for k, v in phases.items()},
         "roofline": roofline,
+        "hip_versions": dict(zip(("build", "runtime"), z.hip_versions())),
     }
-    if not args.no_secondary:
+    if rank == 0 and not args.no_secondary:
         # PCIe-inclusive rate (SURVEY.md 8d "end-to-end proofs/s includes witness upload"): the same K proofs from
         # PINNED HOST witnesses; upload i+1 runs on the copy stream while proofs i-1 and i compute.  Never `value`.
         h_wits = [torch.frombuffer(bytearray(w), dtype=torch.uint8).pin_memory() for w in wits]
@@ -414,7 +583,7 @@ def main():
         out["value_incl_h2d"] = {"value": args.steps / dt, "unit": "proofs/s per GPU", "ms_per_step": 1e3 * dt / args.steps,
                                  "same_proof_bytes_as_resident_run": hp == proofs,
                                  "note": "witnesses in pinned host memory (32 MiB each at 2^20), uploaded on a copy stream "
-                                         "overlapped with the previous proofs; rank 0 only"}
+                                         "overlapped with the previous proofs; rank 0 only, after the timed region"}
     if rank == 0 and world == 1 and not args.no_secondary:
         # latency of ONE proof on an otherwise idle GPU (nothing to overlap with): witness resident -> 192 bytes on the host
         lat = []
@@ -448,7 +617,8 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    return 0 if verified else 1
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -364,6 +364,16 @@ int32_t zkmi_groth16_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_pr
                                  const uint8_t* r, const uint8_t* s, uint8_t* out_proofs);
 /* h-polynomial coefficients only (row a7), N x 32 B canonical LE */
 int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, uint8_t* out_h);
+/* BASELINE config 2 inside ONE host process: a batch of independent proofs over n_dev GPUs,
+ * proof i -> ctxs[i % n_dev]; pks[d] = the same key set up / loaded on ctxs[d] (replicas); one host thread per
+ * device, no collective.  z[i]: host pointer (z_on_device = 0) or device pointer on ctxs[i % n_dev]'s GPU
+ * (z_on_device = 1).  r, s: n_proofs x 32 B; out_proofs: n_proofs x 192 B in the caller's order.
+ * This is what a Rust host calls where the reference's callers loop over actors and call
+ * ZkProof::update_account one by one (shielder/drink_tests/mod.rs:133-207). */
+int32_t zkmi_groth16_prove_batch_multi(zkmi_ctx* const* ctxs, const zkmi_pk* const* pks, uint32_t n_dev, uint32_t n_proofs,
+                                       const void* const* z, int32_t z_on_device, const uint8_t* r, const uint8_t* s,
+                                       uint8_t* out_proofs);
+
 /* row a11: pairing check on the host CPU.  publics excludes the leading 1.
  * Validating, like arkworks' / zcash's deserialisation: proof points must be canonical compressed
  * encodings (one encoding of infinity) of points in the r-order subgroups, and so must the vk's points;

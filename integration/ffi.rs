@@ -58,6 +58,7 @@ pub struct zkmi_note_create { pub tokens: [zkmi_fr; TOKENS_NUMBER], pub note: [z
 extern "C" {
     // context
     pub fn zkmi_version() -> *const c_char;
+    pub fn zkmi_hip_versions(out_build: *mut i32, out_runtime: *mut i32) -> i32;
     pub fn zkmi_device_count(out_count: *mut i32) -> i32;
     pub fn zkmi_ctx_create(device: i32, out_ctx: *mut *mut zkmi_ctx) -> i32;
     pub fn zkmi_ctx_destroy(ctx: *mut zkmi_ctx) -> i32;
@@ -89,6 +90,10 @@ extern "C" {
     pub fn zkmi_groth16_prove_batch(ctx: *mut zkmi_ctx, pk: *const zkmi_pk, n_proofs: u32, z: *const *const u8, r: *const u8, s: *const u8, out_proofs: *mut u8) -> i32;
     pub fn zkmi_groth16_prove_batch_dev(ctx: *mut zkmi_ctx, pk: *const zkmi_pk, n_proofs: u32, d_z: *const *const core::ffi::c_void,
                                         r: *const u8, s: *const u8, out_proofs: *mut u8) -> i32;
+    // one batch over several GPUs from one process: proof i -> ctxs[i % n_dev] (one host thread per device inside)
+    pub fn zkmi_groth16_prove_batch_multi(ctxs: *const *mut zkmi_ctx, pks: *const *const zkmi_pk, n_dev: u32, n_proofs: u32,
+                                          z: *const *const core::ffi::c_void, z_on_device: i32, r: *const u8, s: *const u8,
+                                          out_proofs: *mut u8) -> i32;
     pub fn zkmi_groth16_verify(vk: *const u8, n_pub: u32, publics: *const u8, proof: *const u8) -> i32;
 
     // the mock's own surface, bit for bit (row a12) — lets call sites migrate one at a time

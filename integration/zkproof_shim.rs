@@ -1,15 +1,35 @@
-//! `mocked_zk/src/relations.rs` with real proofs: the four methods the callers use keep their names, arity and
-//! `ZkpError` behaviour (reference: shielder/mocked_zk/src/relations.rs:36-155; callers
-//! contract/drink_tests/utils/shielder.rs:60,105-114 and contract/lib.rs:56,74).  Shown, not compiled.
+//! `mocked_zk/src/relations.rs` with real proofs: a DROP-IN replacement of `ZkProof`.  The five public methods keep
+//! the reference's names, argument lists and return types exactly (reference: shielder/mocked_zk/src/relations.rs:36-155),
+//! so the call sites compile unchanged:
+//!     ZkProof::new(id, trapdoor, nullifier, op_priv, acc)                      drink_tests/utils/shielder.rs:60
+//!     proof.update_account(operation, trapdoor, nullifier, merkle_proof, leaf_id)   drink_tests/utils/shielder.rs:105-114
+//!     proof.verify_creation(h_note_new, tokens)                                 contract/lib.rs:56
+//!     proof.verify_update(op_pub, h_note_new, merkle_root, nullifier_old)        contract/lib.rs:74
+//! Shown, not compiled (no Rust toolchain in the build image); tests/test_cpu_host.py checks the method names and
+//! arities against the reference file when it is present, and every `zkmi_*` call against include/zkmi.h.
 //!
-//! What changes for the callers: `update_account` additionally returns the 192-byte proof (it replaces the witness
-//! struct as the object submitted to the contract), and the verify side needs the verifying keys, which the contract
-//! would hold in storage next to `supported_tokens` (contract/lib.rs:29-35).
-use crate::{errors::ZkpError, ffi::*, ops::{OpPriv, OpPub, Operation}, Scalar, MERKLE_TREE_DEPTH, TOKENS_NUMBER};
+//! What is different underneath:
+//!  * the value carries the 192-byte Groth16 proof (`proof`) next to the caller's knowledge.  The knowledge fields are
+//!    what `update_account` needs on the wallet side; what travels to the contract is SCALE-encoded like before, and a
+//!    production deployment would strip everything but `proof` from the encoding (the verify methods read nothing else);
+//!  * hashes are the relation's Poseidon hashes (relations/src/relations/update_note.rs:100,131), not the mock's SHA-256;
+//!  * the proving side needs a process-global `Prover` (GPU context + three proving keys), the verifying side the three
+//!    verifying keys: `install_prover` / `install_verifying_keys` are called once at start-up.  Inside an ink! contract
+//!    the verify calls would go through a chain extension to the same two C functions (host CPU only, no GPU).
+use crate::{account::Account, errors::ZkpError, ffi::*, ops::{OpPriv, OpPub, Operation}, Scalar, MERKLE_TREE_DEPTH, TOKENS_NUMBER};
+use std::sync::OnceLock;
 
 pub struct Prover { ctx: *mut zkmi_ctx, pk_create: *mut zkmi_pk, pk_deposit: *mut zkmi_pk, pk_withdraw: *mut zkmi_pk }
+unsafe impl Send for Prover {}
+unsafe impl Sync for Prover {}  // guarded by PROVER_LOCK: a zkmi_ctx serves one host thread at a time
 pub struct VerifyingKeys { pub create: Vec<u8>, pub deposit: Vec<u8>, pub withdraw: Vec<u8> }
-pub type ProofBytes = [u8; 192];
+
+static PROVER: OnceLock<Prover> = OnceLock::new();
+static PROVER_LOCK: std::sync::Mutex<()> = std::sync::Mutex::new(());
+static VERIFYING_KEYS: OnceLock<VerifyingKeys> = OnceLock::new();
+
+pub fn install_prover(p: Prover) -> Result<(), Prover> { PROVER.set(p) }
+pub fn install_verifying_keys(k: VerifyingKeys) -> Result<(), VerifyingKeys> { VERIFYING_KEYS.set(k) }
 
 fn err(rc: i32) -> ZkpError {
     match rc {
@@ -26,19 +46,85 @@ fn op(o: &OpPub) -> zkmi_op_pub {
     };
     zkmi_op_pub { kind, amount: amount.to_le_bytes(), token: sc(&token), user: sc(&user) }
 }
+/// prover randomness r || s: two field elements below r (top two bits cleared)
+fn fresh_rs() -> [u8; 64] {
+    let mut rs = [0u8; 64];
+    getrandom::getrandom(&mut rs).expect("os randomness");
+    rs[31] &= 0x3f;
+    rs[63] &= 0x3f;
+    rs
+}
 
-impl super::ZkProof {
-    // `new` is unchanged (relations.rs:37-55): it only stores the caller's knowledge.
+#[ink::scale_derive(Encode, Decode, TypeInfo)]
+#[derive(Debug, Clone, Copy)]
+pub struct ZkProof {
+    id: Scalar,
+    trapdoor_new: Scalar,
+    trapdoor_old: Scalar,
+    nullifier_new: Scalar,
+    acc_old: Account,
+    acc_new: Account,
+    op_priv: OpPriv,
+    merkle_proof: [Scalar; MERKLE_TREE_DEPTH],
+    merkle_proof_leaf_id: u32,
+    /// Groth16 proof of the relation this value was produced by (creation or update), compressed A || B || C
+    proof: [u8; 192],
+    /// the Merkle root the last update was proved against (what the caller passes to the contract's update_note)
+    merkle_root: Scalar,
+}
 
-    /// relations.rs:79-98 + the proof.  `rs` = the prover's randomness (r || s).
-    pub fn update_account_proved(&self, p: &Prover, operation: Operation, trapdoor: Scalar, nullifier: Scalar,
-                                 merkle_proof: [Scalar; MERKLE_TREE_DEPTH], merkle_proof_leaf_id: u32, rs: &[u8; 64])
-                                 -> Result<(Scalar, Scalar, Self, ProofBytes), ZkpError> {
-        let this: zkmi_zkproof = self.to_ffi();
+impl ZkProof {
+    fn knowledge(&self) -> zkmi_zkproof {
+        zkmi_zkproof {
+            id: sc(&self.id), trapdoor_new: sc(&self.trapdoor_new), trapdoor_old: sc(&self.trapdoor_old),
+            nullifier_new: sc(&self.nullifier_new), acc_old: self.acc_old.to_ffi(), acc_new: self.acc_new.to_ffi(),
+            op_priv: zkmi_op_priv { user: sc(&self.op_priv.user) },
+            merkle_proof: self.merkle_proof.map(|s| sc(&s)), merkle_proof_leaf_id: self.merkle_proof_leaf_id,
+        }
+    }
+    fn from_knowledge(k: &zkmi_zkproof, proof: [u8; 192], merkle_root: Scalar) -> Self {
+        Self {
+            id: Scalar::from_bytes(k.id.bytes), trapdoor_new: Scalar::from_bytes(k.trapdoor_new.bytes),
+            trapdoor_old: Scalar::from_bytes(k.trapdoor_old.bytes), nullifier_new: Scalar::from_bytes(k.nullifier_new.bytes),
+            acc_old: Account::from_ffi(&k.acc_old), acc_new: Account::from_ffi(&k.acc_new),
+            op_priv: OpPriv { user: Scalar::from_bytes(k.op_priv.user.bytes) },
+            merkle_proof: k.merkle_proof.map(|s| Scalar::from_bytes(s.bytes)), merkle_proof_leaf_id: k.merkle_proof_leaf_id,
+            proof, merkle_root,
+        }
+    }
+
+    /// relations.rs:37-55, same arguments.  Also proves the note-creation relation (update_note.rs:91-103 +
+    /// update_account.rs:52-65) for the freshly created account, so that `verify_creation` has something to check.
+    pub fn new(id: Scalar, trapdoor: Scalar, nullifier: Scalar, op_priv: OpPriv, acc: Account) -> Self {
+        let mut this = Self {
+            id, trapdoor_new: trapdoor, nullifier_new: nullifier, acc_new: acc, trapdoor_old: 0_u128.into(), acc_old: acc,
+            op_priv, merkle_proof: [0_u128.into(); MERKLE_TREE_DEPTH], merkle_proof_leaf_id: 0,
+            proof: [0u8; 192], merkle_root: 0_u128.into(),
+        };
+        let p = PROVER.get().expect("install_prover() first");
+        let _g = PROVER_LOCK.lock().unwrap();
+        let tokens: [zkmi_scalar; TOKENS_NUMBER] = core::array::from_fn(|t| sc(&acc.balances[t].0));
+        let rs = fresh_rs();
+        let mut h = zkmi_scalar { bytes: [0; 32] };
+        let rc = unsafe {
+            zkmi_shielder_prove_creation(p.ctx, p.pk_create, &this.knowledge(), tokens.as_ptr(), rs.as_ptr(), rs[32..].as_ptr(),
+                                         &mut h, this.proof.as_mut_ptr())
+        };
+        assert_eq!(rc, ZKMI_OK, "creation proof");  // `new` is infallible in the reference
+        this
+    }
+
+    /// relations.rs:79-98, same arguments and return type: (h_note_new, the knowledge after the update).
+    pub fn update_account(&self, operation: Operation, trapdoor: Scalar, nullifier: Scalar,
+                          merkle_proof: [Scalar; MERKLE_TREE_DEPTH], merkle_proof_leaf_id: u32) -> Result<(Scalar, Self), ZkpError> {
+        let p = PROVER.get().ok_or(ZkpError::VerificationError)?;
+        let _g = PROVER_LOCK.lock().unwrap();
+        let this = self.knowledge();
         let (mut h, mut root) = (zkmi_scalar { bytes: [0; 32] }, zkmi_scalar { bytes: [0; 32] });
         let mut next = this;
         let mut proof = [0u8; 192];
-        let path: Vec<zkmi_scalar> = merkle_proof.iter().map(sc).collect();
+        let path: [zkmi_scalar; MERKLE_TREE_DEPTH] = merkle_proof.map(|s| sc(&s));
+        let rs = fresh_rs();
         let rc = unsafe {
             zkmi_shielder_prove_update(p.ctx, p.pk_deposit, p.pk_withdraw, &this, &op(&operation.op_pub),
                                        &zkmi_op_priv { user: sc(&operation.op_priv.user) }, &sc(&trapdoor), &sc(&nullifier),
@@ -46,27 +132,57 @@ impl super::ZkProof {
                                        &mut h, &mut root, &mut next, proof.as_mut_ptr())
         };
         if rc != ZKMI_OK { return Err(err(rc)); }
-        Ok((Scalar::from_bytes(h.bytes), Scalar::from_bytes(root.bytes), Self::from_ffi(&next), proof))
+        Ok((Scalar::from_bytes(h.bytes), Self::from_knowledge(&next, proof, Scalar::from_bytes(root.bytes))))
     }
+
+    /// relations.rs:100-108 (sic: the reference spells it `acccount`), same arguments: the mock's account arithmetic
+    pub fn verify_acccount_update(&self, op: Operation, h_acc_old: Scalar) -> Result<Account, ZkpError> {
+        let mut out = self.acc_old.to_ffi();
+        let rc = unsafe { zkmi_account_update(&self.acc_old.to_ffi(), &self::op(&op.op_pub), &zkmi_op_priv { user: sc(&op.op_priv.user) }, &mut out) };
+        if rc != ZKMI_OK { return Err(err(rc)); }
+        if self.acc_old.hash() != h_acc_old { return Err(ZkpError::VerificationError); }
+        Ok(Account::from_ffi(&out))
+    }
+
+    /// relations.rs:127-136, same arguments: the contract's add_note (contract/lib.rs:50-58)
+    pub fn verify_creation(&self, h_note_new: Scalar, tokens_list: [Scalar; TOKENS_NUMBER]) -> Result<(), ZkpError> {
+        let vk = VERIFYING_KEYS.get().ok_or(ZkpError::VerificationError)?;
+        let t: [zkmi_scalar; TOKENS_NUMBER] = tokens_list.map(|s| sc(&s));
+        match unsafe { zkmi_shielder_verify_creation(vk.create.as_ptr(), &sc(&h_note_new), t.as_ptr(), self.proof.as_ptr()) } {
+            ZKMI_OK => Ok(()),
+            rc => Err(err(rc)),
+        }
+    }
+
+    /// relations.rs:138-155, same arguments: the contract's update_note (contract/lib.rs:63-78)
+    pub fn verify_update(&self, op_pub: OpPub, h_note_new: Scalar, merkle_root: Scalar, nullifier_old: Scalar) -> Result<(), ZkpError> {
+        let vk = VERIFYING_KEYS.get().ok_or(ZkpError::VerificationError)?;
+        match unsafe {
+            zkmi_shielder_verify_update(vk.deposit.as_ptr(), vk.withdraw.as_ptr(), &op(&op_pub), &sc(&h_note_new), &sc(&merkle_root),
+                                        &sc(&nullifier_old), self.proof.as_ptr())
+        } {
+            ZKMI_OK => Ok(()),
+            rc => Err(err(rc)),
+        }
+    }
+
+    /// not in the reference: the Merkle root the last `update_account` was proved against and the raw proof bytes
+    pub fn merkle_root(&self) -> Scalar { self.merkle_root }
+    pub fn proof_bytes(&self) -> &[u8; 192] { &self.proof }
 }
 
-/// relations.rs:127-136: the contract's add_note (contract/lib.rs:50-58)
-pub fn verify_creation(vk: &VerifyingKeys, proof: &ProofBytes, h_note_new: Scalar, tokens_list: [Scalar; TOKENS_NUMBER]) -> Result<(), ZkpError> {
-    let t: Vec<zkmi_scalar> = tokens_list.iter().map(sc).collect();
-    match unsafe { zkmi_shielder_verify_creation(vk.create.as_ptr(), &sc(&h_note_new), t.as_ptr(), proof.as_ptr()) } {
-        ZKMI_OK => Ok(()),
-        rc => Err(err(rc)),
-    }
-}
-
-/// relations.rs:138-155: the contract's update_note (contract/lib.rs:63-78)
-pub fn verify_update(vk: &VerifyingKeys, proof: &ProofBytes, op_pub: OpPub, h_note_new: Scalar, merkle_root: Scalar, nullifier_old: Scalar)
-                     -> Result<(), ZkpError> {
-    match unsafe {
-        zkmi_shielder_verify_update(vk.deposit.as_ptr(), vk.withdraw.as_ptr(), &op(&op_pub), &sc(&h_note_new), &sc(&merkle_root),
-                                    &sc(&nullifier_old), proof.as_ptr())
-    } {
-        ZKMI_OK => Ok(()),
-        rc => Err(err(rc)),
-    }
+/// A batch of updates over all GPUs of the node (BASELINE config 2): what a service does instead of looping over
+/// `update_account`; witnesses come from zkmi_update_note_witness, proofs return in the caller's order.
+pub fn prove_batch_multi(ctxs: &[*mut zkmi_ctx], pks: &[*const zkmi_pk], witnesses: &[&[u8]], rs: &[[u8; 64]]) -> Result<Vec<[u8; 192]>, ZkpError> {
+    let n = witnesses.len();
+    let z: Vec<*const core::ffi::c_void> = witnesses.iter().map(|w| w.as_ptr() as *const _).collect();
+    let r: Vec<u8> = rs.iter().flat_map(|x| x[..32].to_vec()).collect();
+    let s: Vec<u8> = rs.iter().flat_map(|x| x[32..].to_vec()).collect();
+    let mut out = vec![[0u8; 192]; n];
+    let rc = unsafe {
+        zkmi_groth16_prove_batch_multi(ctxs.as_ptr(), pks.as_ptr(), ctxs.len() as u32, n as u32, z.as_ptr(), 0, r.as_ptr(), s.as_ptr(),
+                                       out.as_mut_ptr() as *mut u8)
+    };
+    if rc != ZKMI_OK { return Err(err(rc)); }
+    Ok(out)
 }

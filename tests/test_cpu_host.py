@@ -41,6 +41,77 @@ def test_reference_side_bindings_name_only_exported_functions(zk):
         assert hasattr(zk.lib, name), f"{name} called in examples/prove_withdraw.c but not exported"
 
 
+def _impl_pub_fns(src, type_name):
+    """{name: [argument names]} of the `pub fn`s inside `impl <type_name> { ... }` blocks of a Rust source."""
+    out = {}
+    for m in re.finditer(r"\bimpl\s+(?:super::)?%s\s*\{" % type_name, src):
+        depth, i = 1, m.end()
+        while depth and i < len(src):
+            depth += {"{": 1, "}": -1}.get(src[i], 0)
+            i += 1
+        body = src[m.end(): i]
+        for f in re.finditer(r"\bpub fn (\w+)\s*\(([^)]*)\)\s*(?:->\s*([^{]+?))?\s*\{", body, re.S):
+            args = [a.strip().split(":")[0].strip() for a in f.group(2).split(",") if a.strip()]
+            out[f.group(1)] = (args, re.sub(r"\s+", " ", (f.group(3) or "").strip()))
+    return out
+
+
+def test_rust_shim_is_drop_in_by_name_and_arity(zk):
+    """integration/zkproof_shim.rs replaces mocked_zk::relations::ZkProof: every public method of the reference's
+    `impl ZkProof` (relations.rs:36-155) exists in the shim as a METHOD with the same argument names, arity and return
+    type, so the call sites (contract/lib.rs:56,74; drink_tests/utils/shielder.rs:60,105-114) compile unchanged.
+    Every zkmi_* function the shim calls is bound in ffi.rs and exported by the library.  The comparison with the
+    reference file runs where the reference tree exists (the build container); nothing of it ships."""
+    shim_src = open(os.path.join(ROOT, "integration", "zkproof_shim.rs")).read()
+    ffi_src = open(os.path.join(ROOT, "integration", "ffi.rs")).read()
+    shim = _impl_pub_fns(shim_src, "ZkProof")
+    assert {"new", "update_account", "verify_creation", "verify_update", "verify_acccount_update"} <= set(shim)
+    # the four call-site shapes, hard-coded from SURVEY.md 8b (checked against the reference below when it is there)
+    assert shim["new"][0] == ["id", "trapdoor", "nullifier", "op_priv", "acc"]
+    assert shim["update_account"][0] == ["&self", "operation", "trapdoor", "nullifier", "merkle_proof", "merkle_proof_leaf_id"]
+    assert shim["update_account"][1] == "Result<(Scalar, Self), ZkpError>"
+    assert shim["verify_creation"][0] == ["&self", "h_note_new", "tokens_list"]
+    assert shim["verify_update"][0] == ["&self", "op_pub", "h_note_new", "merkle_root", "nullifier_old"]
+    bound = set(re.findall(r"pub fn (zkmi_[a-z0-9_]+)", ffi_src))
+    for name in set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", shim_src)):
+        assert name in bound, f"{name} called by the shim but not bound in ffi.rs"
+        assert hasattr(zk.lib, name), f"{name} called by the shim but not exported"
+    ref_path = "/root/reference/shielder/mocked_zk/src/relations.rs"
+    if not os.path.exists(ref_path):
+        pytest.skip("reference tree not present (GPU box): names and arities checked against SURVEY.md 8b only")
+    ref = _impl_pub_fns(open(ref_path).read(), "ZkProof")
+    assert ref, "no pub fn found in the reference's impl ZkProof"
+    for name, (args, ret) in ref.items():
+        assert name in shim, f"reference method ZkProof::{name} is missing from the shim"
+        assert shim[name][0] == args, f"ZkProof::{name}: arguments {shim[name][0]} != reference {args}"
+        assert shim[name][1] == ret, f"ZkProof::{name}: return type {shim[name][1]!r} != reference {ret!r}"
+
+
+def test_bench_never_reports_a_line_for_another_gpu_count():
+    """bench.py --gpus N: a launcher with another world size is refused, and without a launcher N > 1 starts N fresh
+    ranks before anything touches the GPU (here, without GPUs, the ranks fail and so does the parent): in neither case
+    does a JSON line come out."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr and "{" not in p.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if zk_has_gpu():
+        pytest.skip("a GPU is visible: the spawn path is exercised by the GPU suite")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "13"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0 and '"n_gpus"' not in p.stdout
+    assert "starting 2 ranks" in p.stderr
+
+
+def zk_has_gpu():
+    from zkmi_loader import load_pkg
+
+    return load_pkg().Zkmi().device_count() > 0
+
+
 def test_ctx_create_without_gpu_fails_loudly(zk, pkg):
     if zk.device_count() > 0:
         pytest.skip("a GPU is visible")

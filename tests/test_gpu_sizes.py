@@ -200,3 +200,78 @@ def test_key_lifecycle_churn_short():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "churn.py"), "--ops", "400", "--seed", "3", "--max-log-n", "20",
                         "--watchdog", "1500"], capture_output=True, text=True, timeout=1700, cwd=ROOT, env=env)
     assert p.returncode == 0 and "CHURN OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+def test_prove_batch_multi_over_two_contexts(ctx, zk):
+    """zkmi_groth16_prove_batch_multi (BASELINE config 2 behind the C ABI): proof i runs on ctxs[i % n_dev] with that
+    context's replica of the key, one host thread per device.  Devices 0 and 1 where the box has two GPUs, two
+    contexts on device 0 otherwise.  Same bytes as the single-context batch prover, from host and device witnesses."""
+    import torch
+
+    import bench
+
+    lg = 14
+    r1, wits = bench.relation_and_witness(zk, "poseidon", lg, [71, 72, 73])
+    rng = ec.SplitMix64(7171)
+    toxic = frs([rng.fr() for _ in range(5)])
+    dev1 = 1 if torch.cuda.device_count() > 1 else 0
+    ctx1 = zk.context(dev1)
+    pk0, vk0 = ctx.groth16_setup(r1, toxic)
+    pk1, vk1 = ctx1.groth16_setup(r1, toxic)
+    assert vk0 == vk1
+    n = 7
+    idx = [i % 3 for i in range(n)]
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(n)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(n)]
+    d0 = [torch.frombuffer(bytearray(w), dtype=torch.uint8).to("cuda:0") for w in wits]
+    d1 = [torch.frombuffer(bytearray(w), dtype=torch.uint8).to(f"cuda:{dev1}") for w in wits]
+    pin = [torch.frombuffer(bytearray(w), dtype=torch.uint8).pin_memory() for w in wits]
+    torch.cuda.synchronize()
+    want = ctx.groth16_prove_batch_dev(pk0, [d0[j].data_ptr() for j in idx], rs, ss)
+    for i in (0, n - 1):
+        assert zk.groth16_verify(vk0, wits[idx[i]][32: 32 * r1.n_pub], want[i]) is True
+    got_host = zk.groth16_prove_batch_multi([ctx, ctx1], [pk0, pk1], [pin[j].data_ptr() for j in idx], False, rs, ss)
+    assert got_host == want
+    ptrs = [(d0 if i % 2 == 0 else d1)[j].data_ptr() for i, j in enumerate(idx)]
+    assert zk.groth16_prove_batch_multi([ctx, ctx1], [pk0, pk1], ptrs, True, rs, ss) == want
+    # a single device through the same entry point, and the argument checks
+    assert zk.groth16_prove_batch_multi([ctx], [pk0], [d0[j].data_ptr() for j in idx], True, rs, ss) == want
+    with pytest.raises(Exception):
+        zk.groth16_prove_batch_multi([ctx, ctx], [pk0, pk0], ptrs, True, rs, ss)  # one context twice
+    pk0.free()
+    pk1.free()
+    ctx1.close()
+    r1.free()
+
+
+def _bench(args, timeout=900):
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_msm26_workload_small():
+    """bench.py --workload msm26 (BASELINE config 3 in the bench contract) at a reduced size on one GPU: the line
+    carries the contract's keys, strong scaling, and the closed-form check of the MSM result."""
+    p, lines = _bench(["--workload", "msm26", "--msm-log-n", "22", "--steps", "2", "--warmup", "1"])
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
+    o = lines[0]
+    assert o["n_gpus"] == 1 and o["scaling"] == "strong" and o["matches_closed_form_on_every_rank"] is True
+    assert o["unit"] == "GB/s" and o["value"] > 0 and o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1
+
+
+def test_bench_gpus_gt_1_spawns_ranks_or_fails():
+    """`python bench.py --gpus 2` without a launcher starts two fresh ranks.  With two GPUs the line must say
+    n_gpus = 2; on a one-GPU box the second rank cannot bind a device and the whole command must fail without
+    printing any line (round 2 printed an n_gpus = 1 line here)."""
+    import torch
+
+    p, lines = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14", "--no-secondary", "--no-cpu-baseline"])
+    assert "starting 2 ranks" in p.stderr
+    if torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["verified_by_pairing"] is True, p.stderr[-3000:]
+    else:
+        assert p.returncode != 0 and not lines, p.stdout[-2000:]

@@ -254,6 +254,21 @@ class Zkmi:
         self._chk(self.lib.zkmi_msm_g1_multi(a_ctx, C.c_uint32(k), a_ptr, a_cnt, a_bas, out))
         return bytes(out)
 
+    def groth16_prove_batch_multi(self, ctxs, pks, z_ptrs, on_device, rs, ss):
+        """zkmi_groth16_prove_batch_multi: proof i runs on ctxs[i % len(ctxs)] with the key replica pks[i % len(ctxs)]."""
+        nd, n = len(ctxs), len(z_ptrs)
+        cs = (C.c_void_p * nd)(*[c.h.value for c in ctxs])
+        ks = (C.c_void_p * nd)(*[k.h.value for k in pks])
+        ptrs = (C.c_void_p * max(1, n))(*z_ptrs)
+        out = (C.c_uint8 * max(1, 192 * n))()
+        rc = self.lib.zkmi_groth16_prove_batch_multi(cs, ks, C.c_uint32(nd), C.c_uint32(n), ptrs, C.c_int32(int(on_device)),
+                                                     _buf(b"".join(rs)), _buf(b"".join(ss)), out)
+        if rc != 0:
+            msgs = "; ".join((self.lib.zkmi_last_error(c.h) or b"").decode() for c in ctxs)
+            raise ZkmiError(rc, msgs)
+        raw = bytes(out)
+        return [raw[192 * i: 192 * i + 192] for i in range(n)]
+
     def groth16_verify(self, vk, publics, proof):
         n_pub = (len(vk) - 672) // 96
         assert len(publics) == 32 * (n_pub - 1)

@@ -1026,6 +1026,52 @@ int32_t zkmi_groth16_prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_pr
   return prove_batch(ctx, pk, n_proofs, reinterpret_cast<const void* const*>(z), true, r_bytes, s_bytes, out_proofs);
 }
 
+// One batch over SEVERAL GPUs from one host process (BASELINE config 2 behind the C ABI; SURVEY.md 8e: independent
+// proofs, proof i -> device i mod n_dev, no data-path collective).  ctxs[d] / pks[d]: one context per device and
+// the key set up (or loaded) on that context.  One host thread per device runs that device's share through the
+// pipelined batch prover; results land in out_proofs in the caller's order.  z[i]: witness of proof i, a host
+// pointer (z_on_device = 0; pinned memory uploads asynchronously) or a device pointer on the device of
+// ctxs[i % n_dev] (z_on_device = 1).  Returns the first failing device's code (its message is in that ctx).
+int32_t zkmi_groth16_prove_batch_multi(zkmi_ctx* const* ctxs, const zkmi_pk* const* pks, uint32_t n_dev, uint32_t n_proofs,
+                                       const void* const* z, int32_t z_on_device, const uint8_t* r_bytes,
+                                       const uint8_t* s_bytes, uint8_t* out_proofs) {
+  if (!ctxs || !pks || n_dev == 0 || n_dev > 64 || (n_proofs && (!z || !r_bytes || !s_bytes || !out_proofs))) return ZKMI_ERR_BAD_ARG;
+  for (uint32_t d = 0; d < n_dev; d++) {
+    if (!ctxs[d] || !pks[d]) return ZKMI_ERR_BAD_ARG;
+    for (uint32_t e = 0; e < d; e++)
+      if (ctxs[e] == ctxs[d]) return ZKMI_ERR_BAD_ARG;  // a context serves one host thread at a time
+    if (pks[d]->n_vars != pks[0]->n_vars || pks[d]->n_pub != pks[0]->n_pub || pks[d]->log_n != pks[0]->log_n)
+      return ctxs[d]->fail(ZKMI_ERR_BAD_ARG, "the keys of a multi-device batch must be replicas of one key");
+  }
+  std::vector<int32_t> rc(n_dev, ZKMI_OK);
+  auto share = [&](uint32_t d) {
+    zkmi_ctx* ctx = ctxs[d];
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+      rc[d] = ctx->fail(ZKMI_ERR_HIP, "hipSetDevice");
+      return;
+    }
+    std::vector<const void*> zz;
+    std::vector<uint8_t> rr, ss;
+    for (uint32_t i = d; i < n_proofs; i += n_dev) {
+      zz.push_back(z[i]);
+      rr.insert(rr.end(), r_bytes + 32ull * i, r_bytes + 32ull * i + 32);
+      ss.insert(ss.end(), s_bytes + 32ull * i, s_bytes + 32ull * i + 32);
+    }
+    if (zz.empty()) return;
+    std::vector<uint8_t> out(192 * zz.size());
+    rc[d] = prove_batch(ctx, pks[d], (uint32_t)zz.size(), zz.data(), z_on_device == 0, rr.data(), ss.data(), out.data());
+    if (rc[d] != ZKMI_OK) return;
+    for (size_t k = 0; k < zz.size(); k++) memcpy(out_proofs + 192ull * (d + k * n_dev), out.data() + 192 * k, 192);
+  };
+  std::vector<std::thread> th;
+  for (uint32_t d = 1; d < n_dev; d++) th.emplace_back(share, d);
+  share(0);  // the calling thread drives device 0
+  for (auto& t : th) t.join();
+  for (uint32_t d = 0; d < n_dev; d++)
+    if (rc[d] != ZKMI_OK) return rc[d];
+  return ZKMI_OK;
+}
+
 int32_t zkmi_groth16_verify(const uint8_t* vk, uint32_t n_pub, const uint8_t* publics, const uint8_t proof[192]) {
   if (!vk || !proof || n_pub == 0 || (n_pub > 1 && !publics)) return ZKMI_ERR_BAD_ARG;
   G1Affine alpha, a, c;

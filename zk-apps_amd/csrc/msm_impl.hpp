@@ -688,12 +688,22 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   const int T = 256;
   XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
-  const bool side = st_heavy && st_heavy != st;
-  if (side) {
-    // heavy and light buckets are disjoint, so the two kernels may run side by side: the heavy stream
-    // only has to see the sort complete
+  // Heavy and light buckets are disjoint, so the heavy-bucket kernels only have to see the sort complete.  Where they
+  // run (ZKMI_HEAVY_ON, read once): 0 = in line on the accumulation stream; 1 = on `st_heavy` beside the accumulation
+  // (round 2: a normal-priority side stream); 2 (default) = at the head of the REDUCTION's stream.  With uniform
+  // scalars the heavy list is empty, but an empty 512-workgroup launch still has to be placed: on a normal-priority
+  // stream it queued behind the next accumulation's workgroups (0.9 ms G1 / 9.8 ms G2 average in the round-2 trace)
+  // and every reduction waited for it.  The reduction streams have high priority, so there the launch is placed as
+  // soon as any workgroup retires, and no cross-stream event sits between it and the reduction.
+  static const int heavy_on = [] {
+    const char* e = getenv("ZKMI_HEAVY_ON");
+    return e ? atoi(e) : 2;
+  }();
+  const bool on_reduce = heavy_on == 2 && st_reduce != st;
+  const bool side = !on_reduce && heavy_on != 0 && st_heavy && st_heavy != st;
+  if (side || on_reduce) {
     if ((e = hipEventRecord(pre[slot], st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(st_heavy, pre[slot], 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(on_reduce ? st_reduce : st_heavy, pre[slot], 0)) != hipSuccess) return e;
   }
   // ZKMI_ACCUM: 0 = the first-generation kernels (madd with an out-of-line doubling path), 2/3 = the call-free
   // kernels at 2 / 3 waves per SIMD (default: see DESIGN.md 4.1 for the measurements behind it)
@@ -759,7 +769,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
                          sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
-  const hipStream_t sh = side ? st_heavy : st;
+  const hipStream_t sh = on_reduce ? st_reduce : side ? st_heavy : st;
   XYZZ<F>* const hp = heavy_partial + (size_t)slot * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
   hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, sh, d_bases,
                      sort.begin, sort.count, sort.heavy, sort.sorted, bk, hp);
@@ -772,6 +782,10 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     if ((e = hipEventRecord(heavy_done[slot], st_heavy)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(st_reduce, heavy_done[slot], 0)) != hipSuccess) return e;
     sort.readers.push_back(heavy_done[slot]);  // the next sort must not overwrite what these kernels read
+  }
+  if (on_reduce && !nocall) {  // (with the call-free kernels redo_done below covers the heavy kernels too: same stream, later)
+    if ((e = hipEventRecord(heavy_done[slot], st_reduce)) != hipSuccess) return e;
+    sort.readers.push_back(heavy_done[slot]);
   }
   if (nocall) {
     // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
