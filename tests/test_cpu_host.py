@@ -112,6 +112,21 @@ def zk_has_gpu():
     return load_pkg().Zkmi().device_count() > 0
 
 
+def test_public_point_encoding_known_answers_on_the_product(zk):
+    """The published encodings of test_cpu_oracle.PUBLIC_KATS through the product's host code (wire.hip, curve.hpp)."""
+    from test_cpu_oracle import PUBLIC_KATS
+
+    g1, g2 = zk.g1_generator(), zk.g2_generator()
+    k = lambda v: int(v).to_bytes(32, "little")
+    assert zk.g1_compress(g1).hex() == PUBLIC_KATS["g1_x1"]
+    assert zk.g1_compress(zk.g1_mul(g1, k(2))).hex() == PUBLIC_KATS["g1_x2"]
+    assert zk.g1_compress(zk.g1_add(zk.g1_mul(g1, k(2)), g1)).hex() == PUBLIC_KATS["g1_x3"]
+    assert zk.g1_compress(zk.g1_mul(g1, k(ec.R - 1))).hex() == PUBLIC_KATS["g1_neg"]
+    assert zk.g2_compress(zk.g2_mul(g2, k(2))).hex() == PUBLIC_KATS["g2_x2"]
+    assert zk.g2_compress(zk.g2_add(g2, g2)).hex() == PUBLIC_KATS["g2_x2"]
+    assert zk.g1_decompress(H(PUBLIC_KATS["g1_x3"])) == zk.g1_mul(g1, k(3))
+
+
 def test_ctx_create_without_gpu_fails_loudly(zk, pkg):
     if zk.device_count() > 0:
         pytest.skip("a GPU is visible")

@@ -24,12 +24,50 @@ def test_curve_constants_known_answers():
         "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
         "6c55e83ff97a1aeffb3af00adb22c6bb"
     )
-    assert c["g2_compressed"].startswith("93e02b6052719f607dacd3a088274f65")
+    # the full 96-byte compressed G2 generator (zcash bls12_381 crate / IETF pairing-friendly-curves draft, appendix)
+    assert c["g2_compressed"] == (
+        "93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+        "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
+    )
     assert ec.g1_compress(ec.G1).hex() == c["g1_compressed"]
     assert ec.g2_compress(ec.G2).hex() == c["g2_compressed"]
     w = int(c["fr_root_2_32"], 16)
     assert w == 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
     assert pow(w, 1 << 32, R) == 1 and pow(w, 1 << 31, R) == R - 1
+
+
+PUBLIC_KATS = {
+    # eth2 interop / BLS-signature public keys of the secret keys 1, 2, 3 = compressed [k]G1 (widely published)
+    "g1_x1": "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb",
+    "g1_x2": "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+    "g1_x3": "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224",
+    # -G1: same x, sign bit set (zcash encoding: bit 5 of the first byte = y is the lexicographically larger root)
+    "g1_neg": "b7f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb",
+    # [2]G2, second entry of the zcash crate's g2_compressed_valid_test_vectors
+    "g2_x2": "aa4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572c6c886f6b57ec72a6178288c47c33577"
+             "1638533957d540a9d2370f17cc7ed5863bc0b995b8825e0ee1ea1e1e4d00dbae81f14b0bf3611b78c952aacab827a053",
+}
+# G2 generator coordinates (IETF draft-irtf-cfrg-pairing-friendly-curves, BLS12-381): x = x0 + x1 u, y = y0 + y1 u
+G2_GEN = (
+    (0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+     0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+    (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+     0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE),
+)
+
+
+def test_public_point_encoding_known_answers():
+    """Published compressed encodings of small multiples of the generators, recalled from public sources that need no
+    toolchain (each labelled above): they pin scalar multiplication, the sign convention and the Fq2 component order
+    (c1 first) of the zcash / ark-bls12-381 encoding in the oracle.  tests/test_cpu_host.py repeats them on the product's
+    host code."""
+    assert ec.g1_compress(ec.G1).hex() == PUBLIC_KATS["g1_x1"]
+    assert ec.g1_compress(ec.g1_mul(2)).hex() == PUBLIC_KATS["g1_x2"]
+    assert ec.g1_compress(ec.g1_mul(3)).hex() == PUBLIC_KATS["g1_x3"]
+    assert ec.g1_compress(ec.g1_mul(R - 1)).hex() == PUBLIC_KATS["g1_neg"]
+    assert ec.g2_compress(ec.g2_mul(2)).hex() == PUBLIC_KATS["g2_x2"]
+    assert (tuple(ec.G2[0]), tuple(ec.G2[1])) == G2_GEN
+    assert ec.g1_compress(None).hex() == "c0" + "00" * 47 and ec.g2_compress(None).hex() == "c0" + "00" * 95
 
 
 def test_reference_pinned_mock_boundary_vectors():

@@ -961,8 +961,8 @@ def test_msm_random_sizes_vs_cpp_oracle(ctx):
 
 
 def test_ntt_every_size_round_trip_and_definition(ctx):
-    """Every domain size 2^0 ... 2^22: inverse(forward(x)) == x and coset round trip on device; sizes
-    up to 2^10 also against the C++ oracle."""
+    """Every domain size 2^0 ... 2^22 (one-, two- and three-pass plans, every tile shape of the register-blocked passes):
+    forward and coset-inverse transforms against the C++ oracle, inverse(forward(x)) == x and the coset round trip."""
     import torch
     from oracle import cpp as ocpp
 
@@ -974,14 +974,16 @@ def test_ntt_every_size_round_trip_and_definition(ctx):
         raw[:, 31] &= 0x3F
         x = raw.clone()
         torch.cuda.synchronize()
+        host = bytes(raw.cpu().numpy().tobytes())
         ctx.ntt_dev(x.data_ptr(), lg)
-        if lg <= 10:
-            assert bytes(x.cpu().numpy().tobytes()) == ocpp.ntt(bytes(raw.cpu().numpy().tobytes()), lg), lg
+        assert bytes(x.cpu().numpy().tobytes()) == ocpp.ntt(host, lg), lg
         ctx.ntt_dev(x.data_ptr(), lg, inverse=True)
         assert torch.equal(x, raw), lg
         ctx.ntt_dev(x.data_ptr(), lg, coset=True)
         ctx.ntt_dev(x.data_ptr(), lg, inverse=True, coset=True)
         assert torch.equal(x, raw), lg
+        ctx.ntt_dev(x.data_ptr(), lg, inverse=True, coset=True)
+        assert bytes(x.cpu().numpy().tobytes()) == ocpp.ntt(host, lg, inverse=True, coset=True), lg
 
 
 @pytest.mark.parametrize("lg", [7, 8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 20, 21])
@@ -1286,7 +1288,8 @@ def test_arkworks_key_layout_load_and_write(ctx, zk):
     r1.free()
 
 
-def test_arkworks_fixture_if_present(ctx, zk):
+@pytest.mark.parametrize("sub", ["arkworks", "arkworks_2p13"])
+def test_arkworks_fixture_if_present(ctx, zk, sub):
     """Consumes what integration/ark_fixture (a Rust program a maintainer with cargo builds; it cannot be built in
     this image) writes to tests/golden/arkworks/: the relation, an ark-groth16 proving key, the witness, (r, s) and
     arkworks' own proof.  With it, proof bytes are pinned against the real arkworks prover; without it this test
@@ -1295,7 +1298,7 @@ def test_arkworks_fixture_if_present(ctx, zk):
 
     from conftest import ROOT
 
-    d = os.path.join(ROOT, "tests", "golden", "arkworks")
+    d = os.path.join(ROOT, "tests", "golden", sub)
     need = ["relation.bin", "pk_uncompressed.bin", "witness.bin", "rs.bin", "proof.bin"]
     if not all(os.path.exists(os.path.join(d, f)) for f in need):
         pytest.skip("no arkworks fixture under tests/golden/arkworks (build integration/ark_fixture with cargo to create it)")

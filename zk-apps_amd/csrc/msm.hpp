@@ -76,6 +76,7 @@ struct MsmSort {
   uint32_t* order_bins = nullptr; // load-ordering: global key histogram -> running offsets
   uint32_t* part_total = nullptr; // shared mode: entries per partition
   uint32_t* blkcnt = nullptr;     // shared mode record pre-pass: per-(block, partition) counts -> slots
+  uint32_t* fpart = nullptr;      // fine-partition sort: [q] first record slot, [NP + q] records of fine partition q
   uint32_t* rec_entry = nullptr;  // records grouped by partition: table index | sign
   uint32_t* rec_bkt = nullptr;    //                               bucket id inside the partition
   uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31

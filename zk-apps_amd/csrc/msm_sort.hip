@@ -209,6 +209,127 @@ k_bucket_pass_rec(const uint32_t* __restrict__ rec_entry, const uint32_t* __rest
   }
 }
 
+// ---- fine-partition sort (shared mode, more than 2^15 buckets) ---------------------------------
+// The (chunk, 2^15-bucket partition) tiles above scatter 4-byte entries at random into a partition's slice of
+// sorted[]: a bucket's run of ~26 entries receives ~1.6 entries from each of 16 tiles, so nearly every write is a
+// partial line (WRITE_SIZE 8x the payload in the round-2 counters, 97 % of wave cycles waiting).  Here the records
+// are grouped by FINE partition instead (2^11 consecutive buckets, ~53 k records at N = 2^20) and ONE workgroup owns
+// a fine partition end to end: LDS histogram of its records -> prefix sum -> count[] / begin[] of its buckets ->
+// scatter into its own contiguous slice of sorted[] (212 KB: the runs of a bucket are completed by one workgroup
+// within microseconds, so the lines are written once).  No per-tile histograms in HBM, no separate totals / scan /
+// bases kernels for this mode.
+constexpr int FINE_LOG = 11;                 // buckets per fine partition
+constexpr uint32_t FINE_NB = 1u << FINE_LOG;
+constexpr uint32_t FINE_MAX_PARTS = 2048;    // 2^22 buckets (c = 23)
+constexpr uint32_t FPART_BLOCKS = 512;       // blocks of the record pre-pass
+
+// records grouped by fine partition: WRITE = false counts per (block, partition), WRITE = true writes
+// rec_entry (table index | sign) and rec_bkt (bucket inside the fine partition) at the slots k_fpart_scan assigned
+template <bool WRITE>
+__global__ void __launch_bounds__(1024)
+k_fpart_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t NP, uint32_t chunk, RecodeConst rc,
+             uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry, uint32_t* __restrict__ rec_bkt) {
+  extern __shared__ uint32_t cnt[];  // NP counters / cursors
+  for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x) cnt[q] = WRITE ? blkcnt[(size_t)blockIdx.x * NP + q] : 0u;
+  __syncthreads();
+  const uint32_t beg = blockIdx.x * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    uint32_t k[9];
+    load_biased(scalars, i, rc, k);
+    for (int w = 0; w < ndigits; w++) {
+      bool neg;
+      const uint32_t d = digit_of(k, w, c, neg);
+      if (d == 0) continue;
+      const uint32_t bkt = d - 1;
+      const uint32_t pos = atomicAdd(&cnt[bkt >> FINE_LOG], 1u);
+      if (WRITE) {
+        rec_entry[pos] = ((uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
+        rec_bkt[pos] = bkt & (FINE_NB - 1u);
+      }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x) blkcnt[(size_t)blockIdx.x * NP + q] = cnt[q];
+  }
+}
+
+// one workgroup: blkcnt[blk][q] -> first record slot of (blk, q); fpart[q] = first slot of partition q, fpart[NP + q] = its size
+__global__ void __launch_bounds__(1024)
+k_fpart_scan(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t NP, uint32_t* __restrict__ fpart) {
+  __shared__ uint32_t tot[FINE_MAX_PARTS];
+  __shared__ uint32_t part[1024];
+  for (uint32_t q = threadIdx.x; q < NP; q += 1024) {
+    uint32_t s = 0;
+    for (uint32_t b = 0; b < nblk; b++) s += blkcnt[(size_t)b * NP + q];
+    tot[q] = s;
+  }
+  __syncthreads();
+  // exclusive prefix over the NP totals: thread t owns partitions [t * per, (t + 1) * per)
+  const uint32_t per = (NP + 1023u) / 1024u;
+  uint32_t s = 0;
+  for (uint32_t q = threadIdx.x * per; q < (threadIdx.x + 1) * per && q < NP; q++) s += tot[q];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t q = threadIdx.x * per; q < (threadIdx.x + 1) * per && q < NP; q++) {
+    const uint32_t t = tot[q];
+    fpart[q] = run;
+    fpart[NP + q] = t;
+    uint32_t r2 = run;
+    for (uint32_t b = 0; b < nblk; b++) {
+      const uint32_t v = blkcnt[(size_t)b * NP + q];
+      blkcnt[(size_t)b * NP + q] = r2;
+      r2 += v;
+    }
+    run += t;
+  }
+}
+
+// one workgroup per fine partition: histogram -> scan -> count / begin -> scatter (see above)
+__global__ void __launch_bounds__(1024)
+k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
+             uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t hist[FINE_NB];
+  __shared__ uint32_t part[1024];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t pbase = fpart[q], ptot = fpart[NP + q];
+  for (uint32_t b = tid; b < FINE_NB; b += 1024) hist[b] = 0;
+  __syncthreads();
+  for (uint32_t r = tid; r < ptot; r += 1024) atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
+  __syncthreads();
+  static_assert(FINE_NB == 2048, "two counters per thread");
+  const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+  part[tid] = c0 + c1;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t ex = pbase + (tid ? part[tid - 1] : 0u);
+  const size_t g = (size_t)q * FINE_NB + 2 * tid;
+  count[g] = c0;
+  count[g + 1] = c1;
+  begin[g] = ex;
+  begin[g + 1] = ex + c0;
+  hist[2 * tid] = ex;  // cursors
+  hist[2 * tid + 1] = ex + c0;
+  __syncthreads();
+  for (uint32_t r = tid; r < ptot; r += 1024) {
+    const uint32_t pos = atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
+    sorted[pos] = rec_entry[pbase + r];
+  }
+}
+
 __global__ void __launch_bounds__(1024)
 k_part_totals(const uint32_t* __restrict__ count, uint32_t* __restrict__ part_total, uint32_t nb) {
   __shared__ uint32_t part[1024];
@@ -522,12 +643,13 @@ void MsmSort::release() {
   if (part_total) (void)hipFree(part_total);
   if (order_bins) (void)hipFree(order_bins);
   if (blkcnt) (void)hipFree(blkcnt);
+  if (fpart) (void)hipFree(fpart);
   if (rec_entry) (void)hipFree(rec_entry);
   if (rec_bkt) (void)hipFree(rec_bkt);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = order_bins = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = order_bins = fpart = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
   has_shared = false;
 }
@@ -583,7 +705,8 @@ hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
   if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
-  if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * 256 * 64)) != hipSuccess) return e;
+  if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * FPART_BLOCKS * FINE_MAX_PARTS)) != hipSuccess) return e;  // also 256 x 64 of the coarse form
+  if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 2 * FINE_MAX_PARTS)) != hipSuccess) return e;
   if (shared) {
     if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * ne)) != hipSuccess) return e;
     if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * ne)) != hipSuccess) return e;
@@ -700,6 +823,25 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
   const bool records = P > 1;
+  // ZKMI_SORT_FINE=0 restores the round-2 record sort ((chunk, 2^15-bucket partition) tiles with HBM tile histograms)
+  static const bool fine_on = !(getenv("ZKMI_SORT_FINE") && getenv("ZKMI_SORT_FINE")[0] == '0');
+  const uint32_t NP = tot_b >> FINE_LOG;
+  if (records && fine_on && NP <= FINE_MAX_PARTS && fpart != nullptr) {
+    uint32_t nblk = (uint32_t)((n + 4095) / 4096);
+    if (nblk > FPART_BLOCKS) nblk = FPART_BLOCKS;
+    const uint32_t chunk_a = (uint32_t)((n + nblk - 1) / nblk);
+    const size_t lds_np = sizeof(uint32_t) * NP;
+    hipLaunchKernelGGL(k_fpart_pass<false>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
+                       rc, blkcnt, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_fpart_scan, dim3(1), dim3(1024), 0, st, blkcnt, nblk, NP, fpart);
+    hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
+                       rc, blkcnt, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_fpart_sort, dim3(NP), dim3(1024), 0, st, rec_entry, rec_bkt, fpart, NP, count, begin, sorted);
+    hipError_t e1 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
+    if (e1 != hipSuccess) return e1;
+    if (prof) prof->end(PH_MSM_SORT, st);
+    return hipGetLastError();
+  }
   uint32_t nblk_a = 0, chunk_a = 0;
   if (records) {
     nblk_a = (uint32_t)((n + 4095) / 4096);

@@ -20,6 +20,9 @@
 // and the coset / 1/N scalings are folded into the last pass of the DIF
 // transforms (table indexed by position).  The natural-order public entry point
 // adds one bit-reversal copy in front of a DIT transform.
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "ntt.hpp"
 
 namespace zkmi {
@@ -131,6 +134,167 @@ k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, in
   for (uint32_t L = threadIdx.x; L < tile_n; L += THREADS) {
     const uint32_t g = gindex(L);
     F v = tile[L];
+    if (LOCAL_TW && DIF && t0 > 0) v = v * twist(L);
+    if (post) v = v * ld28(post + g);
+    if (canon_out) {
+      uint32_t w[8];
+      v.to_canonical(w);
+      st_words8(canon_out + (size_t)g * 8, w);
+    } else {
+      st28(data + g, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-blocked pass (round 3).  Same tiles, same twists and the same stage order as k_ntt_pass, but a thread
+// owns E = 2^LOGE tile elements per ROUND and runs up to LOGE butterfly stages on them in registers (radix-8
+// sub-butterflies for LOGE = 3: 12 products between two barriers instead of one).  A 2048-element tile is a
+// 256-thread workgroup: 10 stages = 4 barriers instead of 10, 3.3x fewer LDS round trips per butterfly, and -- what
+// matters inside the prover -- one wave per SIMD instead of four, so the workgroup fits beside the bucket
+// accumulation's waves (168 VGPRs x 3 per SIMD) as soon as ONE of them retires; the 1024-thread form needed a
+// whole CU to drain (0.49 ms per pass in the round-2 pipeline trace against 0.14 ms alone).
+// LDS layout: limb-major 32-bit words, element index padded by one word per 32 (index L -> L + L / 32), so that the
+// strided element sets of a round (stride 2^(u0 + Q) elements between a thread's own elements, stride 1 or 2^K
+// between lanes) fall into distinct banks; the twiddles of the sub-transform use the same layout.
+// compile-time loops: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- the register
+// arrays of the blocked pass are only ever indexed with constants, so they stay in VGPRs
+template <int... Is, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <class F>
+struct RbLds {
+  uint32_t* w;
+  uint32_t pitch;
+  __device__ __forceinline__ static uint32_t pad(uint32_t L) { return L + (L >> 5); }
+  __device__ __forceinline__ F ld(uint32_t L) const {
+    F r;
+    const uint32_t o = pad(L);
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) r.l[i] = (int32_t)w[i * pitch + o];
+    return r;
+  }
+  __device__ __forceinline__ void st(uint32_t L, const F& v) const {
+    const uint32_t o = pad(L);
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) w[i * pitch + o] = (uint32_t)v.l[i];
+  }
+};
+
+template <class F, bool DIF, bool LOCAL_TW, int LOGE>
+__global__ void __launch_bounds__(256)
+k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
+              const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
+  constexpr int E = 1 << LOGE;
+  data += (size_t)blockIdx.y << log_n;
+  if (canon_out) canon_out += ((size_t)blockIdx.y << log_n) * 8;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const uint32_t tile_n = 1u << (S + Q);
+  const uint32_t nthr = tile_n >> LOGE;  // == blockDim.x
+  RbLds<F> tile{reinterpret_cast<uint32_t*>(lds_raw), tile_n + (tile_n >> 5)};
+  RbLds<F> ctw{tile.w + (size_t)F::NL * tile.pitch, (1u << (S - 1)) + ((1u << (S - 1)) >> 5) + 1u};
+  const uint32_t blk = blockIdx.x, tid = threadIdx.x;
+  const uint32_t mid_bits = (t0 > 0) ? (uint32_t)(t0 - Q) : 0u;
+  const uint32_t mid = blk & ((1u << mid_bits) - 1u);
+  const uint32_t hi = blk >> mid_bits;
+  const uint32_t qeff = (t0 > 0) ? (uint32_t)Q : 0u;
+  auto gindex = [&](uint32_t L) -> uint32_t {
+    if (t0 == 0) return blk * tile_n + L;
+    const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
+    return (hi << (t0 + S)) | (e << t0) | (mid << Q) | c;
+  };
+  auto twist = [&](uint32_t L) -> F {
+    const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
+    const uint32_t col = (mid << Q) | c;
+    const uint32_t ex = col * (__brev(e) >> (32 - S));
+    const uint32_t halfn = 1u << (log_n - 1);
+    F f = ld28(tw + (ex & (halfn - 1u)));
+    return (ex & halfn) ? f.neg() : f;
+  };
+  if (LOCAL_TW)
+    for (uint32_t k = tid; k < (1u << (S - 1)); k += nthr) ctw.st(k, ld28(tw + ((size_t)k << (log_n - S))));
+#pragma unroll
+  for (int m = 0; m < E; m++) {
+    const uint32_t L = tid + (uint32_t)m * nthr;
+    F v = ld28(data + gindex(L));
+    if (LOCAL_TW && !DIF && t0 > 0) v = v * twist(L);
+    tile.st(L, v);
+  }
+  __syncthreads();
+
+  // one round = K consecutive stages [u0, u0 + K) on E elements per thread (2^(LOGE - K) independent groups of 2^K)
+  auto round = [&](auto kc, int u0) __attribute__((always_inline)) {
+    constexpr int K = decltype(kc)::value;
+    const uint32_t sh = (uint32_t)u0 + qeff;
+    F x[E];
+    uint32_t Lm[E];
+    static_for<E>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      constexpr uint32_t j = (uint32_t)m & ((1u << K) - 1u), g = (uint32_t)m >> K;
+      const uint32_t G = (tid << (LOGE - K)) | g;
+      Lm[m] = ((G >> sh) << (sh + K)) | (G & ((1u << sh) - 1u)) | (j << sh);
+      x[m] = tile.ld(Lm[m]);
+    });
+    static_for<K>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = DIF ? (K - 1 - decltype(ic)::value) : decltype(ic)::value;
+      const int u = u0 + i;
+      const uint32_t dist_log = (uint32_t)u + qeff;
+      static_for<E>([&](auto m0c) __attribute__((always_inline)) {
+        constexpr int m0 = decltype(m0c)::value;
+        if constexpr ((m0 & (1 << i)) == 0) {
+          constexpr int m1 = m0 | (1 << i);
+          F w;
+          if (LOCAL_TW) {
+            const uint32_t lo = Lm[m0] & ((1u << dist_log) - 1u);
+            w = ctw.ld((lo >> qeff) << (S - 1 - u));
+          } else {
+            const int t = t0 + u;
+            const uint32_t jj = gindex(Lm[m0]) & ((1u << t) - 1u);
+            w = ld28(tw + ((size_t)jj << (log_n - 1 - t)));
+          }
+          if (DIF) {
+            const F a = x[m0], b = x[m1];
+            x[m0] = a + b;
+            x[m1] = a.sub_lazy(b) * w;
+          } else {
+            const F y = x[m1] * w;
+            const F a = x[m0];
+            x[m0] = a + y;
+            x[m1] = a - y;
+          }
+        }
+      });
+    });
+    static_for<E>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      tile.st(Lm[m], x[m]);
+    });
+    __syncthreads();
+  };
+  {
+    int done = 0;
+    while (done < S) {
+      int k = S - done;
+      if (k > LOGE) k = LOGE;
+      const int u0 = DIF ? (S - done - k) : done;
+      if (LOGE >= 3 && k == 3) round(std::integral_constant<int, (LOGE >= 3 ? 3 : 1)>{}, u0);
+      else if (LOGE >= 2 && k == 2) round(std::integral_constant<int, (LOGE >= 2 ? 2 : 1)>{}, u0);
+      else round(std::integral_constant<int, 1>{}, u0);
+      done += k;
+    }
+  }
+
+#pragma unroll
+  for (int m = 0; m < E; m++) {
+    const uint32_t L = tid + (uint32_t)m * nthr;
+    const uint32_t g = gindex(L);
+    F v = tile.ld(L);
     if (LOCAL_TW && DIF && t0 > 0) v = v * twist(L);
     if (post) v = v * ld28(post + g);
     if (canon_out) {
@@ -277,10 +441,31 @@ hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
 
 // stages [0, log_n) split into passes of <= 10 stages; pass k of a DIT transform
 // covers the low stages first, of a DIF transform the high stages first
+// ZKMI_NTT_RB (read once): 1 (default) = register-blocked passes (k_ntt_pass_rb, 8 elements per thread, tiles of 2048
+// elements for every pass that has them), 2 = the same with 4 elements per thread (512-thread workgroups),
+// 0 = the round-2 form (k_ntt_pass: one butterfly per thread and barrier, short strided passes in 2-column tiles)
+static int ntt_rb_mode() {
+  static const int v = [] {
+    const char* e = getenv("ZKMI_NTT_RB");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+template <class F, bool DIF, bool LTW, int LOGE>
+static void launch_rb(dim3 grid, uint32_t tile_n, int S, hipStream_t stream, F* buf, const F* tw, int log_n, int t0, int Q,
+                      const F* post, uint32_t* canon_out) {
+  const size_t words = (size_t)F::NL * (tile_n + (tile_n >> 5)) +
+                       (LTW ? (size_t)F::NL * ((1u << (S - 1)) + ((1u << (S - 1)) >> 5) + 1u) : 0u);
+  hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE>), grid, dim3(tile_n >> LOGE), words * sizeof(uint32_t), stream, buf, tw, log_n,
+                     t0, S, Q, post, canon_out);
+}
+
 template <class F, bool DIF>
 static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
                              hipStream_t stream, uint32_t batch = 1) {
   const uint32_t n = 1u << log_n;
+  const int rb = ntt_rb_mode();
   struct Pass {
     int t0, S, Q;
   } passes[4];
@@ -288,9 +473,18 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
   for (int t0 = 0; t0 < log_n;) {
     int S = log_n - t0;
     if (S > 10) S = 10;
-    // strided passes: 2 adjacent columns; the contiguous pass: 2 sub-transforms per
-    // workgroup so that all 1024 threads own a butterfly in every stage
-    const int Q = (t0 > 0) ? 1 : ((log_n > S) ? 1 : 0);
+    int Q;
+    if (rb) {
+      // tiles of 2^11 elements wherever the transform has them: a strided pass takes 2^Q adjacent columns (2^Q x 40 B
+      // contiguous per access), the contiguous pass 2^Q whole sub-transforms
+      Q = 11 - S;
+      const int room = (t0 > 0) ? t0 : (log_n - S);
+      if (Q > room) Q = room;
+    } else {
+      // strided passes: 2 adjacent columns; the contiguous pass: 2 sub-transforms per
+      // workgroup so that all 1024 threads own a butterfly in every stage
+      Q = (t0 > 0) ? 1 : ((log_n > S) ? 1 : 0);
+    }
     passes[np++] = {t0, S, Q};
     t0 += S;
   }
@@ -300,21 +494,32 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     const bool last = (k == np - 1);
     const uint32_t tile_n = 1u << (p.S + p.Q);
     const uint32_t nblk = n / tile_n;
-    const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(F);
     const F* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
+    const dim3 grid(nblk, batch);
+    if (rb && tile_n >= 512) {
+      if (rb == 2) {
+        if (local_tw) launch_rb<F, DIF, true, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+        else launch_rb<F, DIF, false, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+      } else {
+        if (local_tw) launch_rb<F, DIF, true, 3>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+        else launch_rb<F, DIF, false, 3>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+      }
+      continue;
+    }
+    const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(F);
     if (tile_n >= 1024) {
       if (local_tw)
-        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), dim3(nblk, batch), dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), grid, dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
                            p.Q, pp, co);
       else
-        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 1024>), dim3(nblk, batch), dim3(1024), lds, stream, buf, tw, log_n, p.t0,
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 1024>), grid, dim3(1024), lds, stream, buf, tw, log_n, p.t0,
                            p.S, p.Q, pp, co);
     } else if (local_tw) {
-      hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 64>), dim3(nblk, batch), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 64>), grid, dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     } else {
-      hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 64>), dim3(nblk, batch), dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
+      hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 64>), grid, dim3(64), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q,
                          pp, co);
     }
   }
@@ -381,6 +586,19 @@ hipError_t ntt_mul_table(F* d, const F* table, uint32_t n, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class F>
+static hipError_t rb_enable_big_lds() {
+  const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 3>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 3>),
+                       reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 3>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 3>),
+                       reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 2>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 2>),
+                       reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 2>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 2>)};
+  for (const void* f : fns) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t ntt_enable_big_lds() {
   const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, true, 1024>),
                        reinterpret_cast<const void*>(k_ntt_pass<Fr28, false, true, 1024>),
@@ -394,7 +612,9 @@ hipError_t ntt_enable_big_lds() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
-  return hipSuccess;
+  hipError_t e = rb_enable_big_lds<Fr28>();
+  if (e == hipSuccess) e = rb_enable_big_lds<BnFr28>();
+  return e;
 }
 
 template struct NttDomainT<Fr28>;
