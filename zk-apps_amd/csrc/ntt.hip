@@ -188,7 +188,7 @@ struct RbLds {
 };
 
 template <class F, bool DIF, bool LOCAL_TW, int LOGE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(2048 >> LOGE)
 k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
               const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
   constexpr int E = 1 << LOGE;
@@ -441,13 +441,20 @@ hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
 
 // stages [0, log_n) split into passes of <= 10 stages; pass k of a DIT transform
 // covers the low stages first, of a DIF transform the high stages first
-// ZKMI_NTT_RB (read once): 1 (default) = register-blocked passes (k_ntt_pass_rb, 8 elements per thread, tiles of 2048
-// elements for every pass that has them), 2 = the same with 4 elements per thread (512-thread workgroups),
-// 0 = the round-2 form (k_ntt_pass: one butterfly per thread and barrier, short strided passes in 2-column tiles)
+// ZKMI_NTT_RB (read once) selects the pass kernels:
+//   0 = the round-2 form: k_ntt_pass, one butterfly per thread and barrier, short strided passes in 2-column tiles
+//   3 = (default) the same kernel, but a short pass (S < 10: the third pass of N >= 2^21) takes 2^(11-S) adjacent
+//       columns per tile when that still leaves >= 512 tiles: 2048-element tiles with 1024 busy threads instead of
+//       8-element tiles in 64-thread workgroups (N = 2^22: 1.62 -> 1.1 ms per transform)
+//   1 / 2 = register-blocked passes k_ntt_pass_rb with 8 / 4 elements per thread (256- / 512-thread workgroups),
+//       2048-element tiles wherever the transform has them.  Measured in round 3 (profiles/r03/ntt_variants.txt): equal
+//       to the plain kernel at N = 2^20 alone (0.25 ms per transform), slower below 2^18 (fewer, larger workgroups),
+//       and the 8-element form costs the prover 2-3 % (one 256-VGPR wave per SIMD plus 105 KB of LDS leaves room for
+//       one accumulation wave instead of three beside it).  Kept selectable; not the default.
 static int ntt_rb_mode() {
   static const int v = [] {
     const char* e = getenv("ZKMI_NTT_RB");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 3;
   }();
   return v;
 }
@@ -465,7 +472,8 @@ template <class F, bool DIF>
 static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
                              hipStream_t stream, uint32_t batch = 1) {
   const uint32_t n = 1u << log_n;
-  const int rb = ntt_rb_mode();
+  const int mode = ntt_rb_mode();
+  const int rb = (mode == 1 || mode == 2) ? mode : 0;
   struct Pass {
     int t0, S, Q;
   } passes[4];
@@ -484,6 +492,8 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
       // strided passes: 2 adjacent columns; the contiguous pass: 2 sub-transforms per
       // workgroup so that all 1024 threads own a butterfly in every stage
       Q = (t0 > 0) ? 1 : ((log_n > S) ? 1 : 0);
+      // wide tiles for a short strided pass of a big transform (mode 3): 2^11 elements per tile, >= 512 tiles per vector
+      if (mode == 3 && t0 > 0 && S < 10 && log_n - 11 >= 9) Q = (11 - S < t0) ? 11 - S : t0;
     }
     passes[np++] = {t0, S, Q};
     t0 += S;
