@@ -141,8 +141,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_front, hipStreamNonBlocking,
                                   (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '0') ? 0 : prio_hi) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess) {  // stream_sort / acc2 / acc3: lazily
+      hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess) {  // stream_sort / heavy / acc3: lazily
     delete c;
     return ZKMI_ERR_HIP;
   }

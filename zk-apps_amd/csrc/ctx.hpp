@@ -18,7 +18,7 @@ struct zkmi_ctx {
   hipStream_t stream_g2 = nullptr;   // G2 accumulation beside the G1 ones
   hipStream_t stream_front = nullptr;  // witness map + NTTs beside the MSMs over z
   hipStream_t stream_copy = nullptr;   // witness uploads / copies of the next proof
-  hipStream_t stream_heavy = nullptr;  // heavy-bucket kernels beside the accumulations (msm.hpp run_device)
+  hipStream_t stream_heavy = nullptr;  // ZKMI_HEAVY_ON=1 only: heavy-bucket kernels beside the accumulations; created at first use
   hipStream_t stream_sort = nullptr;   // the prover's digit sorts, beside the previous proof's accumulations
   hipStream_t stream_acc3 = nullptr;  // L accumulation of a single small proof (groth16.hip); created at first use
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)

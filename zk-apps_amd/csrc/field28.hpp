@@ -182,6 +182,13 @@ struct Fp28 {
   __device__ __attribute__((noinline)) static Fp28 mul_call(Fp28 a, Fp28 b) { return mul_inline(a, b); }
   __device__ __attribute__((noinline)) static Fp28 sqr_call(Fp28 a) { return a.sqr_inline(); }
   ZK_HD static Fp28 mul_inline(const Fp28& a, const Fp28& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_SETPRIO)
+    // A/B build (make prio): raise the wave's issue priority for the multiply-add run of a product (round-3 experiment)
+    struct Prio {
+      __device__ Prio() { __builtin_amdgcn_s_setprio(2); }
+      __device__ ~Prio() { __builtin_amdgcn_s_setprio(0); }
+    } prio_guard;
+#endif
     int64_t T[2 * NL];
 #pragma unroll
     for (int i = 0; i < 2 * NL; i++) T[i] = 0;
@@ -192,6 +199,12 @@ struct Fp28 {
     return reduce(T);
   }
   ZK_HD Fp28 sqr_inline() const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_SETPRIO)
+    struct Prio {
+      __device__ Prio() { __builtin_amdgcn_s_setprio(2); }
+      __device__ ~Prio() { __builtin_amdgcn_s_setprio(0); }
+    } prio_guard;
+#endif
     int64_t T[2 * NL];
 #pragma unroll
     for (int i = 0; i < 2 * NL; i++) T[i] = 0;

@@ -679,8 +679,10 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   if (rc != ZKMI_OK) return rc;
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
-  // ZKMI_HEAVY_SIDE=0: heavy-bucket kernels back on the accumulation streams (A/B runs)
-  static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
+  // ZKMI_HEAVY_ON=1: heavy-bucket kernels on their own side stream (round 2; created on first use); default: at the head
+  // of each MSM's reduction stream, 0: in line on the accumulation streams (msm_impl.hpp run_device)
+  static const bool heavy_side = getenv("ZKMI_HEAVY_ON") && getenv("ZKMI_HEAVY_ON")[0] == '1';
+  if (heavy_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_heavy, false));
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
   // MSM's reduction runs on the aux stream behind its accumulation and leaves the
@@ -738,7 +740,8 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   hipStream_t st = ctx->stream;
   PhaseTimer* t = ctx->timer();
   const bool sh = pk->shared;
-  static const bool heavy_side = !(getenv("ZKMI_HEAVY_SIDE") && getenv("ZKMI_HEAVY_SIDE")[0] == '0');
+  static const bool heavy_side = getenv("ZKMI_HEAVY_ON") && getenv("ZKMI_HEAVY_ON")[0] == '1';
+  if (heavy_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_heavy, false));
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   const bool sort_side = prover_sort_side();
   if (sort_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_sort, true));
