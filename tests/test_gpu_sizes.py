@@ -275,3 +275,28 @@ def test_bench_gpus_gt_1_spawns_ranks_or_fails():
         assert p.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["verified_by_pairing"] is True, p.stderr[-3000:]
     else:
         assert p.returncode != 0 and not lines, p.stdout[-2000:]
+
+
+VARIANTS = [
+    {},
+    {"ZKMI_NTT_RB": "0"}, {"ZKMI_NTT_RB": "1"}, {"ZKMI_NTT_RB": "2"},
+    {"ZKMI_SORT_FINE": "0"}, {"ZKMI_SORT_FINE": "2"},
+    {"ZKMI_HEAVY_ON": "0"}, {"ZKMI_HEAVY_ON": "1"},
+    {"ZKMI_ACCUM": "0", "ZKMI_ACCUM_G2": "0"}, {"ZKMI_AUX_SPLIT": "0", "ZKMI_SORT_SIDE": "1"},
+]
+
+
+def test_ab_switches_do_not_change_any_result():
+    """Every A/B switch that selects another kernel or schedule (register-blocked NTT passes, fine-partition / record
+    digit sort, where the heavy-bucket kernels run, first-generation accumulation kernels, stream layout) must give the
+    same bytes: scripts/variant_check.py (NTTs of five sizes in four modes, four MSMs, 79 proofs at 2^13 and 2^17) is run
+    in a child process per variant -- the switches are read once per process -- and the digests are compared."""
+    digests = {}
+    for env_extra in VARIANTS:
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "variant_check.py")], capture_output=True, text=True, timeout=900,
+                           cwd=ROOT, env=env)
+        line = [l for l in p.stdout.splitlines() if l.startswith("VARIANT_DIGEST")]
+        assert p.returncode == 0 and line, (env_extra, p.stdout[-1500:], p.stderr[-3000:])
+        digests[str(env_extra)] = line[0].split()[1]
+    assert len(set(digests.values())) == 1, digests
