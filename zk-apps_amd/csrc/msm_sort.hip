@@ -213,12 +213,12 @@ k_bucket_pass_rec(const uint32_t* __restrict__ rec_entry, const uint32_t* __rest
 // The (chunk, 2^15-bucket partition) tiles above scatter 4-byte entries at random into a partition's slice of
 // sorted[]: a bucket's run of ~26 entries receives ~1.6 entries from each of 16 tiles, so nearly every write is a
 // partial line (WRITE_SIZE 8x the payload in the round-2 counters, 97 % of wave cycles waiting).  Here the records
-// are grouped by FINE partition instead (2^11 consecutive buckets, ~53 k records at N = 2^20) and ONE workgroup owns
+// are grouped by FINE partition instead (2^10 consecutive buckets, ~27 k records at N = 2^20) and ONE workgroup owns
 // a fine partition end to end: LDS histogram of its records -> prefix sum -> count[] / begin[] of its buckets ->
-// scatter into its own contiguous slice of sorted[] (212 KB: the runs of a bucket are completed by one workgroup
+// scatter into its own contiguous slice of sorted[] (106 KB, staged in LDS: the runs of a bucket are completed by one workgroup
 // within microseconds, so the lines are written once).  No per-tile histograms in HBM, no separate totals / scan /
 // bases kernels for this mode.
-constexpr int FINE_LOG = 11;                 // buckets per fine partition
+constexpr int FINE_LOG = 10;                 // buckets per fine partition
 constexpr uint32_t FINE_NB = 1u << FINE_LOG;
 constexpr uint32_t FINE_MAX_PARTS = 2048;    // 2^22 buckets (c = 23)
 constexpr uint32_t FPART_BLOCKS = 512;       // blocks of the record pre-pass
@@ -228,9 +228,12 @@ constexpr uint32_t FPART_BLOCKS = 512;       // blocks of the record pre-pass
 template <bool WRITE>
 __global__ void __launch_bounds__(1024)
 k_fpart_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t NP, uint32_t chunk, RecodeConst rc,
-             uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry, uint32_t* __restrict__ rec_bkt) {
+             uint32_t* __restrict__ blkcnt, const uint32_t* __restrict__ fpart, uint32_t* __restrict__ rec_entry,
+             uint32_t* __restrict__ rec_bkt) {
   extern __shared__ uint32_t cnt[];  // NP counters / cursors
-  for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x) cnt[q] = WRITE ? blkcnt[(size_t)blockIdx.x * NP + q] : 0u;
+  // blkcnt is partition-major ([q][block], stride FPART_BLOCKS) so that k_fpart_scan's waves read a partition's row coalesced
+  for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x)
+    cnt[q] = WRITE ? fpart[q] + blkcnt[(size_t)q * FPART_BLOCKS + blockIdx.x] : 0u;
   __syncthreads();
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
@@ -251,63 +254,137 @@ k_fpart_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigit
   }
   if (!WRITE) {
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x) blkcnt[(size_t)blockIdx.x * NP + q] = cnt[q];
+    for (uint32_t q = threadIdx.x; q < NP; q += blockDim.x) blkcnt[(size_t)q * FPART_BLOCKS + blockIdx.x] = cnt[q];
   }
 }
 
-// one workgroup: blkcnt[blk][q] -> first record slot of (blk, q); fpart[q] = first slot of partition q, fpart[NP + q] = its size
+// The write pass of the record pre-pass with an LDS stage (NP <= 512, ndigits <= 16): the direct form above lets every
+// lane store its 4-byte record halves wherever its LDS cursor points -- each 64-byte line of a (block, partition) run is
+// hit by 16 separate stores over the block's lifetime and half of them reach HBM as partial lines (WRITE_SIZE 678 MB for
+// 109 MB of records).  Here a batch of 1024 scalars (<= 16 K records) is ranked per partition in LDS, laid out partition
+// by partition in the stage, and written out by consecutive lanes: a partition's records of the batch leave as one run.
+constexpr uint32_t FPASS_MAXD = 16;                       // digits per scalar the staged pass supports
+constexpr uint32_t FPASS_STAGE = 1024 * FPASS_MAXD;       // records per batch
 __global__ void __launch_bounds__(1024)
-k_fpart_scan(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t NP, uint32_t* __restrict__ fpart) {
-  __shared__ uint32_t tot[FINE_MAX_PARTS];
-  __shared__ uint32_t part[1024];
-  for (uint32_t q = threadIdx.x; q < NP; q += 1024) {
-    uint32_t s = 0;
-    for (uint32_t b = 0; b < nblk; b++) s += blkcnt[(size_t)b * NP + q];
-    tot[q] = s;
+k_fpart_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t NP, uint32_t chunk, RecodeConst rc,
+                     const uint32_t* __restrict__ blkcnt, const uint32_t* __restrict__ fpart, uint32_t* __restrict__ rec_entry,
+                     uint32_t* __restrict__ rec_bkt) {
+  __shared__ uint32_t cursor[512];  // next global record slot of (this block, partition)
+  __shared__ uint32_t bcnt[512];    // records of the batch per partition, then their first stage slot (exclusive prefix)
+  __shared__ uint32_t gbase[512];   // global slot of the batch's first record of the partition
+  __shared__ uint32_t part[512];
+  extern __shared__ uint32_t stg[];  // [FPASS_STAGE] entries, then [FPASS_STAGE] (partition << FINE_LOG | bucket)
+  uint32_t* const s_entry = stg;
+  uint32_t* const s_qb = stg + FPASS_STAGE;
+  const uint32_t tid = threadIdx.x;
+  if (tid < 512) cursor[tid] = tid < NP ? fpart[tid] + blkcnt[(size_t)tid * FPART_BLOCKS + blockIdx.x] : 0u;
+  const uint32_t beg = blockIdx.x * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i0 = beg; i0 < end; i0 += 1024) {
+    if (tid < 512) bcnt[tid] = 0;
+    __syncthreads();
+    const uint32_t i = i0 + tid;
+    uint32_t ent[FPASS_MAXD], qb[FPASS_MAXD], rk[FPASS_MAXD];
+    if (i < end) {
+      uint32_t k[9];
+      load_biased(scalars, i, rc, k);
+#pragma unroll
+      for (int w = 0; w < (int)FPASS_MAXD; w++) {
+        qb[w] = 0xffffffffu;
+        if (w < ndigits) {
+          bool neg;
+          const uint32_t d = digit_of(k, w, c, neg);
+          if (d) {
+            const uint32_t bkt = d - 1;
+            ent[w] = ((uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
+            qb[w] = bkt;  // partition = bkt >> FINE_LOG, bucket = low bits
+            rk[w] = atomicAdd(&bcnt[bkt >> FINE_LOG], 1u);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < (int)FPASS_MAXD; w++) qb[w] = 0xffffffffu;
+    }
+    __syncthreads();
+    // exclusive prefix of bcnt over the partitions (512 threads), batch bases from the block's cursors
+    uint32_t mine = 0;
+    if (tid < 512) {
+      mine = bcnt[tid];
+      part[tid] = mine;
+    }
+    __syncthreads();
+    for (uint32_t off = 1; off < 512; off <<= 1) {
+      uint32_t v = 0;
+      if (tid < 512 && tid >= off) v = part[tid - off];
+      __syncthreads();
+      if (tid < 512) part[tid] += v;
+      __syncthreads();
+    }
+    if (tid < 512) {
+      bcnt[tid] = part[tid] - mine;  // first stage slot of the partition
+      gbase[tid] = cursor[tid];
+      cursor[tid] += mine;
+    }
+    const uint32_t total = part[511];
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < (int)FPASS_MAXD; w++)
+      if (qb[w] != 0xffffffffu) {
+        const uint32_t slot = bcnt[qb[w] >> FINE_LOG] + rk[w];
+        s_entry[slot] = ent[w];
+        s_qb[slot] = qb[w];
+      }
+    __syncthreads();
+    for (uint32_t sl = tid; sl < total; sl += 1024) {
+      const uint32_t v = s_qb[sl];
+      const uint32_t q = v >> FINE_LOG;
+      const uint32_t dst = gbase[q] + (sl - bcnt[q]);
+      rec_entry[dst] = s_entry[sl];
+      rec_bkt[dst] = v & (FINE_NB - 1u);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // exclusive prefix over the NP totals: thread t owns partitions [t * per, (t + 1) * per)
+}
+
+// one WAVE per fine partition: exclusive prefix of its row blkcnt[q][0 .. nblk) in place (the slot of (block, q) relative
+// to the partition's first record) and the row total -> fpart[NP + q]
+__global__ void __launch_bounds__(64)
+k_fpart_scan_rows(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t NP, uint32_t* __restrict__ fpart) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  uint32_t* row = blkcnt + (size_t)q * FPART_BLOCKS;
+  constexpr uint32_t PER = FPART_BLOCKS / 64;
+  uint32_t v[PER], s = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t b = lane * PER + k;
+    v[k] = b < nblk ? row[b] : 0u;
+    s += v[k];
+  }
+  uint32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if ((int)lane >= off) incl += t;
+  }
+  uint32_t run = incl - s;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t b = lane * PER + k;
+    if (b < nblk) row[b] = run;
+    run += v[k];
+  }
+  if (lane == 63) fpart[NP + q] = incl;
+}
+// one workgroup: fpart[q] = first record slot of partition q (exclusive prefix of the totals fpart[NP + q])
+__global__ void __launch_bounds__(1024)
+k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
   const uint32_t per = (NP + 1023u) / 1024u;
   uint32_t s = 0;
-  for (uint32_t q = threadIdx.x * per; q < (threadIdx.x + 1) * per && q < NP; q++) s += tot[q];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-  for (uint32_t q = threadIdx.x * per; q < (threadIdx.x + 1) * per && q < NP; q++) {
-    const uint32_t t = tot[q];
-    fpart[q] = run;
-    fpart[NP + q] = t;
-    uint32_t r2 = run;
-    for (uint32_t b = 0; b < nblk; b++) {
-      const uint32_t v = blkcnt[(size_t)b * NP + q];
-      blkcnt[(size_t)b * NP + q] = r2;
-      r2 += v;
-    }
-    run += t;
-  }
-}
-
-// one workgroup per fine partition: histogram -> scan -> count / begin -> scatter (see above)
-__global__ void __launch_bounds__(1024)
-k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
-             uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t hist[FINE_NB];
-  __shared__ uint32_t part[1024];
-  const uint32_t q = blockIdx.x, tid = threadIdx.x;
-  const uint32_t pbase = fpart[q], ptot = fpart[NP + q];
-  for (uint32_t b = tid; b < FINE_NB; b += 1024) hist[b] = 0;
-  __syncthreads();
-  for (uint32_t r = tid; r < ptot; r += 1024) atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
-  __syncthreads();
-  static_assert(FINE_NB == 2048, "two counters per thread");
-  const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-  part[tid] = c0 + c1;
+  for (uint32_t q = tid * per; q < (tid + 1) * per && q < NP; q++) s += fpart[NP + q];
+  part[tid] = s;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
     const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
@@ -315,18 +392,90 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
     part[tid] += v;
     __syncthreads();
   }
-  const uint32_t ex = pbase + (tid ? part[tid - 1] : 0u);
-  const size_t g = (size_t)q * FINE_NB + 2 * tid;
-  count[g] = c0;
-  count[g + 1] = c1;
-  begin[g] = ex;
-  begin[g + 1] = ex + c0;
-  hist[2 * tid] = ex;  // cursors
-  hist[2 * tid + 1] = ex + c0;
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  for (uint32_t q = tid * per; q < (tid + 1) * per && q < NP; q++) {
+    fpart[q] = run;
+    run += fpart[NP + q];
+  }
+}
+
+// one workgroup per fine partition: histogram -> scan -> count / begin -> scatter (see above).
+// The scatter is STAGED in LDS: cursors hand out final positions, the entry goes to stage[position - round base] and the
+// stage is flushed to sorted[] as whole lines, so the 4-byte entries of a bucket's run no longer reach HBM one partial
+// line at a time (WRITE_SIZE 6.5x the payload for the direct scatter).  A partition bigger than the stage (the fine
+// partitions that also receive the partial top digit hold ~3.6x the mean; witness-like scalars can put 20 % of all
+// entries into one bucket) is flushed in rounds of FINE_ROUND positions: bucket b belongs to the round its first
+// position falls into, a run that overshoots the stage's slack is written directly.
+constexpr uint32_t FINE_STAGE = 36000;   // entries the LDS stage holds (144 000 B)
+constexpr uint32_t FINE_ROUND = 32768;   // positions per round; FINE_STAGE - FINE_ROUND = slack for a straddling run
+__global__ void __launch_bounds__(1024)
+k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
+             uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged) {
+  static_assert(FINE_NB == 1024, "one counter per thread");
+  __shared__ uint32_t hist[FINE_NB];  // counts, then cursors (positions relative to the partition)
+  __shared__ uint32_t beg[FINE_NB];   // first position of the bucket, relative to the partition
+  __shared__ uint32_t part[1024];
+  extern __shared__ uint32_t stage[];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t pbase = fpart[q], ptot = fpart[NP + q];
+  hist[tid] = 0;
   __syncthreads();
-  for (uint32_t r = tid; r < ptot; r += 1024) {
-    const uint32_t pos = atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
-    sorted[pos] = rec_entry[pbase + r];
+  for (uint32_t r = tid; r < ptot; r += 1024) atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
+  __syncthreads();
+  const uint32_t c0 = hist[tid];
+  part[tid] = c0;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t ex = tid ? part[tid - 1] : 0u;
+  const size_t g = (size_t)q * FINE_NB + tid;
+  count[g] = c0;
+  begin[g] = pbase + ex;
+  beg[tid] = ex;
+  hist[tid] = ex;  // cursor
+  __syncthreads();
+  if (!staged) {
+    for (uint32_t r = tid; r < ptot; r += 1024) {
+      const uint32_t pos = atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
+      sorted[pbase + pos] = rec_entry[pbase + r];
+    }
+    return;
+  }
+  const uint32_t rounds = (ptot + FINE_ROUND - 1) / FINE_ROUND;
+  uint32_t start = 0;  // first position this round owns = end of the previous round's last run (>= lo)
+  for (uint32_t rd = 0; rd < rounds; rd++) {
+    const uint32_t lo = rd * FINE_ROUND;
+    for (uint32_t r = tid; r < ptot; r += 1024) {
+      const uint32_t b = rec_bkt[pbase + r];
+      if (rounds > 1 && beg[b] / FINE_ROUND != rd) continue;
+      const uint32_t pos = atomicAdd(&hist[b], 1u);
+      const uint32_t e = rec_entry[pbase + r];
+      if (pos - lo < FINE_STAGE) stage[pos - lo] = e;
+      else sorted[pbase + pos] = e;  // a run longer than the slack: the rest goes out directly
+    }
+    __syncthreads();
+    // positions [lo, hi) were staged: hi = end of the last bucket of this round, capped by the stage
+    uint32_t hi = ptot;
+    if (rd + 1 < rounds) {
+      // first bucket of a later round = first b with beg[b] >= (rd + 1) * FINE_ROUND; its beg is the end of this round
+      // (found by every thread from the monotone beg[] with a binary search: 10 steps)
+      uint32_t l = 0, h = FINE_NB;
+      while (l < h) {
+        const uint32_t m = (l + h) >> 1;
+        if (beg[m] >= (rd + 1) * FINE_ROUND) h = m;
+        else l = m + 1;
+      }
+      hi = (l < FINE_NB) ? beg[l] : ptot;
+    }
+    uint32_t top = hi - lo;
+    if (top > FINE_STAGE) top = FINE_STAGE;
+    for (uint32_t k = start - lo + tid; k < top; k += 1024) sorted[pbase + lo + k] = stage[k];
+    start = hi;
+    __syncthreads();
   }
 }
 
@@ -734,7 +883,14 @@ hipError_t msm_sort_enable_big_lds() {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
-  return hipSuccess;
+  // the staged kernels keep static LDS beside their stage: ask for exactly the stage
+  {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_write_staged), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(uint32_t) * 2 * FPASS_STAGE));
+    if (e != hipSuccess) return e;
+  }
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)(sizeof(uint32_t) * FINE_STAGE));
 }
 
 hipError_t MsmSort::wait_readers(hipStream_t st) {
@@ -830,17 +986,24 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   // against 27 ms), so bigger plans keep the record sort.  ZKMI_SORT_FINE=0 / =2: never / whenever it is applicable.
   static const int fine_mode = getenv("ZKMI_SORT_FINE") ? atoi(getenv("ZKMI_SORT_FINE")) : 1;
   const uint32_t NP = tot_b >> FINE_LOG;
-  if (records && fine_mode != 0 && NP <= (fine_mode == 2 ? FINE_MAX_PARTS : 256u) && fpart != nullptr) {
+  if (records && fine_mode != 0 && NP <= (fine_mode == 2 ? FINE_MAX_PARTS : 512u) && fpart != nullptr) {
     uint32_t nblk = (uint32_t)((n + 4095) / 4096);
     if (nblk > FPART_BLOCKS) nblk = FPART_BLOCKS;
     const uint32_t chunk_a = (uint32_t)((n + nblk - 1) / nblk);
     const size_t lds_np = sizeof(uint32_t) * NP;
     hipLaunchKernelGGL(k_fpart_pass<false>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
-                       rc, blkcnt, rec_entry, rec_bkt);
-    hipLaunchKernelGGL(k_fpart_scan, dim3(1), dim3(1024), 0, st, blkcnt, nblk, NP, fpart);
-    hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
-                       rc, blkcnt, rec_entry, rec_bkt);
-    hipLaunchKernelGGL(k_fpart_sort, dim3(NP), dim3(1024), 0, st, rec_entry, rec_bkt, fpart, NP, count, begin, sorted);
+                       rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_fpart_scan_rows, dim3(NP), dim3(64), 0, st, blkcnt, nblk, NP, fpart);
+    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart);
+    static const bool stage_on = !(getenv("ZKMI_SORT_STAGE") && getenv("ZKMI_SORT_STAGE")[0] == '0');
+    if (stage_on && NP <= 512 && plan.ndigits <= (int)FPASS_MAXD)
+      hipLaunchKernelGGL(k_fpart_write_staged, dim3(nblk), dim3(1024), sizeof(uint32_t) * 2 * FPASS_STAGE, st, d_scalars, (uint32_t)n, plan.c,
+                         plan.ndigits, NP, chunk_a, rc, (const uint32_t*)blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+    else
+      hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
+                         rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+    hipLaunchKernelGGL(k_fpart_sort, dim3(NP), dim3(1024), stage_on ? sizeof(uint32_t) * FINE_STAGE : 0, st, rec_entry, rec_bkt, fpart, NP,
+                       count, begin, sorted, stage_on ? 1 : 0);
     hipError_t e1 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e1 != hipSuccess) return e1;
     if (prof) prof->end(PH_MSM_SORT, st);
