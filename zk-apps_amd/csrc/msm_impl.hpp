@@ -384,11 +384,14 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
 }
 
 // the listed buckets again, with the complete addition (rare: repeated bases with equal digits)
+// The kernel also CLEARS the list for the slot's next MSM: every workgroup reads the length first, and the last one to
+// finish (a ticket word behind the list) resets length and ticket -- no hipMemsetAsync launch in front of an accumulation
+// (a kernel of its own that waited up to 0.8 ms for a slot on a full chip).  The buffer is zeroed once when it is allocated.
 template <class F>
 __global__ void __launch_bounds__(64)
 k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
              const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
-             XYZZ<F>* __restrict__ buckets, const uint32_t* __restrict__ redo) {
+             XYZZ<F>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket) {
   const uint32_t n = redo[0];
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t b = redo[1 + k];
@@ -401,6 +404,12 @@ k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ b
       acc.madd(p);
     }
     store_vec(buckets + b, acc);
+  }
+  // every workgroup has read the length by now; the last one to get here clears the list for the slot's next MSM
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    redo[0] = 0;
+    *ticket = 0;
   }
 }
 
@@ -659,7 +668,8 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * nslots)) != hipSuccess) return e;  // per slot
-  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 1) * nslots)) != hipSuccess) return e;  // one list per slot
+  if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // one list per slot
+  if ((e = hipMemset(redo, 0, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // lengths and tickets start at zero
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
     hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
@@ -718,7 +728,7 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   }();
   const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
   const bool nocall = mode == 2 || mode == 3;
-  uint32_t* const redo = this->redo + (size_t)slot * (cap_buckets + 1);  // the reduce stream reads it later
+  uint32_t* const redo = this->redo + (size_t)slot * (cap_buckets + 2);  // [0] length, [1 ..] list, [cap_buckets + 1] ticket (k_accum_redo)
   // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
   // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
   static const int accum_block = [] {
@@ -734,7 +744,6 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     if (accum_rounds > 1) blocks = (blocks + accum_rounds - 1) / accum_rounds;
     return blocks ? blocks : 1u;
   };
-  if (nocall && (e = hipMemsetAsync(redo, 0, sizeof(uint32_t), st)) != hipSuccess) return e;
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     const dim3 grid((2 * tot_b + T - 1) / T);
@@ -791,7 +800,8 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
     // heavy buckets are never listed, so the heavy kernels may still be running
     using RF = typename std::conditional<std::is_same<F, Fq2_28>::value, Fq2_28, F>::type;
-    hipLaunchKernelGGL(k_accum_redo<RF>, dim3(64), dim3(64), 0, st_reduce, d_bases, sort.begin, sort.count, sort.sorted, bk, redo);
+    hipLaunchKernelGGL(k_accum_redo<RF>, dim3(64), dim3(64), 0, st_reduce, d_bases, sort.begin, sort.count, sort.sorted, bk, redo,
+                       redo + cap_buckets + 1);
     // the list reads the sort: the next sort must wait for this kernel too
     if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;
     sort.readers.push_back(redo_done[slot]);

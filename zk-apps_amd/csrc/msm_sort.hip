@@ -568,26 +568,38 @@ __device__ __forceinline__ uint32_t order_key(uint32_t cnt, uint32_t thr, int sh
   // 0 = heaviest light bucket ... MSM_HEAVY = empty; heavy buckets sort last (key MSM_HEAVY + 1)
   return cnt > thr ? MSM_HEAVY + 1 : MSM_HEAVY - (cnt >> shift);
 }
+// (No memset launches in this chain: a 4-byte hipMemsetAsync is a kernel of its own, and on a chip kept full by another
+// stream's accumulation it waited 0.07 - 0.8 ms for a slot, ten times per proof.  Every block writes its own row of bins,
+// the scan kernel sums the rows and also clears the heavy-bucket counter.)
+constexpr uint32_t ORDER_MAX_BLOCKS = 256;
 __global__ void __launch_bounds__(1024)
-k_order_hist(const uint32_t* __restrict__ count, uint32_t* __restrict__ gbins, uint32_t total, uint32_t thr, int shift) {
+k_order_hist(const uint32_t* __restrict__ count, uint32_t* __restrict__ blockbins, uint32_t total, uint32_t thr, int shift) {
   __shared__ uint32_t bins[ORDER_BINS];
   for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024) bins[i] = 0;
   __syncthreads();
   for (uint32_t b = blockIdx.x * 1024 + threadIdx.x; b < total; b += gridDim.x * 1024) atomicAdd(&bins[order_key(count[b], thr, shift)], 1u);
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024)
-    if (bins[i]) atomicAdd(&gbins[i], bins[i]);
+  for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += 1024) blockbins[(size_t)(1 + blockIdx.x) * ORDER_BINS + i] = bins[i];
 }
-__global__ void __launch_bounds__(64)
-k_order_scan(uint32_t* __restrict__ gbins) {
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t i = 0; i < ORDER_BINS; i++) {
-      const uint32_t v = gbins[i];
-      gbins[i] = run;
-      run += v;
-    }
+// one workgroup: gbins[i] (row 0) = exclusive prefix over the keys of the per-block rows' sums; *n_heavy = 0
+__global__ void __launch_bounds__(512)
+k_order_scan(uint32_t* __restrict__ blockbins, uint32_t nblocks, uint32_t* __restrict__ n_heavy) {
+  static_assert(ORDER_BINS <= 512, "one key per thread");
+  __shared__ uint32_t part[512];
+  const uint32_t i = threadIdx.x;
+  uint32_t v = 0;
+  if (i < ORDER_BINS)
+    for (uint32_t b = 0; b < nblocks; b++) v += blockbins[(size_t)(1 + b) * ORDER_BINS + i];
+  part[i] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < 512; off <<= 1) {
+    const uint32_t t = (i >= off) ? part[i - off] : 0u;
+    __syncthreads();
+    part[i] += t;
+    __syncthreads();
   }
+  if (i < ORDER_BINS) blockbins[i] = part[i] - v;
+  if (i == 0) *n_heavy = 0;
 }
 __global__ void __launch_bounds__(1024)
 k_order_scatter(const uint32_t* __restrict__ count, uint32_t* __restrict__ gbins, uint32_t* __restrict__ perm,
@@ -616,14 +628,11 @@ k_order_scatter(const uint32_t* __restrict__ count, uint32_t* __restrict__ gbins
 // records the launches of the three ordering kernels on `st`
 static hipError_t bucket_order(const uint32_t* count, uint32_t* perm, uint32_t* heavy, uint32_t* order_bins, uint32_t total,
                                uint32_t thr, int shift, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(heavy, 0, sizeof(uint32_t), st);
-  if (e != hipSuccess) return e;
-  if ((e = hipMemsetAsync(order_bins, 0, sizeof(uint32_t) * ORDER_BINS, st)) != hipSuccess) return e;
   uint32_t blocks = (total + 16383) / 16384;
-  if (blocks > 256) blocks = 256;
+  if (blocks > ORDER_MAX_BLOCKS) blocks = ORDER_MAX_BLOCKS;
   if (!blocks) blocks = 1;
   hipLaunchKernelGGL(k_order_hist, dim3(blocks), dim3(1024), 0, st, count, order_bins, total, thr, shift);
-  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, order_bins);
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(512), 0, st, order_bins, blocks, heavy);
   hipLaunchKernelGGL(k_order_scatter, dim3(blocks), dim3(1024), 0, st, count, order_bins, perm, heavy + 1, heavy, total, thr, shift);
   return hipGetLastError();
 }
@@ -853,7 +862,7 @@ hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
-  if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2))) != hipSuccess) return e;
+  if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2) * (256 + 1))) != hipSuccess) return e;  // row 0: offsets, rows 1..: per-block key counts
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * FPART_BLOCKS * FINE_MAX_PARTS)) != hipSuccess) return e;  // also 256 x 64 of the coarse form
   if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 2 * FINE_MAX_PARTS)) != hipSuccess) return e;
   if (shared) {
