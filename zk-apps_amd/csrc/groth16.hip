@@ -47,11 +47,25 @@ __device__ __forceinline__ void stv(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
-// out[i] = <M_i, z> for i < nc; rows [nc, nc+n_pub) = z_j if is_a else 0; rest 0
+// the three constraint matrices of a relation (CSR, limb-form values), handed to k_matvec by value
+struct MatSet {
+  const uint32_t* rowptr[3];
+  const uint32_t* col[3];
+  const Fr28* val[3];
+};
+// out[m][i] = <M_i, z> for i < nc; rows [nc, nc+n_pub) = z_j for m = A (0), else 0; rest 0.
+// blockIdx.z = matrix (A, B, C in ONE launch: the three mat-vecs, like the three transforms after them, are queued as
+// one grid each -- every extra launch on the front stream is one more hand-over between it and the accumulations,
+// DESIGN.md 4.10); the outputs of the three matrices lie back to back (stride = proofs x n)
 __global__ void __launch_bounds__(256)
-k_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr28* __restrict__ val,
-         const Fr28* __restrict__ z, Fr28* __restrict__ out, uint32_t nc, uint32_t n, uint32_t n_pub, int is_a,
+k_matvec(MatSet ms, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uint32_t nc, uint32_t n, uint32_t n_pub,
          uint32_t n_vars) {
+  const int m = blockIdx.z;
+  const uint32_t* __restrict__ rowptr = ms.rowptr[m];
+  const uint32_t* __restrict__ col = ms.col[m];
+  const Fr28* __restrict__ val = ms.val[m];
+  const int is_a = m == 0;
+  Fr28* __restrict__ out = out_base + (size_t)m * gridDim.y * n;
   // blockIdx.y = proof of a group: assignments of n_vars elements and outputs of n elements back to back
   z += (size_t)blockIdx.y * n_vars;
   out += (size_t)blockIdx.y * n;
@@ -192,7 +206,7 @@ struct zkmi_pk {
   // A/B/L MSMs) and h coefficients in canonical words, bit-reversed order (digit source of the H MSM)
   Fr* d_z[zkmi_ctx::PROOF_RING] = {};
   uint32_t* d_h[zkmi_ctx::PROOF_RING] = {};
-  Fr28 *d_zm = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;  // limb form (field28.hpp), front stream only
+  Fr28 *d_zm = nullptr, *d_a = nullptr;  // limb form (field28.hpp), front stream only; d_a holds a, b, c of a group back to back
   uint32_t* d_unsat = nullptr;  // per proof in flight: set by k_check_sat
   uint32_t* h_unsat = nullptr;  // pinned host copy, valid once the proof's H MSM has landed
   ~zkmi_pk() {
@@ -203,7 +217,7 @@ struct zkmi_pk {
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
-    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_zm, d_a, d_b, d_c, a28, b1_28, h28, h28_rev, l28, b2_28,
+    void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_zm, d_a, a28, b1_28, h28, h28_rev, l28, b2_28,
                     a_tab, b1_tab, l_tab, h_tab, b2_tab, d_z[0], d_z[1], d_z[2], d_h[0], d_h[1], d_h[2]};
     static_assert(zkmi_ctx::PROOF_RING == 3, "ring size");
     for (void* p : ptrs)
@@ -270,9 +284,10 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
     if ((e = hipMalloc(&pk->d_h[i], 32ull * N * G)) != hipSuccess) return e;
   }
   if ((e = hipMalloc(&pk->d_zm, sizeof(Fr28) * r->n_vars * G)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * N * G)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_b, sizeof(Fr28) * N * G)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_c, sizeof(Fr28) * N * G)) != hipSuccess) return e;
+  // a, b, c back to back in ONE buffer: the three inverse and the three forward transforms of the witness map run as
+  // one batched launch per pass (3 x G vectors)
+  // (a group of g <= G proofs uses the first 3 g N elements: a[0..g), b[0..g), c[0..g))
+  if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * 3 * N * G)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->d_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t))) != hipSuccess) return e;
   if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
@@ -613,11 +628,16 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 255) / 256), dim3(256), 0, st,
                      reinterpret_cast<const uint32_t*>(pk->d_z[par]), G * nv, pk->d_unsat + par);
   ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, G * nv, st));
-  Fr28* outv[3] = {pk->d_a, pk->d_b, pk->d_c};
-  for (int m = 0; m < 3; m++)
-    hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256, G), dim3(256), 0, st, pk->d_rowptr[m], pk->d_col[m], pk->d_val[m],
-                       pk->d_zm, outv[m], pk->nc, N, pk->n_pub, m == 0 ? 1 : 0, nv);
-  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256, G), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, pk->d_zm, pk->nc,
+  MatSet ms;
+  for (int m = 0; m < 3; m++) {
+    ms.rowptr[m] = pk->d_rowptr[m];
+    ms.col[m] = pk->d_col[m];
+    ms.val[m] = pk->d_val[m];
+  }
+  hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256, G, 3), dim3(256), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
+  Fr28* const d_b = pk->d_a + (size_t)N * G;  // the layout follows the size of THIS group, not the key's maximum
+  Fr28* const d_c = pk->d_a + 2 * (size_t)N * G;
+  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256, G), dim3(256), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
                      pk->d_unsat + par, N, nv);
   ZK_HIP(ctx, hipMemcpyAsync(pk->h_unsat + par, pk->d_unsat + par, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   if (t) t->end(PH_WITNESS, st);
@@ -626,16 +646,23 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   if (!dom) return ctx->hip_fail(e, "ntt domain");
   if (t) t->begin(PH_NTT, st);
   // evaluations -> coefficients (bit-reversed, scaled by g^i / N) -> evaluations on the coset
-  for (int m = 0; m < 3; m++) {
-    ZK_HIP(ctx, dom->inverse_to_rev(outv[m], dom->rev_coset_n, nullptr, st, G));
-    ZK_HIP(ctx, dom->forward_from_rev(outv[m], st, G));
+  // a, b, c together: two batched passes down, two up (3 x G vectors per launch instead of six launch pairs)
+  static const bool batch_abc = !(getenv("ZKMI_WITNESS_BATCH") && getenv("ZKMI_WITNESS_BATCH")[0] == '0');  // A/B: one transform per launch
+  if (batch_abc) {
+    ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_n, nullptr, st, 3 * G));
+    ZK_HIP(ctx, dom->forward_from_rev(pk->d_a, st, 3 * G));
+  } else {
+    for (int m = 0; m < 3; m++) {
+      ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a + (size_t)m * N * G, dom->rev_coset_n, nullptr, st, G));
+      ZK_HIP(ctx, dom->forward_from_rev(pk->d_a + (size_t)m * N * G, st, G));
+    }
   }
   // 1 / Z(g) with Z(g) = g^N - 1, g = 7
   Fr gn = fr_from_u64(7);
   for (uint32_t i = 0; i < pk->log_n; i++) gn = gn.sqr();
   const Fr zinv = (gn - Fr::one()).inv().from_mont();
   const Fr28 zinv28 = Fr28::from_canonical(zinv.l);
-  hipLaunchKernelGGL(k_quotient, dim3((G * N + 255) / 256), dim3(256), 0, st, pk->d_a, pk->d_b, pk->d_c, zinv28, G * N);
+  hipLaunchKernelGGL(k_quotient, dim3((G * N + 255) / 256), dim3(256), 0, st, pk->d_a, d_b, d_c, zinv28, G * N);
   // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
   ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h[par], st, G));
   if (t) t->end(PH_NTT, st);

@@ -187,16 +187,21 @@ struct RbLds {
   }
 };
 
-template <class F, bool DIF, bool LOCAL_TW, int LOGE>
-__global__ void __launch_bounds__(2048 >> LOGE)
+// LOGR > 0: a thread owns 2^LOGR units of E elements per round and works through them one after the other -- the
+// one-wave form (LOGE = 2, LOGR = 2 on a 1024-element tile: 64 threads, <= 160 VGPRs, 63 KB of LDS) is the only NTT
+// workgroup that finds a place beside the bucket accumulations.
+template <class F, bool DIF, bool LOCAL_TW, int LOGE, int LOGR = 0>
+__global__ void __launch_bounds__(LOGR ? 64 : (2048 >> LOGE))
 k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
               const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
   constexpr int E = 1 << LOGE;
+  constexpr int REP = 1 << LOGR;
   data += (size_t)blockIdx.y << log_n;
   if (canon_out) canon_out += ((size_t)blockIdx.y << log_n) * 8;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t tile_n = 1u << (S + Q);
-  const uint32_t nthr = tile_n >> LOGE;  // == blockDim.x
+  const uint32_t nthr = tile_n >> (LOGE + LOGR);  // == blockDim.x
+  const uint32_t nunit = tile_n >> LOGE;        // units of E elements per round
   RbLds<F> tile{reinterpret_cast<uint32_t*>(lds_raw), tile_n + (tile_n >> 5)};
   RbLds<F> ctw{tile.w + (size_t)F::NL * tile.pitch, (1u << (S - 1)) + ((1u << (S - 1)) >> 5) + 1u};
   const uint32_t blk = blockIdx.x, tid = threadIdx.x;
@@ -220,7 +225,7 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
   if (LOCAL_TW)
     for (uint32_t k = tid; k < (1u << (S - 1)); k += nthr) ctw.st(k, ld28(tw + ((size_t)k << (log_n - S))));
 #pragma unroll
-  for (int m = 0; m < E; m++) {
+  for (int m = 0; m < E * REP; m++) {
     const uint32_t L = tid + (uint32_t)m * nthr;
     F v = ld28(data + gindex(L));
     if (LOCAL_TW && !DIF && t0 > 0) v = v * twist(L);
@@ -232,12 +237,13 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
   auto round = [&](auto kc, int u0) __attribute__((always_inline)) {
     constexpr int K = decltype(kc)::value;
     const uint32_t sh = (uint32_t)u0 + qeff;
+    for (uint32_t unit = tid; unit < nunit; unit += nthr) {
     F x[E];
     uint32_t Lm[E];
     static_for<E>([&](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value;
       constexpr uint32_t j = (uint32_t)m & ((1u << K) - 1u), g = (uint32_t)m >> K;
-      const uint32_t G = (tid << (LOGE - K)) | g;
+      const uint32_t G = (unit << (LOGE - K)) | g;
       Lm[m] = ((G >> sh) << (sh + K)) | (G & ((1u << sh) - 1u)) | (j << sh);
       x[m] = tile.ld(Lm[m]);
     });
@@ -275,6 +281,7 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
       constexpr int m = decltype(mc)::value;
       tile.st(Lm[m], x[m]);
     });
+    }  // units of this thread (disjoint element sets: no barrier between them)
     __syncthreads();
   };
   {
@@ -291,7 +298,7 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
   }
 
 #pragma unroll
-  for (int m = 0; m < E; m++) {
+  for (int m = 0; m < E * REP; m++) {
     const uint32_t L = tid + (uint32_t)m * nthr;
     const uint32_t g = gindex(L);
     F v = tile.ld(L);
@@ -459,13 +466,13 @@ static int ntt_rb_mode() {
   return v;
 }
 
-template <class F, bool DIF, bool LTW, int LOGE>
+template <class F, bool DIF, bool LTW, int LOGE, int LOGR = 0>
 static void launch_rb(dim3 grid, uint32_t tile_n, int S, hipStream_t stream, F* buf, const F* tw, int log_n, int t0, int Q,
                       const F* post, uint32_t* canon_out) {
   const size_t words = (size_t)F::NL * (tile_n + (tile_n >> 5)) +
                        (LTW ? (size_t)F::NL * ((1u << (S - 1)) + ((1u << (S - 1)) >> 5) + 1u) : 0u);
-  hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE>), grid, dim3(tile_n >> LOGE), words * sizeof(uint32_t), stream, buf, tw, log_n,
-                     t0, S, Q, post, canon_out);
+  hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE, LOGR>), grid, dim3(tile_n >> (LOGE + LOGR)), words * sizeof(uint32_t), stream, buf,
+                     tw, log_n, t0, S, Q, post, canon_out);
 }
 
 template <class F, bool DIF>
@@ -473,7 +480,8 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
                              hipStream_t stream, uint32_t batch = 1) {
   const uint32_t n = 1u << log_n;
   const int mode = ntt_rb_mode();
-  const int rb = (mode == 1 || mode == 2) ? mode : 0;
+  const int rb = (mode == 1 || mode == 2 || mode == 4) ? mode : 0;
+  const int tile_log = mode == 4 ? 10 : 11;  // mode 4: 1024-element tiles in one-wave workgroups
   struct Pass {
     int t0, S, Q;
   } passes[4];
@@ -485,7 +493,7 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     if (rb) {
       // tiles of 2^11 elements wherever the transform has them: a strided pass takes 2^Q adjacent columns (2^Q x 40 B
       // contiguous per access), the contiguous pass 2^Q whole sub-transforms
-      Q = 11 - S;
+      Q = tile_log - S;
       const int room = (t0 > 0) ? t0 : (log_n - S);
       if (Q > room) Q = room;
     } else {
@@ -507,7 +515,12 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     const F* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
     const dim3 grid(nblk, batch);
-    if (rb && tile_n >= 512) {
+    if (rb == 4 && tile_n == 1024) {
+      if (local_tw) launch_rb<F, DIF, true, 2, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+      else launch_rb<F, DIF, false, 2, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
+      continue;
+    }
+    if (rb && rb != 4 && tile_n >= 512) {
       if (rb == 2) {
         if (local_tw) launch_rb<F, DIF, true, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
         else launch_rb<F, DIF, false, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
@@ -580,7 +593,7 @@ hipError_t NttDomainT<F>::transform(F* d_data, bool inverse, bool coset, hipStre
 template <class F>
 hipError_t ntt_from_canonical(const uint32_t* d_in, F* d_out, uint32_t n, hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_from_canonical<F>, dim3((n + 255) / 256), dim3(256), 0, s, d_in, d_out, n);
+  hipLaunchKernelGGL(k_from_canonical<F>, dim3((n + 63) / 64), dim3(64), 0, s, d_in, d_out, n);  // one-wave workgroups
   return hipGetLastError();
 }
 template <class F>
@@ -601,7 +614,9 @@ static hipError_t rb_enable_big_lds() {
   const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 3>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 3>),
                        reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 3>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 3>),
                        reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 2>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 2>),
-                       reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 2>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 2>)};
+                       reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 2>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 2>),
+                       reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, true, 2, 2>)),  reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, true, 2, 2>)),
+                       reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, false, 2, 2>)), reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, false, 2, 2>))};
   for (const void* f : fns) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
