@@ -625,7 +625,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   if (st != ctx->stream) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z[par], 0));
   if (t) t->begin(PH_WITNESS, st);
   ZK_HIP(ctx, hipMemsetAsync(pk->d_unsat + par, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 63) / 64), dim3(64), 0, st,
                      reinterpret_cast<const uint32_t*>(pk->d_z[par]), G * nv, pk->d_unsat + par);
   ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, G * nv, st));
   MatSet ms;
@@ -634,10 +634,10 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     ms.col[m] = pk->d_col[m];
     ms.val[m] = pk->d_val[m];
   }
-  hipLaunchKernelGGL(k_matvec, dim3((N + 255) / 256, G, 3), dim3(256), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
+  hipLaunchKernelGGL(k_matvec, dim3((N + 63) / 64, G, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
   Fr28* const d_b = pk->d_a + (size_t)N * G;  // the layout follows the size of THIS group, not the key's maximum
   Fr28* const d_c = pk->d_a + 2 * (size_t)N * G;
-  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 256) / 256, G), dim3(256), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
+  hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 64) / 64, G), dim3(64), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
                      pk->d_unsat + par, N, nv);
   ZK_HIP(ctx, hipMemcpyAsync(pk->h_unsat + par, pk->d_unsat + par, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   if (t) t->end(PH_WITNESS, st);
@@ -662,7 +662,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   for (uint32_t i = 0; i < pk->log_n; i++) gn = gn.sqr();
   const Fr zinv = (gn - Fr::one()).inv().from_mont();
   const Fr28 zinv28 = Fr28::from_canonical(zinv.l);
-  hipLaunchKernelGGL(k_quotient, dim3((G * N + 255) / 256), dim3(256), 0, st, pk->d_a, d_b, d_c, zinv28, G * N);
+  hipLaunchKernelGGL(k_quotient, dim3((G * N + 63) / 64), dim3(64), 0, st, pk->d_a, d_b, d_c, zinv28, G * N);
   // h coefficients = coset iNTT, left in bit-reversed order as canonical words (H MSM digits)
   ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_inv_n, pk->d_h[par], st, G));
   if (t) t->end(PH_NTT, st);

@@ -86,7 +86,8 @@ k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, in
   auto twist = [&](uint32_t L) -> F {
     const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
     const uint32_t col = (mid << Q) | c;
-    const uint32_t ex = col * (__brev(e) >> (32 - S));
+    // (root of order 2^(t0+S): the shift is zero for the last pass of a plan, non-zero for the middle pass of three)
+    const uint32_t ex = (col * (__brev(e) >> (32 - S))) << (log_n - t0 - S);
     const uint32_t halfn = 1u << (log_n - 1);
     F f = ld28(tw + (ex & (halfn - 1u)));
     return (ex & halfn) ? f.neg() : f;
@@ -190,8 +191,11 @@ struct RbLds {
 // LOGR > 0: a thread owns 2^LOGR units of E elements per round and works through them one after the other -- the
 // one-wave form (LOGE = 2, LOGR = 2 on a 1024-element tile: 64 threads, <= 160 VGPRs, 63 KB of LDS) is the only NTT
 // workgroup that finds a place beside the bucket accumulations.
-template <class F, bool DIF, bool LOCAL_TW, int LOGE, int LOGR = 0>
-__global__ void __launch_bounds__(LOGR ? 64 : (2048 >> LOGE))
+// ONEW (LOGE = 2, LOGR = 1 on a 512-element tile): the whole workgroup is one wave of <= 170 VGPRs with 24 KB of LDS -- up
+// to three of them fit a CU beside twelve accumulation waves (mode 5 below: three passes of <= 7 stages at N = 2^20).
+// (Eight elements per thread would halve the LDS round trips again but needs 247 VGPRs: 75 of them spill at 168.)
+template <class F, bool DIF, bool LOCAL_TW, int LOGE, int LOGR = 0, bool ONEW = false>
+__global__ void __launch_bounds__((LOGR || ONEW) ? 64 : (2048 >> LOGE), ONEW ? 3 : 1)
 k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, int S, int Q,
               const F* __restrict__ post, uint32_t* __restrict__ canon_out) {
   constexpr int E = 1 << LOGE;
@@ -217,7 +221,9 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
   auto twist = [&](uint32_t L) -> F {
     const uint32_t e = L >> Q, c = L & ((1u << Q) - 1u);
     const uint32_t col = (mid << Q) | c;
-    const uint32_t ex = col * (__brev(e) >> (32 - S));
+    // stages [0, t0 + S) are independent 2^(t0+S)-point transforms: the cross terms are powers of the root of THAT order,
+    // w_N^(2^(log_n - t0 - S)) -- the shift is zero for the last pass of a plan, non-zero for a middle pass
+    const uint32_t ex = (col * (__brev(e) >> (32 - S))) << (log_n - t0 - S);
     const uint32_t halfn = 1u << (log_n - 1);
     F f = ld28(tw + (ex & (halfn - 1u)));
     return (ex & halfn) ? f.neg() : f;
@@ -466,29 +472,37 @@ static int ntt_rb_mode() {
   return v;
 }
 
-template <class F, bool DIF, bool LTW, int LOGE, int LOGR = 0>
+template <class F, bool DIF, bool LTW, int LOGE, int LOGR = 0, bool ONEW = false>
 static void launch_rb(dim3 grid, uint32_t tile_n, int S, hipStream_t stream, F* buf, const F* tw, int log_n, int t0, int Q,
                       const F* post, uint32_t* canon_out) {
   const size_t words = (size_t)F::NL * (tile_n + (tile_n >> 5)) +
                        (LTW ? (size_t)F::NL * ((1u << (S - 1)) + ((1u << (S - 1)) >> 5) + 1u) : 0u);
-  hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE, LOGR>), grid, dim3(tile_n >> (LOGE + LOGR)), words * sizeof(uint32_t), stream, buf,
-                     tw, log_n, t0, S, Q, post, canon_out);
+  hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE, LOGR, ONEW>), grid, dim3(tile_n >> (LOGE + LOGR)), words * sizeof(uint32_t), stream,
+                     buf, tw, log_n, t0, S, Q, post, canon_out);
 }
 
 template <class F, bool DIF>
 static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
                              hipStream_t stream, uint32_t batch = 1) {
   const uint32_t n = 1u << log_n;
-  const int mode = ntt_rb_mode();
-  const int rb = (mode == 1 || mode == 2 || mode == 4) ? mode : 0;
-  const int tile_log = mode == 4 ? 10 : 11;  // mode 4: 1024-element tiles in one-wave workgroups
+  int mode = ntt_rb_mode();
+  if (mode == 5 && log_n < 9) mode = 3;  // mode 5 needs 512-element tiles
+  const int rb = (mode == 1 || mode == 2 || mode == 4 || mode == 5) ? mode : 0;
+  const int tile_log = mode == 5 ? 9 : mode == 4 ? 10 : 11;  // modes 4 / 5: 1024- / 512-element tiles in one-wave workgroups
   struct Pass {
     int t0, S, Q;
   } passes[4];
   int np = 0;
+  // mode 5: passes of <= 9 stages, split evenly (N = 2^20: 7 + 7 + 6), every pass with the local-twiddle + twist scheme
+  const int max_s = mode == 5 ? 9 : 10;
+  const int want_np = (log_n + max_s - 1) / max_s;
   for (int t0 = 0; t0 < log_n;) {
     int S = log_n - t0;
-    if (S > 10) S = 10;
+    if (S > max_s) S = max_s;
+    if (mode == 5) {
+      const int left = want_np - np;  // passes still to come, this one included
+      S = (log_n - t0 + left - 1) / left;
+    }
     int Q;
     if (rb) {
       // tiles of 2^11 elements wherever the transform has them: a strided pass takes 2^Q adjacent columns (2^Q x 40 B
@@ -506,7 +520,11 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     passes[np++] = {t0, S, Q};
     t0 += S;
   }
-  const bool local_tw = np <= 2;
+  // Plans of three passes (N > 2^20) gather a twiddle per butterfly (it comes out of L2); the local-twiddle + twist scheme
+  // also covers them since round 3 (the twist of a middle pass is a power of the root of order 2^(t0+S)) but measured 5 %
+  // slower there (2^21: 0.549 vs 0.518 ms): ZKMI_NTT_LOCAL3=1 selects it; mode 5 always uses it.
+  static const bool local3 = getenv("ZKMI_NTT_LOCAL3") && getenv("ZKMI_NTT_LOCAL3")[0] == '1';
+  const bool local_tw = np <= 2 || mode == 5 || local3;
   for (int k = 0; k < np; k++) {
     const Pass& p = DIF ? passes[np - 1 - k] : passes[k];
     const bool last = (k == np - 1);
@@ -515,12 +533,16 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     const F* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
     const dim3 grid(nblk, batch);
+    if (rb == 5) {  // tile_n == 512 by construction (log_n >= 9)
+      launch_rb<F, DIF, true, 2, 1, true>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);  // 4 elements x 2 units per thread
+      continue;
+    }
     if (rb == 4 && tile_n == 1024) {
       if (local_tw) launch_rb<F, DIF, true, 2, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
       else launch_rb<F, DIF, false, 2, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
       continue;
     }
-    if (rb && rb != 4 && tile_n >= 512) {
+    if (rb && rb != 4 && rb != 5 && tile_n >= 512) {
       if (rb == 2) {
         if (local_tw) launch_rb<F, DIF, true, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
         else launch_rb<F, DIF, false, 2>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);
@@ -616,7 +638,8 @@ static hipError_t rb_enable_big_lds() {
                        reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 2>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 2>),
                        reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, false, 2>), reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, false, 2>),
                        reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, true, 2, 2>)),  reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, true, 2, 2>)),
-                       reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, false, 2, 2>)), reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, false, 2, 2>))};
+                       reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, false, 2, 2>)), reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, false, 2, 2>)),
+                       reinterpret_cast<const void*>((k_ntt_pass_rb<F, true, true, 2, 1, true>)), reinterpret_cast<const void*>((k_ntt_pass_rb<F, false, true, 2, 1, true>))};
   for (const void* f : fns) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
