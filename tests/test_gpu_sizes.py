@@ -279,8 +279,9 @@ def test_bench_gpus_gt_1_spawns_ranks_or_fails():
 
 VARIANTS = [
     {},
-    {"ZKMI_NTT_RB": "0"}, {"ZKMI_NTT_RB": "1"}, {"ZKMI_NTT_RB": "2"},
-    {"ZKMI_SORT_FINE": "0"}, {"ZKMI_SORT_FINE": "2"},
+    {"ZKMI_NTT_RB": "0"}, {"ZKMI_NTT_RB": "1"}, {"ZKMI_NTT_RB": "2"}, {"ZKMI_NTT_RB": "4"}, {"ZKMI_NTT_RB": "5"},
+    {"ZKMI_NTT_LOCAL3": "1", "ZKMI_WITNESS_BATCH": "0"},
+    {"ZKMI_SORT_FINE": "0"}, {"ZKMI_SORT_FINE": "2"}, {"ZKMI_SORT_STAGE": "0"},
     {"ZKMI_HEAVY_ON": "0"}, {"ZKMI_HEAVY_ON": "1"},
     {"ZKMI_ACCUM": "0", "ZKMI_ACCUM_G2": "0"}, {"ZKMI_AUX_SPLIT": "0", "ZKMI_SORT_SIDE": "1"},
 ]
