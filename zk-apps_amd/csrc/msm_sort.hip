@@ -264,24 +264,28 @@ k_fpart_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigit
 // 109 MB of records).  Here a batch of 1024 scalars (<= 16 K records) is ranked per partition in LDS, laid out partition
 // by partition in the stage, and written out by consecutive lanes: a partition's records of the batch leave as one run.
 constexpr uint32_t FPASS_MAXD = 16;                       // digits per scalar the staged pass supports
-constexpr uint32_t FPASS_STAGE = 1024 * FPASS_MAXD;       // records per batch
+// NPMAX = 512 (plans of up to 2^19 buckets: the prover at N <= 2^20) or 2048 (up to 2^21 buckets: N = 2^21, 2^22); the stage
+// holds 1024 x ndigits records (dynamic LDS: 128 KB at 16 digits, 96 KB at the 12 digits of the big plans).
+template <int NPMAX>
 __global__ void __launch_bounds__(1024)
 k_fpart_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t NP, uint32_t chunk, RecodeConst rc,
                      const uint32_t* __restrict__ blkcnt, const uint32_t* __restrict__ fpart, uint32_t* __restrict__ rec_entry,
                      uint32_t* __restrict__ rec_bkt) {
-  __shared__ uint32_t cursor[512];  // next global record slot of (this block, partition)
-  __shared__ uint32_t bcnt[512];    // records of the batch per partition, then their first stage slot (exclusive prefix)
-  __shared__ uint32_t gbase[512];   // global slot of the batch's first record of the partition
-  __shared__ uint32_t part[512];
-  extern __shared__ uint32_t stg[];  // [FPASS_STAGE] entries, then [FPASS_STAGE] (partition << FINE_LOG | bucket)
+  __shared__ uint32_t cursor[NPMAX];  // next global record slot of (this block, partition)
+  __shared__ uint32_t bcnt[NPMAX];    // records of the batch per partition, then their first stage slot (exclusive prefix)
+  __shared__ uint32_t gbase[NPMAX];   // global slot of the batch's first record of the partition
+  __shared__ uint32_t part[1024];
+  extern __shared__ uint32_t stg[];  // [1024 * ndigits] entries, then as many (partition << FINE_LOG | bucket)
+  const uint32_t stage_n = 1024u * (uint32_t)ndigits;
   uint32_t* const s_entry = stg;
-  uint32_t* const s_qb = stg + FPASS_STAGE;
+  uint32_t* const s_qb = stg + stage_n;
   const uint32_t tid = threadIdx.x;
-  if (tid < 512) cursor[tid] = tid < NP ? fpart[tid] + blkcnt[(size_t)tid * FPART_BLOCKS + blockIdx.x] : 0u;
+  constexpr uint32_t PER = NPMAX > 1024 ? NPMAX / 1024 : 1;  // partitions per thread in the scan
+  for (uint32_t q = tid; q < (uint32_t)NPMAX; q += 1024) cursor[q] = q < NP ? fpart[q] + blkcnt[(size_t)q * FPART_BLOCKS + blockIdx.x] : 0u;
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
   for (uint32_t i0 = beg; i0 < end; i0 += 1024) {
-    if (tid < 512) bcnt[tid] = 0;
+    for (uint32_t q = tid; q < (uint32_t)NPMAX; q += 1024) bcnt[q] = 0;
     __syncthreads();
     const uint32_t i = i0 + tid;
     uint32_t ent[FPASS_MAXD], qb[FPASS_MAXD], rk[FPASS_MAXD];
@@ -307,26 +311,34 @@ k_fpart_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
       for (int w = 0; w < (int)FPASS_MAXD; w++) qb[w] = 0xffffffffu;
     }
     __syncthreads();
-    // exclusive prefix of bcnt over the partitions (512 threads), batch bases from the block's cursors
-    uint32_t mine = 0;
-    if (tid < 512) {
-      mine = bcnt[tid];
-      part[tid] = mine;
+    // exclusive prefix of bcnt over the partitions (thread t owns partitions [t * PER, (t + 1) * PER)), batch bases from the cursors
+    uint32_t mine[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t q = tid * PER + k;
+      mine[k] = q < (uint32_t)NPMAX ? bcnt[q] : 0u;
+      sum += mine[k];
     }
+    part[tid] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < 512; off <<= 1) {
-      uint32_t v = 0;
-      if (tid < 512 && tid >= off) v = part[tid - off];
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
       __syncthreads();
-      if (tid < 512) part[tid] += v;
+      part[tid] += v;
       __syncthreads();
     }
-    if (tid < 512) {
-      bcnt[tid] = part[tid] - mine;  // first stage slot of the partition
-      gbase[tid] = cursor[tid];
-      cursor[tid] += mine;
+    uint32_t run = part[tid] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t q = tid * PER + k;
+      if (q < (uint32_t)NPMAX) {
+        bcnt[q] = run;  // first stage slot of the partition
+        gbase[q] = cursor[q];
+        cursor[q] += mine[k];
+        run += mine[k];
+      }
     }
-    const uint32_t total = part[511];
+    const uint32_t total = part[1023];
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < (int)FPASS_MAXD; w++)
@@ -894,8 +906,11 @@ hipError_t msm_sort_enable_big_lds() {
   }
   // the staged kernels keep static LDS beside their stage: ask for exactly the stage
   {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_write_staged), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)(sizeof(uint32_t) * 2 * FPASS_STAGE));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_write_staged<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(uint32_t) * 2 * 1024 * FPASS_MAXD));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_write_staged<2048>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(uint32_t) * 2 * 1024 * 13));
     if (e != hipSuccess) return e;
   }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -988,14 +1003,16 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
   const bool records = P > 1;
-  // The fine-partition sort serves plans of up to 2^19 buckets (N <= 2^20 in the prover): measured alone it equals the
-  // (chunk, 2^15-bucket partition) record sort there (0.58 vs 0.60 ms at 2^20) and inside the proof pipeline it is worth
-  // +2.7 % proofs/s (sort phase 3.6 -> 2.5 ms per proof: five launches instead of nine, no 32 MiB of tile histograms
-  // written and re-read); with more buckets one workgroup per fine partition becomes the bottleneck (2^26 terms: 55 ms
-  // against 27 ms), so bigger plans keep the record sort.  ZKMI_SORT_FINE=0 / =2: never / whenever it is applicable.
+  // The fine-partition sort (kernels above) serves the plans whose fine partitions hold at most two stage rounds of
+  // records: the prover up to N = 2^21 and prepared MSMs of the same sizes.  Alone: 0.60 -> 0.28 ms at 2^20 terms, 1.24 ->
+  // 0.87 ms at 2^21; inside the proof pipeline +4.8 % proofs/s at N = 2^20.  Beyond that the digit width stays at 20 bits
+  // (2^19 buckets) while the records grow with n, every extra stage round re-reads the partition's records, and the record
+  // sort wins again (2^22: 3.3 vs 2.0 ms, 2^24: 42 vs 6 ms).  ZKMI_SORT_FINE=0 / =2: never / whenever it is applicable.
   static const int fine_mode = getenv("ZKMI_SORT_FINE") ? atoi(getenv("ZKMI_SORT_FINE")) : 1;
   const uint32_t NP = tot_b >> FINE_LOG;
-  if (records && fine_mode != 0 && NP <= (fine_mode == 2 ? FINE_MAX_PARTS : 512u) && fpart != nullptr) {
+  const bool fine_fits = NP <= FINE_MAX_PARTS && (uint64_t)plan.ndigits * n / (NP ? NP : 1) <= 2 * FINE_ROUND &&
+                         plan.ndigits <= (int)FPASS_MAXD;
+  if (records && fine_mode != 0 && (fine_mode == 2 ? NP <= FINE_MAX_PARTS : fine_fits) && fpart != nullptr) {
     uint32_t nblk = (uint32_t)((n + 4095) / 4096);
     if (nblk > FPART_BLOCKS) nblk = FPART_BLOCKS;
     const uint32_t chunk_a = (uint32_t)((n + nblk - 1) / nblk);
@@ -1005,9 +1022,13 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     hipLaunchKernelGGL(k_fpart_scan_rows, dim3(NP), dim3(64), 0, st, blkcnt, nblk, NP, fpart);
     hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart);
     static const bool stage_on = !(getenv("ZKMI_SORT_STAGE") && getenv("ZKMI_SORT_STAGE")[0] == '0');
+    const size_t stage_bytes = sizeof(uint32_t) * 2 * 1024 * (size_t)plan.ndigits;
     if (stage_on && NP <= 512 && plan.ndigits <= (int)FPASS_MAXD)
-      hipLaunchKernelGGL(k_fpart_write_staged, dim3(nblk), dim3(1024), sizeof(uint32_t) * 2 * FPASS_STAGE, st, d_scalars, (uint32_t)n, plan.c,
-                         plan.ndigits, NP, chunk_a, rc, (const uint32_t*)blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+      hipLaunchKernelGGL(k_fpart_write_staged<512>, dim3(nblk), dim3(1024), stage_bytes, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP,
+                         chunk_a, rc, (const uint32_t*)blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+    else if (stage_on && NP <= 2048 && plan.ndigits <= 13)  // 32 KB of cursors + <= 104 KB of stage
+      hipLaunchKernelGGL(k_fpart_write_staged<2048>, dim3(nblk), dim3(1024), stage_bytes, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP,
+                         chunk_a, rc, (const uint32_t*)blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
     else
       hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                          rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
