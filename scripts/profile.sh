@@ -1,13 +1,13 @@
 #!/bin/bash
 # Regenerates every file under profiles/<round>/ in one command, on the GPU box, from the repo root:
 #
-#     bash scripts/profile.sh r02            # -> gpurun_out/prof_r02/{trace,pmc_*}/..., summaries in profiles/r02/
+#     bash scripts/profile.sh r03            # -> gpurun_out/prof_r03/{trace,pmc_*}/..., summaries in profiles/r03/
 #
 # rocprofv3 is always given the program itself after `--` (python3 bench.py ...), tracing and counter
 # collection are separate runs, and the counters are split over passes that fit the hardware slots
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: /opt/skills/guides/MI355X_MICROARCH.md, PMC slots).
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 OUT=gpurun_out/prof_$ROUND
 DST=profiles/$ROUND
 STEPS_TRACE=${STEPS_TRACE:-8}
