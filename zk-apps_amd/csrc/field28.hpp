@@ -464,6 +464,16 @@ using Fq2_28 = Fq2T<Fq28>;
 // (templates on the parameter set: the BLS12-381 and the BN254 base fields share them)
 template <class P>
 ZK_HD Fp28<P> f_sub_lazy(const Fp28<P>& a, const Fp28<P>& b) { return a.sub_lazy(b); }
+// (+-a) - b without a carry sweep: m = 0 keeps a, m = 0xffffffff negates it (two's complement per limb).  The bucket
+// accumulation folds the digit's sign into the first difference of the mixed addition instead of negating the
+// point's y coordinate beforehand (a 14-limb negation plus a 39-instruction carry sweep per insertion).
+template <class P>
+ZK_HD Fp28<P> f_signed_sub_lazy(const Fp28<P>& a, uint32_t m, const Fp28<P>& b) {
+  Fp28<P> r;
+#pragma unroll
+  for (int i = 0; i < P::NL; i++) r.l[i] = (int32_t)(((uint32_t)a.l[i] ^ m) - m) - b.l[i];
+  return r;
+}
 template <class P>
 ZK_HD Fp28<P> f_x3(const Fp28<P>& rr, const Fp28<P>& ppp, const Fp28<P>& q) {
   Fp28<P> r;
@@ -655,6 +665,15 @@ __device__ __forceinline__ Fq2P f_mul_sub_mul(const Fq2P& a, const Fq2P& b, cons
   Fq2P::mul_cols(T, a, b, false);
   Fq2P::mul_cols(T, c, d, true);
   return {Fq28::reduce(T)};
+}
+// (+-a) - b per component; carried (unlike the Fq form above): an Fq2 product column sums two partial products, so its
+// operands have no spare bit for a lazy difference.  Still one carry sweep instead of the two of "negate, then subtract".
+__device__ __forceinline__ Fq2P f_signed_sub_lazy(const Fq2P& a, uint32_t m, const Fq2P& b) {
+  Fq28 r;
+#pragma unroll
+  for (int i = 0; i < Fq28::NL; i++) r.l[i] = (int32_t)(((uint32_t)a.v.l[i] ^ m) - m) - b.v.l[i];
+  r.carry();
+  return {r};
 }
 __device__ __forceinline__ Fq2P f_x3(const Fq2P& rr, const Fq2P& ppp, const Fq2P& q) {
   return {f_x3(rr.v, ppp.v, q.v)};

@@ -227,10 +227,11 @@ k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __res
 // ---------------------------------------------------------------------------------------------
 // acc += p for acc != O, p != O; returns false when the sum needs the complete group law (p = +-acc):
 // the caller hands the bucket to k_accum_redo.  No state besides acc: the loop around it has one path.
+// negmask = 0xffffffff adds -p instead of p (the sign of the digit): folded into the lazy difference R = +-(y zzz) - Y
 template <class F>
-__device__ __forceinline__ bool madd_generic(XYZZ<F>& acc, const Affine<F>& p) {
+__device__ __forceinline__ bool madd_generic(XYZZ<F>& acc, const Affine<F>& p, uint32_t negmask = 0) {
   F pp_ = f_sub_lazy(p.x * acc.zz, acc.x);
-  F r = f_sub_lazy(p.y * acc.zzz, acc.y);
+  F r = f_signed_sub_lazy(p.y * acc.zzz, negmask, acc.y);
   F pp = pp_.sqr();
   F rr = r.sqr();
   if (pp.is_zero()) return false;
@@ -316,8 +317,7 @@ k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
       if (j + 2 < end) v_next = sorted[j + 2];
     }
     if (affine_is_zero_words(p)) continue;
-    if (v >> 31) p.y = p.y.neg();
-    if (!madd_generic(acc, p)) {
+    if (!madd_generic(acc, p, 0u - (v >> 31))) {
       redo[1 + atomicAdd(redo, 1u)] = b;  // doubling or cancellation: k_accum_redo recomputes the bucket
       return;
     }
@@ -349,8 +349,7 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
 #pragma unroll
     for (int i = 0; i < Fq28::NL; i++) o |= (uint32_t)p.x.v.l[i] | (uint32_t)p.y.v.l[i];
     o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
-    if (v >> 31) p.y = p.y.neg();
-    return o == 0;
+    return o == 0;  // (the digit's sign is applied by the caller: first point, or folded into madd_generic)
   };
   XYZZ<Fq2P> acc;
   uint32_t j = beg;
@@ -361,9 +360,10 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
       return;
     }
     Affine<Fq2P> p;
-    if (load_point(sorted[j], p)) continue;
+    const uint32_t v = sorted[j];
+    if (load_point(v, p)) continue;
     acc.x = p.x;
-    acc.y = p.y;
+    acc.y = (v >> 31) ? p.y.neg() : p.y;
     acc.zz = Fq2P::one();
     acc.zzz = Fq2P::one();
     j++;
@@ -371,8 +371,9 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
   }
   for (; j < end; j++) {
     Affine<Fq2P> p;
-    if (load_point(sorted[j], p)) continue;
-    if (!madd_generic(acc, p)) {  // pair-uniform (Fq2P::is_zero exchanges the halves)
+    const uint32_t v = sorted[j];
+    if (load_point(v, p)) continue;
+    if (!madd_generic(acc, p, 0u - (v >> 31))) {  // pair-uniform (Fq2P::is_zero exchanges the halves)
       if (comp == 0) redo[1 + atomicAdd(redo, 1u)] = b;
       return;
     }
