@@ -89,9 +89,10 @@ def cpu_kernel_twins(z, ctx, log_n):
     msm_bigint shape) and Fr NTT over 2^log_n terms on the host cores."""
     from oracle import cpp as ocpp  # the checker; only the cpu_baseline leg may touch oracle/
 
+    import numpy as np
+
     n = 1 << log_n
-    rng = SplitMix64(0x5A4B00C1)
-    raw = bytearray(os.urandom(32 * n))
+    raw = bytearray(np.random.default_rng(0x5A4B00C1).bytes(32 * n))
     for i in range(31, 32 * n, 32):
         raw[i] &= 0x3F  # canonical
     raw = bytes(raw)

@@ -1,6 +1,6 @@
 """Turns a rocprofv3 kernel trace (…_kernel_trace.csv) into a small text report of the steady state:
 per stream, which kernels ran when (last WINDOW ms of the run), how busy each stream was, and how long
-no kernel at all was running.  Usage: python scripts/trace_timeline.py TRACE.csv OUT.txt [WINDOW_MS]"""
+no kernel at all was running.  Usage: python scripts/trace_timeline.py TRACE.csv OUT.txt [WINDOW_MS [MIN_KERNEL_MS]]"""
 import collections
 import csv
 import re
@@ -19,6 +19,7 @@ def short(n):
 def main():
     path, out = sys.argv[1], sys.argv[2]
     window_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
+    min_ms = float(sys.argv[4]) if len(sys.argv) > 4 else 0.05
     ev = []
     for r in csv.DictReader(open(path)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], short(r["Kernel_Name"])))
@@ -51,9 +52,9 @@ def main():
     for (st, name), (c, tot) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
         lines.append("  s%-2s %-46s %4d %9.3f %8.3f" % (st, name[:46], c, tot, tot / c))
     lines.append("")
-    lines.append("timeline (start ms, end ms, duration ms, stream, kernel); kernels shorter than 0.05 ms omitted")
+    lines.append("timeline (start ms, end ms, duration ms, stream, kernel); kernels shorter than %g ms omitted" % min_ms)
     for s, e, st, name in win:
-        if (e - s) / 1e6 >= 0.05:
+        if (e - s) / 1e6 >= min_ms:
             lines.append("%9.3f %9.3f %8.3f s%-2s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, st, name[:60]))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))

@@ -22,6 +22,7 @@
 #include <new>
 #include <string>
 #include <memory>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
@@ -850,16 +851,29 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
   std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
   std::vector<G2XYZZ> acc_b2(G);
   if (G == 1) {
+    static const bool lat_debug = getenv("ZKMI_LAT_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    long tm[6] = {0, 0, 0, 0, 0, 0};
+    auto mark = [&](int i) { tm[i] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
     // one proof: the scalar multiplications of assembly (the expensive part) run while the GPU still works on L and H
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
+    mark(0);
     ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+    mark(1);
     AssemblyHead head = assemble_head(pk, acc_a[0], acc_b1[0], acc_b2[0], r_bytes, s_bytes);
+    mark(2);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
+    mark(3);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3));
+    mark(4);
     if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
     if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
     assemble_tail(head, acc_l[0], acc_h[0], out_proofs);
+    mark(5);
+    if (lat_debug)
+      fprintf(stderr, "zkmi: finish: A,B1 ready %ld us, B2 %ld, head assembled %ld, L ready %ld, H ready %ld, tail done %ld\n", tm[0], tm[1],
+              tm[2], tm[3], tm[4], tm[5]);
     return ZKMI_OK;
   } else {
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
@@ -901,9 +915,16 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
   if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
   const void* src[1] = {z ? static_cast<const void*>(z) : d_z};
+  // ZKMI_LAT_DEBUG=1: host-side timestamps of one proof (queueing the two halves, waiting + assembly) on stderr
+  static const bool lat_debug = getenv("ZKMI_LAT_DEBUG") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
   int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0);
+  const long t_z = us();
   if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0);
+  const long t_h = us();
   if (rc == ZKMI_OK) rc = prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
+  if (lat_debug) fprintf(stderr, "zkmi: single proof 2^%u: queued z-half %ld us, h-half %ld us, finished %ld us\n", pk->log_n, t_z, t_h, us());
   if (rc != ZKMI_OK) {
     // whatever was queued before the failure still reads the caller's witness and the key: wait for it
     const std::string msg = ctx->err;
