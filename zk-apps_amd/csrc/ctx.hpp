@@ -24,6 +24,7 @@ struct zkmi_ctx {
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
   hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
   unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes
+  bool h_fused = false;  // single small proof: the first half queued the H accumulation together with A, B1 and L (groth16.hip)
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;

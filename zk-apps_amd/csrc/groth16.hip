@@ -699,7 +699,9 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
 // consumer of the NTTs, and the NTT kernels (1024-thread blocks, 100 KB of LDS) only get workgroup
 // slots in the gaps the accumulation kernels leave, so h arrives late; with the halves interleaved the
 // main stream always has a full accumulation to run instead of waiting for it.
-static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par) {
+// solo = nothing else of this context is in flight or will be queued before the second half (zkmi_groth16_prove[_dev]): the
+// second half's sort of h may then be queued by the first half
+static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par, bool solo = false) {
   const uint32_t nv = pk->n_vars;
   hipStream_t st = ctx->stream;
   // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the MSMs over z
@@ -744,13 +746,37 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
   // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
   static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
-  const bool spread = spread_on && G == 1 && pk->log_n <= 16;
+  const bool spread = spread_on && G == 1 && pk->log_n <= 16 && !sort_side && sh;
   // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
   if (spread) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
   const hipStream_t sb1 = spread ? ctx->stream_copy : st, sl = spread ? ctx->stream_acc3 : st;
   if (spread) {
     ZK_HIP(ctx, hipStreamWaitEvent(sb1, ctx->ev_sort[par], 0));
     ZK_HIP(ctx, hipStreamWaitEvent(sl, ctx->ev_sort[par], 0));
+  }
+  if (spread && solo) {
+    // The latency of one small proof is a matter of placement: the transforms and the digit sorts are 1024-thread
+    // workgroups, which find no CU while accumulation waves (168-256 registers each) sit on every SIMD -- in the trace the
+    // last transform pass took 0.41 ms instead of 0.04 and the sort of h started 0.6 ms after h was ready.  So the sort
+    // of h is queued here, on the front stream right behind the transforms, and every accumulation waits for it: first
+    // everything that needs whole CUs (0.5 ms), then the five accumulations side by side.
+    ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], 1u << pk->log_n, ctx->stream_front, t));
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_sorth[par], ctx->stream_front));
+    for (hipStream_t s : {ctx->stream_g2, st}) ZK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_sorth[par], 0));
+    // A, B1, L and H as ONE launch on the main stream, G2 beside it.  (On separate streams the grids did not start
+    // together: a kernel that cannot place all its workgroups holds its dispatch pipe, and the streams sharing that pipe
+    // wait -- L started when A had finished, H when the G2 heavy-bucket kernel had.)  The two sorts plan the same bucket
+    // set unless n_vars is far below N; then H goes by itself (prove_enqueue_h).
+    ZK_HIP(ctx, ctx->g2.run_device(sz, pk->b2_tab, ctx->stream_g2, rc2, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
+    const MsmPlan &pz = sz.plan, &ph = ctx->sort_h.plan;
+    ctx->h_fused = pz.nwin == ph.nwin && pz.nb == ph.nb && pz.seg_log == ph.seg_log && pz.c == ph.c && pz.shared == ph.shared;
+    const MsmSort* sorts[4] = {&sz, &sz, &sz, &ctx->sort_h};
+    const Affine<Fq28>* tabs[4] = {pk->a_tab, pk->b1_tab, pk->l_tab, pk->h_tab};
+    // four reduction chains, four streams: the front and copy streams have nothing left to do for this proof
+    const hipStream_t reds[4] = {ra, rb, ctx->stream_front, ctx->stream_copy};
+    const int slots4[4] = {s0 + 0, s0 + 1, s0 + 2, s0 + 3};
+    ZK_HIP(ctx, ctx->g1.run_device_multi(sorts, tabs, ctx->h_fused ? 4 : 3, st, reds, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, slots4, sth));
+    return ZKMI_OK;
   }
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
@@ -763,9 +789,15 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   return ZKMI_OK;
 }
 
-static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int par) {
+static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int par, bool solo = false) {
   const uint32_t N = 1u << pk->log_n;
-  hipStream_t st = ctx->stream;
+  // one small proof (the solo case of prove_enqueue_z): h is already sorted (front stream, right behind the transforms) and
+  // normally accumulated in the same launch as A, B1 and L; otherwise the H accumulation runs on the copy stream, idle by now
+  static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
+  const bool spread = solo && spread_on && G == 1 && pk->log_n <= 16 && !prover_sort_side() && pk->shared;
+  if (spread && ctx->h_fused) return ZKMI_OK;  // accumulated with A, B1 and L
+  hipStream_t st = spread ? ctx->stream_copy : ctx->stream;
+  if (spread) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));  // the sort of h, queued on the front stream
   PhaseTimer* t = ctx->timer();
   const bool sh = pk->shared;
   static const bool heavy_side = getenv("ZKMI_HEAVY_ON") && getenv("ZKMI_HEAVY_ON")[0] == '1';
@@ -777,7 +809,9 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   ZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_h[par], 0));  // h coefficients from the front stream
   // H: all N coefficients (bit-reversed order) against the permuted h query; entry N-1 of the query is
   // infinity.  Own sort buffers (ctx->sort_h), written on the sort stream behind the previous H accumulation.
-  if (G > 1)
+  if (spread)
+    ;  // queued by prove_enqueue_z in front of the accumulations
+  else if (G > 1)
     ZK_HIP(ctx, ctx->sort_h.run_shared_batch(pk->d_h[par], N, 8ull * N, G, ss, t));
   else if (sh)
     ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], N, ss, t));
@@ -801,31 +835,54 @@ struct AssemblyHead {
   G1XYZZ g_a, g_c;
   G2XYZZ g2_b;
 };
-static AssemblyHead assemble_head(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G2XYZZ& acc_b2,
-                                  const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
-  uint32_t rk[8], sk[8], rsk[8];
-  memcpy(rk, r_bytes, 32);
-  memcpy(sk, s_bytes, 32);
+// What assembly can compute from (r, s) and the key alone, i.e. before any MSM has finished: r * delta, s * delta,
+// rs * delta in G1 and s * delta in G2 from the key's fixed-base tables (a single proof computes them while the GPU works)
+struct AssemblyPre {
+  uint32_t rk[8], sk[8];
+  G1XYZZ d_r, d_s, d_rs;
+  G2XYZZ d2_s;
+};
+static AssemblyPre assemble_pre(const zkmi_pk* pk, const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
+  AssemblyPre p;
+  uint32_t rsk[8];
+  memcpy(p.rk, r_bytes, 32);
+  memcpy(p.sk, s_bytes, 32);
   Fr rm, sm;
   fr_from_wire(r_bytes, &rm);
   fr_from_wire(s_bytes, &sm);
   fr_limbs(rm * sm, rsk);
-  AssemblyHead h;
-  // r * delta, s * delta, rs * delta from the key's fixed-base tables; s * A + r * B1 over one doubling chain
-  h.g_a = pk->delta1_tab->mul(rk);
+  p.d_r = pk->delta1_tab->mul(p.rk);
+  p.d_s = pk->delta1_tab->mul(p.sk);
+  p.d_rs = pk->delta1_tab->mul(rsk);
+  p.d2_s = pk->delta2_tab->mul(p.sk);
+  return p;
+}
+// A and s * A + r * B1 - rs * delta (one doubling chain) once the A and B1 MSMs are in
+static void assemble_g1(const zkmi_pk* pk, const AssemblyPre& p, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, AssemblyHead& h) {
+  h.g_a = p.d_r;
   h.g_a.madd(pk->a0);
   h.g_a.add(acc_a);
   h.g_a.madd(pk->alpha_g1);
-  G1XYZZ g1_b = pk->delta1_tab->mul(sk);
+  G1XYZZ g1_b = p.d_s;
   g1_b.madd(pk->b1_0);
   g1_b.add(acc_b1);
   g1_b.madd(pk->beta_g1);
-  h.g2_b = pk->delta2_tab->mul(sk);
+  h.g_c = scalar_mul2(h.g_a, p.sk, g1_b, p.rk);
+  h.g_c.add(p.d_rs.neg());
+}
+// B once the G2 MSM is in: two additions
+static void assemble_g2(const zkmi_pk* pk, const AssemblyPre& p, const G2XYZZ& acc_b2, AssemblyHead& h) {
+  h.g2_b = p.d2_s;
   h.g2_b.madd(pk->b2_0);
   h.g2_b.add(acc_b2);
   h.g2_b.madd(pk->beta_g2);
-  h.g_c = scalar_mul2(h.g_a, sk, g1_b, rk);
-  h.g_c.add(pk->delta1_tab->mul(rsk).neg());
+}
+static AssemblyHead assemble_head(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G2XYZZ& acc_b2,
+                                  const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
+  const AssemblyPre p = assemble_pre(pk, r_bytes, s_bytes);
+  AssemblyHead h;
+  assemble_g1(pk, p, acc_a, acc_b1, h);
+  assemble_g2(pk, p, acc_b2, h);
   return h;
 }
 // Stage 2: C += L + H, compression of A, B, C
@@ -855,13 +912,17 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     const auto t0 = std::chrono::steady_clock::now();
     long tm[6] = {0, 0, 0, 0, 0, 0};
     auto mark = [&](int i) { tm[i] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
-    // one proof: the scalar multiplications of assembly (the expensive part) run while the GPU still works on L and H
+    // one proof: the host's scalar multiplications run while the GPU works -- the fixed-base ones before anything is
+    // waited for, s * A + r * B1 as soon as the two G1 MSMs over z are in (the G2 MSM takes three times as long)
+    AssemblyHead head;
+    const AssemblyPre pre = assemble_pre(pk, r_bytes, s_bytes);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
     mark(0);
-    ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+    assemble_g1(pk, pre, acc_a[0], acc_b1[0], head);
     mark(1);
-    AssemblyHead head = assemble_head(pk, acc_a[0], acc_b1[0], acc_b2[0], r_bytes, s_bytes);
+    ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+    assemble_g2(pk, pre, acc_b2[0], head);
     mark(2);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
     mark(3);
@@ -872,7 +933,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     assemble_tail(head, acc_l[0], acc_h[0], out_proofs);
     mark(5);
     if (lat_debug)
-      fprintf(stderr, "zkmi: finish: A,B1 ready %ld us, B2 %ld, head assembled %ld, L ready %ld, H ready %ld, tail done %ld\n", tm[0], tm[1],
+      fprintf(stderr, "zkmi: finish: A,B1 ready %ld us, G1 part assembled %ld, B2 ready + B assembled %ld, L ready %ld, H ready %ld, tail done %ld\n", tm[0], tm[1],
               tm[2], tm[3], tm[4], tm[5]);
     return ZKMI_OK;
   } else {
@@ -919,9 +980,9 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   static const bool lat_debug = getenv("ZKMI_LAT_DEBUG") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
-  int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0);
+  int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0, true);
   const long t_z = us();
-  if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0);
+  if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0, true);
   const long t_h = us();
   if (rc == ZKMI_OK) rc = prove_finish(ctx, pk, r_bytes, s_bytes, 1, 0, out_proof);
   if (lat_debug) fprintf(stderr, "zkmi: single proof 2^%u: queued z-half %ld us, h-half %ld us, finished %ld us\n", pk->log_n, t_z, t_h, us());

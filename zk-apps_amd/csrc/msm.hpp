@@ -119,9 +119,11 @@ struct MsmEngine {
   XYZZ<F>* segw = nullptr;
   uint64_t seg_cap = 0;
   XYZZ<F>* heavy_partial = nullptr;  // SLOTS x MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
+  uint32_t* heavy_ticket = nullptr;  // SLOTS x MSM_HEAVY_CAP: workgroups of a split heavy bucket that have finished (k_accum_heavy)
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event
   XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS
+  XYZZ<F>* tree_stage = nullptr;  // device, nslots x MSM_STAGE_PTS: slices of k_treesum's job lists (small plans)
   XYZZ<HF>* h_partial = nullptr;  // pinned host, SLOTS x SLOT_PTS
   hipEvent_t done[SLOTS] = {};      // partials landed in h_partial
   hipEvent_t acc_done[SLOTS] = {};  // bucket accumulation finished
@@ -150,6 +152,11 @@ struct MsmEngine {
   // a free workgroup slot before the next accumulation could start
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, hipStream_t st_reduce,
                         PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0, hipStream_t st_heavy = nullptr);
+  // nm <= 4 MSMs of one plan shape (sorts[m] may repeat: several tables over one sort), each with its own slot and
+  // reduction stream; the G1 call-free kernels accumulate them in one launch (one small proof: A, B1, L and H side by side)
+  hipError_t run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
+                              const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce, const int* slots,
+                              hipStream_t st_heavy = nullptr);
   // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points

@@ -38,6 +38,7 @@ namespace zkmi {
 // segment arrays: 16-bucket segments for big plans, down to 1-bucket segments for plans of <= 2^16 buckets
 static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
+constexpr uint32_t MSM_STAGE_PTS = 4096;  // k_treesum slices of one slot (small plans only)
 #ifndef ZKMI_ACCUM_DEFAULT
 #define ZKMI_ACCUM_DEFAULT 3
 #endif
@@ -257,12 +258,50 @@ __device__ __forceinline__ bool affine_is_zero_words(const Affine<Fp28<P>>& p) {
 // G1 (and BN254 G1): thread per bucket, next table entry prefetched through ONE LDS buffer per wave
 // (the entry is read into registers at the top of the iteration, so the buffer is free for the next
 // direct-to-LDS load straight away): 7 KB per wave.
-template <class F, int W, int BW>
+// What one launch accumulates: one MSM (table, bucket array, redo list + the digit sort it reads), or up to four MSMs of
+// the same shape, one per blockIdx.y -- the A, B1, L queries of a proof over the sort of z and the H query over the sort of
+// h.  One small proof uses the second form: 256-wave grids on separate streams did not start together (a kernel that
+// cannot place all its workgroups at once holds its dispatch pipe, and the other streams of that pipe wait).
+constexpr int MSM_MULTI_MAX = 4;
+struct SortView {
+  const uint32_t *begin, *count, *perm, *sorted;
+  uint32_t heavy_thr;
+};
+template <class F, bool MULTI>
+struct AccumArgs;
+template <class F>
+struct AccumArgs<F, false> {
+  const Affine<F>* bases_;
+  XYZZ<F>* buckets_;
+  uint32_t* redo_;
+  SortView sort_;
+  __device__ __forceinline__ const Affine<F>* bases() const { return bases_; }
+  __device__ __forceinline__ XYZZ<F>* buckets() const { return buckets_; }
+  __device__ __forceinline__ uint32_t* redo() const { return redo_; }
+  __device__ __forceinline__ const SortView& sort() const { return sort_; }
+};
+template <class F>
+struct AccumArgs<F, true> {
+  const Affine<F>* bases_[MSM_MULTI_MAX];
+  XYZZ<F>* buckets_[MSM_MULTI_MAX];
+  uint32_t* redo_[MSM_MULTI_MAX];
+  SortView sort_[MSM_MULTI_MAX];
+  __device__ __forceinline__ const Affine<F>* bases() const { return bases_[blockIdx.y]; }
+  __device__ __forceinline__ XYZZ<F>* buckets() const { return buckets_[blockIdx.y]; }
+  __device__ __forceinline__ uint32_t* redo() const { return redo_[blockIdx.y]; }
+  __device__ __forceinline__ const SortView& sort() const { return sort_[blockIdx.y]; }
+};
+template <class F, int W, int BW, bool MULTI = false>
 __global__ void __launch_bounds__(64 * BW, W)
-k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
-              const uint32_t* __restrict__ count, const uint32_t* __restrict__ perm,
-              const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets, uint32_t total_buckets,
-              uint32_t heavy_thr, uint32_t* __restrict__ redo) {
+k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
+  const Affine<F>* __restrict__ const bases = args.bases();
+  XYZZ<F>* __restrict__ const buckets = args.buckets();
+  uint32_t* __restrict__ const redo = args.redo();
+  const uint32_t* __restrict__ const begin = args.sort().begin;
+  const uint32_t* __restrict__ const count = args.sort().count;
+  const uint32_t* __restrict__ const perm = args.sort().perm;
+  const uint32_t* __restrict__ const sorted = args.sort().sorted;
+  const uint32_t heavy_thr = args.sort().heavy_thr;
   constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
   __shared__ uint4 tile[BW][CHUNKS][64];          // [wave][chunk][lane]
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +365,6 @@ k_accum_g1_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
   }
   store_vec(buckets + b, acc);
 }
-
 // G2, lane pair per bucket (see k_accum_g2_split)
 template <int W, int BW>
 __global__ void __launch_bounds__(64 * BW, W)
@@ -421,7 +459,7 @@ k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ b
 
 // Heavy buckets (repeated scalars, booleans: one bucket can hold 20 % of all points):
 // MSM_HSPLIT workgroups share one bucket, each reduces a sub-range with an LDS tree into
-// heavy_partial[h][r]; k_heavy_combine adds the MSM_HSPLIT partials.  Buckets beyond the
+// heavy_partial[h][r]; the last of them to finish adds the partials.  Buckets beyond the
 // partial-slot capacity (pathological inputs) fall back to one workgroup per bucket.
 constexpr uint32_t MSM_HSPLIT = 64;
 constexpr uint32_t MSM_HEAVY_CAP = 1024;
@@ -440,36 +478,37 @@ __device__ __forceinline__ XYZZ<F> block_tree_sum(XYZZ<F> acc, XYZZ<F>* sh) {
   return acc;
 }
 
-// grid = (MSM_HSPLIT, groups)
+// grid = (MSM_HSPLIT, groups).  The sub-ranges of a split bucket are added up by whichever of its workgroups finishes
+// last (ticket word per heavy bucket, left at zero for the slot's next MSM): there is no separate combine launch -- a
+// kernel of 330-register waves (G2) that found no SIMD until the accumulation beside it had drained, with the reduction
+// waiting behind it (0.23 ms of one 2^14 proof's critical path for a list in which no bucket was split at all).
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
               const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
-              XYZZ<F>* __restrict__ heavy_partial) {
+              XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
+  __shared__ uint32_t is_last;
   const uint32_t n_heavy = heavy[0];
   const uint32_t r = blockIdx.x;
   for (uint32_t h = blockIdx.y; h < n_heavy; h += gridDim.y) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
-    const bool split = h < MSM_HEAVY_CAP;
-    if (split) {
+    uint32_t nsplit = 1;
+    if (h < MSM_HEAVY_CAP) {
       // as many sub-ranges as the bucket can feed: ~4 points per thread before the tree (a bucket of 400 points on
       // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group)
-      uint32_t nsplit = (count[b] + 4 * MSM_TREE_T - 1) / (4 * MSM_TREE_T);
+      nsplit = (count[b] + 4 * MSM_TREE_T - 1) / (4 * MSM_TREE_T);
       nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
-      if (r >= nsplit) {  // block-uniform
-        if (threadIdx.x == 0) store_vec(heavy_partial + (size_t)h * MSM_HSPLIT + r, XYZZ<F>::infinity());
-        continue;
-      }
+    }
+    if (r >= nsplit) continue;  // block-uniform
+    if (nsplit > 1) {
       const uint32_t len = (count[b] + nsplit - 1) / nsplit;
       const uint32_t sb = beg + r * len;
       end = (sb + len < end) ? sb + len : end;
       beg = sb < end ? sb : end;
-    } else if (r != 0) {
-      continue;  // block-uniform
     }
     XYZZ<F> acc = XYZZ<F>::infinity();
     for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
@@ -479,24 +518,26 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
       acc.madd(p);
     }
     acc = block_tree_sum(acc, sh);
-    if (threadIdx.x == 0) store_vec(split ? heavy_partial + (size_t)h * MSM_HSPLIT + r : buckets + b, acc);
-    __syncthreads();
-  }
-}
-
-// one workgroup of MSM_HSPLIT threads per heavy bucket: sum of its partials -> bucket
-template <class F>
-__global__ void __launch_bounds__(MSM_HSPLIT)
-k_heavy_combine(const uint32_t* __restrict__ heavy, const XYZZ<F>* __restrict__ heavy_partial,
-                XYZZ<F>* __restrict__ buckets) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
-  uint32_t n_heavy = heavy[0];
-  if (n_heavy > MSM_HEAVY_CAP) n_heavy = MSM_HEAVY_CAP;
-  for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-    XYZZ<F> acc = load_vec(heavy_partial + (size_t)h * MSM_HSPLIT + threadIdx.x);
-    acc = block_tree_sum(acc, sh);
-    if (threadIdx.x == 0) store_vec(buckets + heavy[1 + h], acc);
+    if (nsplit == 1) {
+      if (threadIdx.x == 0) store_vec(buckets + b, acc);
+    } else {
+      if (threadIdx.x == 0) {
+        store_vec(heavy_partial + (size_t)h * MSM_HSPLIT + r, acc);
+        __threadfence();  // the partial is visible device-wide before the ticket is taken
+        is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+      }
+      __syncthreads();
+      if (is_last) {  // block-uniform
+        __threadfence();
+        XYZZ<F> v = XYZZ<F>::infinity();
+        if (threadIdx.x < nsplit) v = load_vec(heavy_partial + (size_t)h * MSM_HSPLIT + threadIdx.x);
+        v = block_tree_sum(v, sh);
+        if (threadIdx.x == 0) {
+          store_vec(buckets + b, v);
+          ticket[h] = 0;
+        }
+      }
+    }
     __syncthreads();
   }
 }
@@ -555,27 +596,36 @@ k_segreduce_g2_split(const XYZZ<Fq2_28>* __restrict__ buckets, XYZZ<Fq2_28>* __r
   st_xyzz_split(segw + t, acc, comp);
 }
 
-// grid = (njobs, nwin).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t];
-// job plain_job (shared-bucket mode only): sum_t segsum[w][t]
+// grid = (njobs, nwin, nchunk).  job 0: sum_t segw[w][t]; job j>=1: sum_{t: bit (j-1)} segsum[w][t];
+// job plain_job (shared-bucket mode only): sum_t segsum[w][t].
+// nchunk = 1: the workgroup sums the job's whole list and writes the result in the host representation.
+// nchunk > 1 (small plans, where the reduction is a latency chain and the chip is empty): workgroup z sums the z-th
+// slice of the list into stage[(w * njobs + job) * nchunk + z]; k_treesum_final adds the slices.  A list of 2^13 segments
+// then costs 2 + 7 + 5 dependent additions instead of 64 + 7.
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, uint32_t segs_per_win,
-          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial, int plain_job) {
+          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial, int plain_job, XYZZ<F>* __restrict__ stage) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const int job = blockIdx.x;
   const int w = blockIdx.y;
+  const uint32_t nchunk = gridDim.z, z = blockIdx.z;
   const XYZZ<F>* src = (job == 0 ? segw : segsum) + (size_t)w * segs_per_win;
+  const bool whole = job == 0 || job == plain_job;
+  const uint32_t len = whole ? segs_per_win : segs_per_win / 2;
+  const uint32_t per = (len + nchunk - 1) / nchunk;
+  const uint32_t lo = z * per, hi = lo + per < len ? lo + per : len;
   XYZZ<F> acc = XYZZ<F>::infinity();
-  if (job == 0 || job == plain_job) {
-    for (uint32_t t = threadIdx.x; t < segs_per_win; t += blockDim.x) {
+  if (whole) {
+    for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
       XYZZ<F> v = load_vec(src + t);
       acc.add(v);
     }
   } else {
     // bit job: enumerate only the segments whose bit (job - 1) is set, so that no lane idles through an addition
     const uint32_t b = (uint32_t)(job - 1), lowmask = (1u << b) - 1u;
-    for (uint32_t u = threadIdx.x; u < segs_per_win / 2; u += blockDim.x) {
+    for (uint32_t u = lo + threadIdx.x; u < hi; u += blockDim.x) {
       const uint32_t t = ((u & ~lowmask) << 1) | (1u << b) | (u & lowmask);
       XYZZ<F> v = load_vec(src + t);
       acc.add(v);
@@ -591,9 +641,189 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    if (nchunk == 1) {
+      XYZZ<typename HostFieldOf<F>::type> o = {fq_from_fq28(acc.x), fq_from_fq28(acc.y), fq_from_fq28(acc.zz),
+                                               fq_from_fq28(acc.zzz)};
+      store_vec(partial + (size_t)w * gridDim.x + job, o);
+    } else {
+      store_vec(stage + ((size_t)w * gridDim.x + job) * nchunk + z, acc);
+    }
+  }
+}
+
+// grid = (njobs, nwin), nchunk <= blockDim.x (a power of two) <= MSM_TREE_T: adds the slices of one (window, job)
+template <class F>
+__global__ void __launch_bounds__(MSM_TREE_T)
+k_treesum_final(const XYZZ<F>* __restrict__ stage, uint32_t nchunk, XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
+  const size_t idx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  if (threadIdx.x < nchunk) acc = load_vec(stage + idx * nchunk + threadIdx.x);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      acc.add(sh[threadIdx.x + s]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     XYZZ<typename HostFieldOf<F>::type> o = {fq_from_fq28(acc.x), fq_from_fq28(acc.y), fq_from_fq28(acc.zz),
                                              fq_from_fq28(acc.zzz)};
-    store_vec(partial + (size_t)w * gridDim.x + job, o);
+    store_vec(partial + idx, o);
+  }
+}
+
+// Lane-pair forms of the two tree-sum kernels for G2 (see k_accum_g2_split): a pair owns one list element, so the
+// unsplit form's 330-register additions (one wave per SIMD, 45-60 us each in a latency chain) become G1-sized ones.
+// Used for the sliced (small-plan) case, where the tree sums ARE the latency of a proof; blockDim.x / 2 pairs per workgroup.
+__device__ __forceinline__ void st_host_split(XYZZ<Fq2>* dst, const XYZZ<Fq2P>& v, uint32_t comp) {
+  Fq* d = reinterpret_cast<Fq*>(dst);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+  d[comp] = fq_from_fq28(v.x.v);
+  d[2 + comp] = fq_from_fq28(v.y.v);
+  d[4 + comp] = fq_from_fq28(v.zz.v);
+  d[6 + comp] = fq_from_fq28(v.zzz.v);
+}
+__device__ __forceinline__ XYZZ<Fq2P> pair_tree_sum(XYZZ<Fq2P> acc, XYZZ<Fq2_28>* sh, uint32_t pair, uint32_t npair, uint32_t comp) {
+  st_xyzz_split(sh + pair, acc, comp);
+  __syncthreads();
+  for (uint32_t s = npair / 2; s > 0; s >>= 1) {
+    if (pair < s) {  // pair-uniform
+      XYZZ<Fq2P> o = ld_xyzz_split(sh + pair + s, comp);
+      acc.add(o);
+      st_xyzz_split(sh + pair, acc, comp);
+    }
+    __syncthreads();
+  }
+  return acc;
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(MSM_TREE_T, 2)
+k_treesum_g2_split(const XYZZ<Fq2_28>* __restrict__ segsum, const XYZZ<Fq2_28>* __restrict__ segw, uint32_t segs_per_win,
+                   XYZZ<Fq2>* __restrict__ partial, int plain_job, XYZZ<Fq2_28>* __restrict__ stage) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
+  const int job = blockIdx.x;
+  const int w = blockIdx.y;
+  const uint32_t nchunk = gridDim.z, z = blockIdx.z;
+  const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
+  const XYZZ<Fq2_28>* src = (job == 0 ? segw : segsum) + (size_t)w * segs_per_win;
+  const bool whole = job == 0 || job == plain_job;
+  const uint32_t len = whole ? segs_per_win : segs_per_win / 2;
+  const uint32_t per = (len + nchunk - 1) / nchunk;
+  const uint32_t lo = z * per, hi = lo + per < len ? lo + per : len;
+  const uint32_t b = whole ? 0u : (uint32_t)(job - 1), lowmask = (1u << b) - 1u;
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  for (uint32_t u = lo + pair; u < hi; u += npair) {
+    const uint32_t t = whole ? u : (((u & ~lowmask) << 1) | (1u << b) | (u & lowmask));
+    XYZZ<Fq2P> v = ld_xyzz_split(src + t, comp);
+    acc.add(v);
+  }
+  acc = pair_tree_sum(acc, sh, pair, npair, comp);
+  if (pair == 0) {
+    if (nchunk == 1)
+      st_host_split(partial + (size_t)w * gridDim.x + job, acc, comp);
+    else
+      st_xyzz_split(stage + ((size_t)w * gridDim.x + job) * nchunk + z, acc, comp);
+  }
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(2 * MSM_TREE_T, 2)
+k_treesum_final_g2_split(const XYZZ<Fq2_28>* __restrict__ stage, uint32_t nchunk, XYZZ<Fq2>* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
+  const size_t idx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  if (pair < nchunk) acc = ld_xyzz_split(stage + idx * nchunk + pair, comp);
+  acc = pair_tree_sum(acc, sh, pair, npair, comp);
+  if (pair == 0) st_host_split(partial + idx, acc, comp);
+}
+
+// Lane-pair forms of the heavy-bucket and redo kernels for G2: same logic as k_accum_heavy / k_accum_redo with a lane
+// pair per point (the unsplit forms are 330-register kernels with 55-75 us per dependent addition: 0.8 ms for one
+// 600-point bucket of a 2^14 proof, on the critical path of the G2 reduction; and 0.1 ms to place an EMPTY redo kernel).
+__device__ __forceinline__ Affine<Fq2P> ld_affine_split(const Affine<Fq2_28>* bases, uint32_t v, uint32_t comp) {
+  const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));  // x.c0 x.c1 y.c0 y.c1
+  Affine<Fq2P> p;
+  p.x.v = ld_comp(src + comp);
+  p.y.v = ld_comp(src + 2 + comp);
+  if (v >> 31) p.y = p.y.neg();
+  return p;
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(MSM_TREE_T, 2)
+k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+                       const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
+                       const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets,
+                       XYZZ<Fq2_28>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
+  __shared__ uint32_t is_last;
+  const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
+  const uint32_t n_heavy = heavy[0];
+  const uint32_t r = blockIdx.x;
+  for (uint32_t h = blockIdx.y; h < n_heavy; h += gridDim.y) {
+    const uint32_t b = heavy[1 + h];
+    uint32_t beg = begin[b], end = beg + count[b];
+    uint32_t nsplit = 1;
+    if (h < MSM_HEAVY_CAP) {  // ~4 points per lane pair before the tree
+      nsplit = (count[b] + 4 * npair - 1) / (4 * npair);
+      nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
+    }
+    if (r >= nsplit) continue;  // block-uniform
+    if (nsplit > 1) {
+      const uint32_t len = (count[b] + nsplit - 1) / nsplit;
+      const uint32_t sb = beg + r * len;
+      end = (sb + len < end) ? sb + len : end;
+      beg = sb < end ? sb : end;
+    }
+    XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+    for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));  // pair-uniform
+    acc = pair_tree_sum(acc, sh, pair, npair, comp);
+    if (nsplit == 1) {
+      if (pair == 0) st_xyzz_split(buckets + b, acc, comp);
+    } else {
+      if (pair == 0) {
+        st_xyzz_split(heavy_partial + (size_t)h * MSM_HSPLIT + r, acc, comp);
+        __threadfence();  // each lane's half of the partial is visible device-wide ...
+      }
+      __syncthreads();  // ... before the ticket is taken
+      if (threadIdx.x == 0) is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+      __syncthreads();
+      if (is_last) {  // block-uniform; nsplit <= MSM_HSPLIT = npair
+        __threadfence();
+        XYZZ<Fq2P> v = XYZZ<Fq2P>::infinity();
+        if (pair < nsplit) v = ld_xyzz_split(heavy_partial + (size_t)h * MSM_HSPLIT + pair, comp);
+        v = pair_tree_sum(v, sh, pair, npair, comp);
+        if (pair == 0) st_xyzz_split(buckets + b, v, comp);
+        if (threadIdx.x == 0) ticket[h] = 0;
+      }
+    }
+    __syncthreads();
+  }
+}
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64, 2)
+k_accum_redo_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
+                      const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
+                      XYZZ<Fq2_28>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket) {
+  const uint32_t n = redo[0];
+  const uint32_t comp = threadIdx.x & 1u;
+  for (uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 1; k < n; k += (gridDim.x * blockDim.x) >> 1) {  // pair-uniform
+    const uint32_t b = redo[1 + k];
+    const uint32_t beg = begin[b], end = beg + count[b];
+    XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+    for (uint32_t j = beg; j < end; j++) acc.madd(ld_affine_split(bases, sorted[j], comp));
+    st_xyzz_split(buckets + b, acc, comp);
+  }
+  // every workgroup has read the length by now; the last one to get here clears the list for the slot's next MSM
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    redo[0] = 0;
+    *ticket = 0;
   }
 }
 
@@ -617,8 +847,12 @@ void MsmEngine<F>::release() {
   if (segsum) (void)hipFree(segsum);
   if (segw) (void)hipFree(segw);
   if (partial) (void)hipFree(partial);
+  if (tree_stage) (void)hipFree(tree_stage);
+  tree_stage = nullptr;
   if (heavy_partial) (void)hipFree(heavy_partial);
   heavy_partial = nullptr;
+  if (heavy_ticket) (void)hipFree(heavy_ticket);
+  heavy_ticket = nullptr;
   if (redo) (void)hipFree(redo);
   redo = nullptr;
   if (h_partial) (void)hipHostFree(h_partial);
@@ -673,7 +907,10 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segsum, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
+  if ((e = hipMalloc(&tree_stage, sizeof(XYZZ<F>) * MSM_STAGE_PTS * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * nslots)) != hipSuccess) return e;  // per slot
+  if ((e = hipMalloc(&heavy_ticket, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots)) != hipSuccess) return e;
+  if ((e = hipMemset(heavy_ticket, 0, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots)) != hipSuccess) return e;  // every use leaves zeros behind
   if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // one list per slot
   if ((e = hipMemset(redo, 0, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // lengths and tickets start at zero
   if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
@@ -697,12 +934,27 @@ template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
                                     hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot,
                                     hipStream_t st_heavy) {
-  if (slot < 0 || slot >= nslots) return hipErrorInvalidValue;
-  const MsmPlan& pl = sort.plan;
-  slot_plan[slot] = pl;
+  const MsmSort* sp = &sort;
+  return run_device_multi(&sp, &d_bases, 1, st, &st_reduce, prof, ph_accum, ph_reduce, &slot, st_heavy);
+}
+
+// nm MSMs of the same plan shape (sorts[m] may repeat: different tables over one digit sort): one fused accumulation
+// launch where the kernel has a fused form (the call-free G1 kernels), otherwise nm launches in line; each MSM keeps
+// its own slot and reduction stream.  All sorts must be complete on `st` (stream order or events) when this is called.
+template <class F>
+hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
+                                          const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce,
+                                          const int* slots, hipStream_t st_heavy) {
+  if (nm < 1 || nm > MSM_MULTI_MAX) return hipErrorInvalidValue;
+  for (int m = 0; m < nm; m++)
+    if (slots[m] < 0 || slots[m] >= nslots) return hipErrorInvalidValue;
+  const MsmPlan& pl = sorts[0]->plan;  // bucket count, windows, segment length: common to all (checked); heavy_thr is per sort
+  for (int m = 1; m < nm; m++) {
+    const MsmPlan& q = sorts[m]->plan;
+    if (q.nwin != pl.nwin || q.nb != pl.nb || q.seg_log != pl.seg_log || q.shared != pl.shared || q.c != pl.c) return hipErrorInvalidValue;
+  }
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
-  XYZZ<F>* bk = buckets + (size_t)slot * cap_buckets;
   hipError_t e;
   // Heavy and light buckets are disjoint, so the heavy-bucket kernels only have to see the sort complete.  Where they
   // run (ZKMI_HEAVY_ON, read once): 0 = in line on the accumulation stream; 1 = on `st_heavy` beside the accumulation
@@ -715,12 +967,6 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     const char* e = getenv("ZKMI_HEAVY_ON");
     return e ? atoi(e) : 2;
   }();
-  const bool on_reduce = heavy_on == 2 && st_reduce != st;
-  const bool side = !on_reduce && heavy_on != 0 && st_heavy && st_heavy != st;
-  if (side || on_reduce) {
-    if ((e = hipEventRecord(pre[slot], st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(on_reduce ? st_reduce : st_heavy, pre[slot], 0)) != hipSuccess) return e;
-  }
   // ZKMI_ACCUM: 0 = the first-generation kernels (madd with an out-of-line doubling path), 2/3 = the call-free
   // kernels at 2 / 3 waves per SIMD (default: see DESIGN.md 4.1 for the measurements behind it)
   static const int accum_mode = [] {
@@ -734,7 +980,6 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
   }();
   const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
   const bool nocall = mode == 2 || mode == 3;
-  uint32_t* const redo = this->redo + (size_t)slot * (cap_buckets + 2);  // [0] length, [1 ..] list, [cap_buckets + 1] ticket (k_accum_redo)
   // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
   // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
   static const int accum_block = [] {
@@ -750,90 +995,189 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
     if (accum_rounds > 1) blocks = (blocks + accum_rounds - 1) / accum_rounds;
     return blocks ? blocks : 1u;
   };
+  auto bk_of = [&](int m) { return buckets + (size_t)slots[m] * cap_buckets; };
+  // [0] length, [1 ..] list, [cap_buckets + 1] ticket (k_accum_redo)
+  auto redo_of = [&](int m) { return this->redo + (size_t)slots[m] * (cap_buckets + 2); };
+
+  // ---- in front of the accumulation: heavy-bucket kernels of every MSM that runs them on another stream ----
+  // On another stream they are queued BEFORE the accumulation: their workgroups (two waves of up to 330 registers, 28-56 KB
+  // of LDS) are then placed while the SIMDs are still free; queued behind it they waited for the accumulation to drain.
+  bool heavy_first[MSM_MULTI_MAX];
+  hipStream_t heavy_stream[MSM_MULTI_MAX];
+  auto launch_heavy = [&](int m) {
+    const MsmSort& sort = *sorts[m];
+    XYZZ<F>* const hp = heavy_partial + (size_t)slots[m] * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
+    if constexpr (std::is_same<F, Fq2_28>::value)
+      hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
+                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
+                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP);
+    else
+      hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
+                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
+                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP);
+  };
+  for (int m = 0; m < nm; m++) {
+    slot_plan[slots[m]] = sorts[m]->plan;
+    const hipStream_t st_reduce = st_reduces[m];
+    const bool on_reduce = heavy_on == 2 && st_reduce != st;
+    const bool side = !on_reduce && heavy_on != 0 && st_heavy && st_heavy != st;
+    heavy_first[m] = side || on_reduce;
+    heavy_stream[m] = on_reduce ? st_reduce : side ? st_heavy : st;
+    if (heavy_first[m]) {
+      if ((e = hipEventRecord(pre[slots[m]], st)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(heavy_stream[m], pre[slots[m]], 0)) != hipSuccess) return e;
+      launch_heavy(m);
+    }
+  }
+  auto view_of = [&](int m) {
+    const MsmSort& sort = *sorts[m];
+    return SortView{sort.begin, sort.count, sort.perm, sort.sorted, sort.plan.heavy_thr};
+  };
+
+  // ---- the accumulation ----
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
-    const dim3 grid((2 * tot_b + T - 1) / T);
-    if (mode == 3)
-      hipLaunchKernelGGL((k_accum_g2_nc<3, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
-                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
-    else if (mode == 2)
-      hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
-                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
-    else if (accum_block == 64)
-      hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases, sort.begin, sort.count,
-                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+    for (int m = 0; m < nm; m++) {
+      const MsmSort& sort = *sorts[m];
+      const uint32_t heavy_thr = sort.plan.heavy_thr;
+      XYZZ<F>* const bk = bk_of(m);
+      uint32_t* const redo = redo_of(m);
+      if (mode == 3)
+        hipLaunchKernelGGL((k_accum_g2_nc<3, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
+      else if (mode == 2)
+        hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
+      else if (accum_block == 64)
+        hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+      else
+        hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+    }
+  } else if (nm > 1 && nocall) {
+    AccumArgs<F, true> set;
+    for (int m = 0; m < MSM_MULTI_MAX; m++) {
+      const int k = m < nm ? m : 0;
+      set.bases_[m] = d_bases[k];
+      set.buckets_[m] = bk_of(k);
+      set.redo_[m] = redo_of(k);
+      set.sort_[m] = view_of(k);
+    }
+    if (accum_mode == 3)
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
     else
-      hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases, sort.begin, sort.count,
-                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
   } else {
     const dim3 grid((tot_b + T - 1) / T);
-    if (accum_mode == 3)
-      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
-                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
-    else if (accum_mode == 2)
-      hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, d_bases, sort.begin, sort.count, sort.perm,
-                         sort.sorted, bk, tot_b, pl.heavy_thr, redo);
-    else if (accum_mode == 1)
-      hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases, sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
-                         pl.heavy_thr);
-    else if (accum_block == 64)
-      hipLaunchKernelGGL((k_accum_g1_glds<F, 1>), dim3(striped(tot_b, 64)), dim3(64), 0, st, d_bases, sort.begin, sort.count,
-                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
-    else
-      hipLaunchKernelGGL((k_accum_g1_glds<F, 4>), dim3(striped(tot_b, 256)), dim3(256), 0, st, d_bases, sort.begin, sort.count,
-                         sort.perm, sort.sorted, bk, tot_b, pl.heavy_thr);
+    for (int m = 0; m < nm; m++) {
+      const MsmSort& sort = *sorts[m];
+      const uint32_t heavy_thr = sort.plan.heavy_thr;
+      XYZZ<F>* const bk = bk_of(m);
+      uint32_t* const redo = redo_of(m);
+      const AccumArgs<F, false> one = {d_bases[m], bk, redo, view_of(m)};
+      if (accum_mode == 3)
+        hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
+      else if (accum_mode == 2)
+        hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
+      else if (accum_mode == 1)
+        hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases[m], sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
+                           heavy_thr);
+      else if (accum_block == 64)
+        hipLaunchKernelGGL((k_accum_g1_glds<F, 1>), dim3(striped(tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+      else
+        hipLaunchKernelGGL((k_accum_g1_glds<F, 4>), dim3(striped(tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+    }
   }
-  if (prof) prof->end(ph_accum, st);  // the phase brackets exactly one k_accum launch (roofline leg of bench.py)
-  const hipStream_t sh = on_reduce ? st_reduce : side ? st_heavy : st;
-  XYZZ<F>* const hp = heavy_partial + (size_t)slot * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
-  hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, sh, d_bases,
-                     sort.begin, sort.count, sort.heavy, sort.sorted, bk, hp);
-  hipLaunchKernelGGL(k_heavy_combine<F>, dim3(64), dim3(MSM_HSPLIT), sizeof(XYZZ<F>) * MSM_HSPLIT, sh, sort.heavy,
-                     hp, bk);
-  if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
-  sort.readers.push_back(acc_done[slot]);  // the next sort into these buffers may be queued on another stream
-  if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
-  if (side) {
-    if ((e = hipEventRecord(heavy_done[slot], st_heavy)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(st_reduce, heavy_done[slot], 0)) != hipSuccess) return e;
-    sort.readers.push_back(heavy_done[slot]);  // the next sort must not overwrite what these kernels read
-  }
-  if (on_reduce && !nocall) {  // (with the call-free kernels redo_done below covers the heavy kernels too: same stream, later)
-    if ((e = hipEventRecord(heavy_done[slot], st_reduce)) != hipSuccess) return e;
-    sort.readers.push_back(heavy_done[slot]);
-  }
-  if (nocall) {
-    // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
-    // heavy buckets are never listed, so the heavy kernels may still be running
-    using RF = typename std::conditional<std::is_same<F, Fq2_28>::value, Fq2_28, F>::type;
-    hipLaunchKernelGGL(k_accum_redo<RF>, dim3(64), dim3(64), 0, st_reduce, d_bases, sort.begin, sort.count, sort.sorted, bk, redo,
-                       redo + cap_buckets + 1);
-    // the list reads the sort: the next sort must wait for this kernel too
-    if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;
-    sort.readers.push_back(redo_done[slot]);
-  }
-  if (prof) prof->begin(ph_reduce, st_reduce);
+  if (prof) prof->end(ph_accum, st);  // the phase brackets the accumulation launch(es) only (roofline leg of bench.py)
+
+  // ---- behind it, per MSM: heavy kernels that run in line, redo list, reduction, copy of the partials ----
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
   const int seg = 1 << pl.seg_log;
-  XYZZ<F>* const ssum = segsum + (size_t)slot * seg_cap;
-  XYZZ<F>* const sw = segw + (size_t)slot * seg_cap;
-  if constexpr (std::is_same<F, Fq2_28>::value) {
-    hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
-                       tot_segs, seg);
-  } else {
-    hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg);
-  }
+  if (tot_segs > seg_cap || (uint64_t)(2 + msm_seg_bits(pl)) * pl.nwin > SLOT_PTS) return hipErrorInvalidValue;
   const int plain_job = pl.shared ? 1 + msm_seg_bits(pl) : -1;
   const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
-  XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
-  hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                     ssum, sw, segs_per_win, dp, plain_job);
-  if (prof) prof->end(ph_reduce, st_reduce);
-  e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
-                     hipMemcpyDeviceToHost, st_reduce);
-  if (e != hipSuccess) return e;
-  if ((e = hipEventRecord(done[slot], st_reduce)) != hipSuccess) return e;
+  // small plans: the job lists are cut into slices of two segments per thread or lane pair (k_treesum_final adds the slices)
+  constexpr bool is_g2 = std::is_same<F, Fq2_28>::value;
+  const uint32_t per_block = is_g2 ? MSM_TREE_T : 2 * MSM_TREE_T;  // G2: 64 lane pairs x 2 segments
+  uint32_t nchunk = 1;
+  if (tot_b <= (1u << 16) && segs_per_win > per_block) {
+    nchunk = segs_per_win / per_block;
+    if (nchunk > MSM_TREE_T) nchunk = MSM_TREE_T;
+    if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS) nchunk = 1;
+  }
+  for (int m = 0; m < nm; m++) {
+    const MsmSort& sort = *sorts[m];
+    const int slot = slots[m];
+    const hipStream_t st_reduce = st_reduces[m];
+    XYZZ<F>* const bk = bk_of(m);
+    if (!heavy_first[m]) launch_heavy(m);
+    if ((e = hipEventRecord(acc_done[slot], st)) != hipSuccess) return e;
+    sort.readers.push_back(acc_done[slot]);  // the next sort into these buffers may be queued on another stream
+    if (st_reduce != st && (e = hipStreamWaitEvent(st_reduce, acc_done[slot], 0)) != hipSuccess) return e;
+    if (heavy_first[m] && heavy_stream[m] != st_reduce) {  // side stream
+      if ((e = hipEventRecord(heavy_done[slot], heavy_stream[m])) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(st_reduce, heavy_done[slot], 0)) != hipSuccess) return e;
+      sort.readers.push_back(heavy_done[slot]);  // the next sort must not overwrite what these kernels read
+    }
+    if (heavy_first[m] && heavy_stream[m] == st_reduce && !nocall) {  // (with the call-free kernels redo_done below covers the heavy kernels too: same stream, later)
+      if ((e = hipEventRecord(heavy_done[slot], st_reduce)) != hipSuccess) return e;
+      sort.readers.push_back(heavy_done[slot]);
+    }
+    if (nocall) {
+      // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
+      // heavy buckets are never listed, so the heavy kernels may still be running
+      uint32_t* const redo = redo_of(m);
+      if constexpr (std::is_same<F, Fq2_28>::value)
+        hipLaunchKernelGGL(k_accum_redo_g2_split<0>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk,
+                           redo, redo + cap_buckets + 1);
+      else
+        hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
+                           redo + cap_buckets + 1);
+      // the list reads the sort: the next sort must wait for this kernel too
+      if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;
+      sort.readers.push_back(redo_done[slot]);
+    }
+    if (prof) prof->begin(ph_reduce, st_reduce);
+    XYZZ<F>* const ssum = segsum + (size_t)slot * seg_cap;
+    XYZZ<F>* const sw = segw + (size_t)slot * seg_cap;
+    if constexpr (is_g2) {
+      hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
+                         tot_segs, seg);
+    } else {
+      hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg);
+    }
+    XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
+    XYZZ<F>* const stg = tree_stage + (size_t)slot * MSM_STAGE_PTS;
+    if constexpr (is_g2) {
+      if (nchunk > 1) {
+        hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, st_reduce,
+                           ssum, sw, segs_per_win, dp, plain_job, stg);
+        uint32_t tf = 64;
+        while (tf < 2 * nchunk) tf <<= 1;
+        hipLaunchKernelGGL(k_treesum_final_g2_split<0>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf / 2, st_reduce, stg, nchunk, dp);
+      } else {
+        hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+                           ssum, sw, segs_per_win, dp, plain_job, stg);
+      }
+    } else {
+      hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+                         ssum, sw, segs_per_win, dp, plain_job, stg);
+      if (nchunk > 1) {
+        uint32_t tf = 64;
+        while (tf < nchunk) tf <<= 1;
+        hipLaunchKernelGGL(k_treesum_final<F>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf, st_reduce, stg, nchunk, dp);
+      }
+    }
+    if (prof) prof->end(ph_reduce, st_reduce);
+    e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
+                       hipMemcpyDeviceToHost, st_reduce);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventRecord(done[slot], st_reduce)) != hipSuccess) return e;
+  }
   return hipGetLastError();
 }
 

@@ -676,11 +676,14 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
     if (thr < 48) thr = 48;
   }
   // short segments where the reduction is pure latency (one small MSM: a segment is a dependent chain of 2 x length
-  // additions), 16 buckets once there are enough segments to fill the chip
-  p.seg_log = buckets <= (1u << 13) ? 2 : buckets <= (1u << 15) ? 3 : 4;
+  // additions, and the tree sums behind it are cut into slices, msm_impl.hpp k_treesum: 2^14 buckets = 4 + 14 dependent
+  // additions, against 16 + 23 with 8-bucket segments and one workgroup per job), 16 buckets once there are enough
+  // segments to fill the chip
+  p.seg_log = buckets <= (1u << 14) ? 1 : buckets <= (1u << 15) ? 2 : buckets <= (1u << 16) ? 3 : 4;
   {
     static const int seg_env = getenv("ZKMI_SEG_LOG") ? atoi(getenv("ZKMI_SEG_LOG")) : 0;  // A/B: segment length of big plans
-    if (seg_env >= 2 && seg_env <= 7 && buckets > (1u << 13)) p.seg_log = seg_env;
+    // (the segment arrays hold max(buckets / 16, 2^16) entries: msm_impl.hpp msm_max_segments)
+    if (seg_env >= 1 && seg_env <= 7 && (buckets >> seg_env) <= (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16))) p.seg_log = seg_env;
   }
   if ((1u << p.seg_log) > p.nb) p.seg_log = 0;
   p.heavy_thr = (uint32_t)thr;
