@@ -189,6 +189,24 @@ def test_msm_g1_all_scalars_equal(ctx):
     b.free()
 
 
+@pytest.mark.parametrize("n", [3000, 40000])
+def test_msm_g2_witness_like_heavy_buckets(ctx, n):
+    """The G2 twin of test_msm_g1_witness_like_heavy_buckets: buckets of thousands of points go through the lane-pair
+    heavy-bucket kernel, the biggest ones split over several workgroups whose last one adds the partials."""
+    rng = ec.SplitMix64(37 * n)
+    rep = rng.fr()
+    s = []
+    for _ in range(n):
+        t = rng.next() % 10
+        s.append(0 if t < 4 else 1 if t < 6 else (rng.next() & 0xFFFF) if t < 7 else rep if t < 8 else rng.fr())
+    b = ctx.bases_g2_synthetic(n)
+    q = ec.g2_mul(0xC0FFEE)
+    exp = ec.pt_add(ec.Fq2, ec.g2_mul(sum(s) % R), ec.g2_mul(sum(i * v for i, v in enumerate(s)) % R, q))
+    for _ in range(2):  # the second run finds the tickets of the first one reset
+        assert ctx.msm_g2(frs(s), b) == ec.g2_to_bytes(exp)
+    b.free()
+
+
 @pytest.mark.parametrize("n", [300, 5000])
 def test_msm_g2_structured_vs_closed_form(ctx, n):
     rng = ec.SplitMix64(7 * n)
