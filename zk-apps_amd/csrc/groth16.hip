@@ -173,6 +173,13 @@ static bool prover_sort_side() {
   static const bool v = getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '1';
   return v;
 }
+// largest domain (log2) whose single proofs take the latency path: h sorted ahead of the accumulations, A, B1, L and H
+// accumulated in one launch (ZKMI_SOLO_MAX_LOG).  Measured, same box: 2^17 5.3 vs 5.4 ms, 2^18 9.3 -> 8.9, 2^19 16.2 -> 14.1,
+// 2^20 20.9 -> 22.9 (there the z accumulations should not wait for the transforms: the default path starts them at once)
+static uint32_t prover_solo_max_log() {
+  static const uint32_t v = getenv("ZKMI_SOLO_MAX_LOG") ? (uint32_t)atoi(getenv("ZKMI_SOLO_MAX_LOG")) : 19u;
+  return v;
+}
 static bool prover_aux_split() {
   static const bool v = !(getenv("ZKMI_AUX_SPLIT") && getenv("ZKMI_AUX_SPLIT")[0] == '0');
   return v;
@@ -746,7 +753,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
   // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
   static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
-  const bool spread = spread_on && G == 1 && pk->log_n <= 16 && !sort_side && sh;
+  const bool spread = spread_on && G == 1 && pk->log_n <= (solo ? prover_solo_max_log() : 16u) && !sort_side && sh;
   // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
   if (spread) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
   const hipStream_t sb1 = spread ? ctx->stream_copy : st, sl = spread ? ctx->stream_acc3 : st;
@@ -794,7 +801,7 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   // one small proof (the solo case of prove_enqueue_z): h is already sorted (front stream, right behind the transforms) and
   // normally accumulated in the same launch as A, B1 and L; otherwise the H accumulation runs on the copy stream, idle by now
   static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
-  const bool spread = solo && spread_on && G == 1 && pk->log_n <= 16 && !prover_sort_side() && pk->shared;
+  const bool spread = solo && spread_on && G == 1 && pk->log_n <= prover_solo_max_log() && !prover_sort_side() && pk->shared;
   if (spread && ctx->h_fused) return ZKMI_OK;  // accumulated with A, B1 and L
   hipStream_t st = spread ? ctx->stream_copy : ctx->stream;
   if (spread) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));  // the sort of h, queued on the front stream
