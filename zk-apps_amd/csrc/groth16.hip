@@ -58,6 +58,10 @@ struct MatSet {
 // blockIdx.z = matrix (A, B, C in ONE launch: the three mat-vecs, like the three transforms after them, are queued as
 // one grid each -- every extra launch on the front stream is one more hand-over between it and the accumulations,
 // DESIGN.md 4.10); the outputs of the three matrices lie back to back (stride = proofs x n)
+// S lanes per row (adjacent lanes, partial sums added over __shfl_xor): 1 for throughput; 8 for one small proof, whose
+// mat-vec lasts as long as its longest row on one lane (the Poseidon relation has rows of ~100 terms: 0.12 ms at the head of
+// the latency chain, section 4.11)
+template <int S>
 __global__ void __launch_bounds__(256)
 k_matvec(MatSet ms, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uint32_t nc, uint32_t n, uint32_t n_pub,
          uint32_t n_vars) {
@@ -70,14 +74,25 @@ k_matvec(MatSet ms, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uin
   // blockIdx.y = proof of a group: assignments of n_vars elements and outputs of n elements back to back
   z += (size_t)blockIdx.y * n_vars;
   out += (size_t)blockIdx.y * n;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = gi / S, lane = gi % S;
+  if (i >= n) return;  // the S lanes of a row leave together
   Fr28 acc = Fr28::zero();
   if (i < nc) {
     const uint32_t b = rowptr[i], e = rowptr[i + 1];
-    for (uint32_t k = b; k < e; k++) acc = acc + ld28(val + k) * ld28(z + col[k]);
-  } else if (is_a && i < nc + n_pub) {
+    for (uint32_t k = b + lane; k < e; k += S) acc = acc + ld28(val + k) * ld28(z + col[k]);
+  } else if (is_a && i < nc + n_pub && lane == 0) {
     acc = ld28(z + (i - nc));
+  }
+  if constexpr (S > 1) {
+#pragma unroll
+    for (int o = S / 2; o > 0; o >>= 1) {
+      Fr28 t;
+#pragma unroll
+      for (int q = 0; q < Fr28::NL; q++) t.l[q] = __shfl_xor(acc.l[q], o);
+      acc = acc + t;
+    }
+    if (lane != 0) return;
   }
   st28(out + i, acc);
 }
@@ -642,7 +657,10 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     ms.col[m] = pk->d_col[m];
     ms.val[m] = pk->d_val[m];
   }
-  hipLaunchKernelGGL(k_matvec, dim3((N + 63) / 64, G, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
+  if (G == 1 && pk->log_n <= 16)
+    hipLaunchKernelGGL(k_matvec<8>, dim3((8 * N + 63) / 64, 1, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
+  else
+    hipLaunchKernelGGL(k_matvec<1>, dim3((N + 63) / 64, G, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
   Fr28* const d_b = pk->d_a + (size_t)N * G;  // the layout follows the size of THIS group, not the key's maximum
   Fr28* const d_c = pk->d_a + 2 * (size_t)N * G;
   hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 64) / 64, G), dim3(64), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
