@@ -794,7 +794,8 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     // set unless n_vars is far below N; then H goes by itself (prove_enqueue_h).
     ZK_HIP(ctx, ctx->g2.run_device(sz, pk->b2_tab, ctx->stream_g2, rc2, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
     const MsmPlan &pz = sz.plan, &ph = ctx->sort_h.plan;
-    ctx->h_fused = pz.nwin == ph.nwin && pz.nb == ph.nb && pz.seg_log == ph.seg_log && pz.c == ph.c && pz.shared == ph.shared;
+    static const bool fuse_h = !(getenv("ZKMI_SOLO_FUSE_H") && getenv("ZKMI_SOLO_FUSE_H")[0] == '0');  // test switch: H by itself
+    ctx->h_fused = fuse_h && pz.nwin == ph.nwin && pz.nb == ph.nb && pz.seg_log == ph.seg_log && pz.c == ph.c && pz.shared == ph.shared;
     const MsmSort* sorts[4] = {&sz, &sz, &sz, &ctx->sort_h};
     const Affine<Fq28>* tabs[4] = {pk->a_tab, pk->b1_tab, pk->l_tab, pk->h_tab};
     // four reduction chains, four streams: the front and copy streams have nothing left to do for this proof
