@@ -773,9 +773,11 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
   const bool spread = spread_on && G == 1 && pk->log_n <= (solo ? prover_solo_max_log() : 16u) && !sort_side && sh;
   // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
-  if (spread) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
-  const hipStream_t sb1 = spread ? ctx->stream_copy : st, sl = spread ? ctx->stream_acc3 : st;
-  if (spread) {
+  // (a lone proof at the end of a batch; a proof by itself -- solo -- takes the fused launch below and needs neither)
+  const bool three_streams = spread && !solo;
+  if (three_streams) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_acc3, false));
+  const hipStream_t sb1 = three_streams ? ctx->stream_copy : st, sl = three_streams ? ctx->stream_acc3 : st;
+  if (three_streams) {
     ZK_HIP(ctx, hipStreamWaitEvent(sb1, ctx->ev_sort[par], 0));
     ZK_HIP(ctx, hipStreamWaitEvent(sl, ctx->ev_sort[par], 0));
   }

@@ -21,10 +21,12 @@
 //                           (2^15 u32 counters = 128 KiB of the CU's 160 KiB LDS)
 //   2 k_bucket_totals / k_window_scan / k_bucket_bases   prefix sums -> slots
 //   3 k_bucket_pass<true>   same tiles: LDS cursors (ds_add_rtn) -> sorted[]   (bucket scatter)
-//   4 k_accum     thread/bucket : gather affine points, XYZZ mixed adds   <- dominant
-//   5 k_segreduce thread/16 buckets : running-sum  sum (i+1) B_i  and  sum B_i
-//   6 k_treesum   block/(window, job) : plain sums (LDS tree) of segw, and of
-//                 segsum over {t : bit j of t set}
+//   4 k_accum_g1_nc / k_accum_g2_nc   thread (lane pair) per bucket : gather affine points, XYZZ mixed adds   <- dominant
+//     k_accum_heavy[_g2_split]  workgroups per heavy bucket (the last one of a split bucket adds the sub-range sums),
+//     k_accum_redo[_g2_split]   buckets that met P + P, with the complete addition
+//   5 k_segreduce thread/2..16 buckets : running-sum  sum (i+1) B_i  and  sum B_i
+//   6 k_treesum   block/(window, job[, slice]) : plain sums (LDS tree) of segw, and of
+//                 segsum over {t : bit j of t set}; small plans: slices + k_treesum_final
 //   host: window_w = P[w][0] + SEG * sum_j 2^j P[w][1+j];  result = sum_w 2^(c w) window_w
 #pragma once
 #include <stdlib.h>
