@@ -785,11 +785,15 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     // The latency of one small proof is a matter of placement: the transforms and the digit sorts are 1024-thread
     // workgroups, which find no CU while accumulation waves (168-256 registers each) sit on every SIMD -- in the trace the
     // last transform pass took 0.41 ms instead of 0.04 and the sort of h started 0.6 ms after h was ready.  So the sort
-    // of h is queued here, on the front stream right behind the transforms, and every accumulation waits for it: first
-    // everything that needs whole CUs (0.5 ms), then the five accumulations side by side.
+    // of h is queued here, on the front stream right behind the transforms, and the G1 accumulations wait for it: first
+    // everything that needs whole CUs (0.5 ms), then the accumulations side by side.
     ZK_HIP(ctx, ctx->sort_h.run_shared(pk->d_h[par], 1u << pk->log_n, ctx->stream_front, t));
     ZK_HIP(ctx, hipEventRecord(ctx->ev_sorth[par], ctx->stream_front));
-    for (hipStream_t s : {ctx->stream_g2, st}) ZK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_sorth[par], 0));
+    // (G2 does not wait: its waves have no LDS and leave the sort's 1024-thread workgroups -- 8-42 registers -- room on
+    // every SIMD; same box, ZKMI_SOLO_G2_EARLY=0 against the default: 2^14 2.45 vs 2.37 ms, 2^18 8.9 vs 8.25)
+    static const bool g2_early = !(getenv("ZKMI_SOLO_G2_EARLY") && getenv("ZKMI_SOLO_G2_EARLY")[0] == '0');
+    if (!g2_early) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sorth[par], 0));
+    ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
     // A, B1, L and H as ONE launch on the main stream, G2 beside it.  (On separate streams the grids did not start
     // together: a kernel that cannot place all its workgroups holds its dispatch pipe, and the streams sharing that pipe
     // wait -- L started when A had finished, H when the G2 heavy-bucket kernel had.)  The two sorts plan the same bucket
