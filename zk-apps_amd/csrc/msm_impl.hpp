@@ -702,7 +702,7 @@ __device__ __forceinline__ XYZZ<Fq2P> pair_tree_sum(XYZZ<Fq2P> acc, XYZZ<Fq2_28>
   return acc;
 }
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(MSM_TREE_T, 2)
+__global__ void __launch_bounds__(2 * MSM_TREE_T, 2)
 k_treesum_g2_split(const XYZZ<Fq2_28>* __restrict__ segsum, const XYZZ<Fq2_28>* __restrict__ segw, uint32_t segs_per_win,
                    XYZZ<Fq2>* __restrict__ partial, int plain_job, XYZZ<Fq2_28>* __restrict__ stage) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1162,8 +1162,15 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         while (tf < 2 * nchunk) tf <<= 1;
         hipLaunchKernelGGL(k_treesum_final_g2_split<0>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf / 2, st_reduce, stg, nchunk, dp);
       } else {
-        hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                           ssum, sw, segs_per_win, dp, plain_job, stg);
+        // big plans: the same lane-pair kernel, 128 pairs per job (the unsplit form's 330-register additions made this the
+        // slowest link of a proof's tail: 16 + 7 dependent additions of 45-60 us); ZKMI_G2_TREE_SPLIT=0: the unsplit kernel
+        static const bool tree_split = !(getenv("ZKMI_G2_TREE_SPLIT") && getenv("ZKMI_G2_TREE_SPLIT")[0] == '0');
+        if (tree_split)
+          hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+                             ssum, sw, segs_per_win, dp, plain_job, stg);
+        else
+          hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+                             ssum, sw, segs_per_win, dp, plain_job, stg);
       }
     } else {
       hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
