@@ -367,6 +367,125 @@ k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
   }
   store_vec(buckets + b, acc);
 }
+// acc += o for acc, o != O; false when the sum needs the complete group law (o = +-acc): same contract as madd_generic
+template <class F>
+__device__ __forceinline__ bool add_generic(XYZZ<F>& a, const XYZZ<F>& o) {
+  F u1 = a.x * o.zz;
+  F u2 = o.x * a.zz;
+  F s1 = a.y * o.zzz;
+  F s2 = o.y * a.zzz;
+  F pp_ = f_sub_lazy(u2, u1);
+  F r = f_sub_lazy(s2, s1);
+  F pp = pp_.sqr();
+  F rr = r.sqr();
+  if (pp.is_zero()) return false;
+  F ppp = pp_ * pp;
+  F q = u1 * pp;
+  F x3 = f_x3(rr, ppp, q);
+  a.y = f_mul_sub_mul(r, f_sub_lazy(q, x3), s1, ppp);
+  a.x = x3;
+  a.zz = a.zz * o.zz * pp;
+  a.zzz = a.zzz * o.zzz * ppp;
+  return true;
+}
+// Two adjacent lanes per bucket (even lane: entries beg, beg + 2, ...; odd lane: beg + 1, beg + 3, ...), the even lane adds
+// the two partial sums at the end.  For ONE small proof: its accumulation launch is 0.3 ms of chip time but lasts as long as
+// the fullest bucket's chain of dependent additions (25-35 of them, 0.65 ms); two lanes halve the chain (section 4.11).
+// Always the multi form (table / bucket array / redo list / sort per blockIdx.y); a doubling in either half or in the
+// final addition sends the bucket to the redo list like the one-lane kernel does.
+template <class F, int BW>
+__global__ void __launch_bounds__(64 * BW, 2)
+k_accum_g1_split2(const AccumArgs<F, true> args, uint32_t total_buckets) {
+  const Affine<F>* __restrict__ const bases = args.bases();
+  XYZZ<F>* __restrict__ const buckets = args.buckets();
+  uint32_t* __restrict__ const redo = args.redo();
+  const uint32_t* __restrict__ const begin = args.sort().begin;
+  const uint32_t* __restrict__ const count = args.sort().count;
+  const uint32_t* __restrict__ const perm = args.sort().perm;
+  const uint32_t* __restrict__ const sorted = args.sort().sorted;
+  const uint32_t heavy_thr = args.sort().heavy_thr;
+  constexpr int CHUNKS = sizeof(Affine<F>) / 16;
+  __shared__ uint4 tile[BW][CHUNKS][64];  // [wave][chunk][lane]
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt >> 1, sub = gt & 1u;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (t >= total_buckets) return;  // pair-uniform from here on
+  const uint32_t b = perm[t];
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
+  const uint32_t beg = begin[b], end = beg + cnt;
+  auto fetch = [&](uint32_t v) {
+    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[wave][q][0], 16, 0, 0);
+  };
+  auto take = [&](Affine<F>& p) {
+    uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) d[q] = tile[wave][q][lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  bool has = false, bad = false;
+  uint32_t j = beg + sub;
+  for (; j < end; j += 2) {  // first entry of this lane that is not the point at infinity starts its accumulator
+    const uint32_t v = sorted[j];
+    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+    if (affine_is_zero_words(p)) continue;
+    if (v >> 31) p.y = p.y.neg();
+    acc.x = p.x;
+    acc.y = p.y;
+    acc.zz = F::one();
+    acc.zzz = F::one();
+    has = true;
+    j += 2;
+    break;
+  }
+  uint32_t v_cur = 0, v_next = 0;
+  if (j < end) {
+    v_cur = sorted[j];
+    fetch(v_cur);
+    if (j + 2 < end) v_next = sorted[j + 2];
+  }
+  for (; j < end; j += 2) {
+    Affine<F> p;
+    take(p);
+    const uint32_t v = v_cur;
+    if (j + 2 < end) {
+      fetch(v_next);
+      v_cur = v_next;
+      if (j + 4 < end) v_next = sorted[j + 4];
+    }
+    if (affine_is_zero_words(p)) continue;
+    if (!madd_generic(acc, p, 0u - (v >> 31))) {
+      bad = true;
+      break;
+    }
+  }
+  // the partner's state and partial sum
+  const uint32_t flags = (has ? 1u : 0u) | (bad ? 2u : 0u);
+  const uint32_t pflags = (uint32_t)__shfl_xor((int)flags, 1);
+  XYZZ<F> o;
+#pragma unroll
+  for (int i = 0; i < F::NL; i++) {
+    o.x.l[i] = __shfl_xor(acc.x.l[i], 1);
+    o.y.l[i] = __shfl_xor(acc.y.l[i], 1);
+    o.zz.l[i] = __shfl_xor(acc.zz.l[i], 1);
+    o.zzz.l[i] = __shfl_xor(acc.zzz.l[i], 1);
+  }
+  if (sub != 0) return;
+  bool redo_it = ((flags | pflags) & 2u) != 0;
+  if (!redo_it) {
+    if (has && (pflags & 1u)) redo_it = !add_generic(acc, o);
+    else if (!has) acc = (pflags & 1u) ? o : XYZZ<F>::infinity();
+  }
+  if (redo_it)
+    redo[1 + atomicAdd(redo, 1u)] = b;  // k_accum_redo recomputes the bucket with the complete addition
+  else
+    store_vec(buckets + b, acc);
+}
+
 // G2, lane pair per bucket (see k_accum_g2_split)
 template <int W, int BW>
 __global__ void __launch_bounds__(64 * BW, W)
@@ -1066,7 +1185,11 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       set.redo_[m] = redo_of(k);
       set.sort_[m] = view_of(k);
     }
-    if (accum_mode == 3)
+    // small plans (one small proof): two lanes per bucket (ZKMI_SOLO_SPLIT=0: one)
+    static const bool split2 = !(getenv("ZKMI_SOLO_SPLIT") && getenv("ZKMI_SOLO_SPLIT")[0] == '0');
+    if (split2 && tot_b <= (1u << 16))
+      hipLaunchKernelGGL((k_accum_g1_split2<F, 1>), dim3((2 * tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
+    else if (accum_mode == 3)
       hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
     else
       hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
