@@ -38,6 +38,30 @@ b.prepare()
 h.update(ctx.msm_g1(sc.tobytes(), b))
 h.update(ctx.msm_g1(wl.tobytes(), b))
 b.free()
+# degenerate inputs (the pattern of tests/test_gpu_parity.py::test_msm_degenerate_bases_and_scalars) through the plain and the
+# prepared G1 MSM: equal points with equal scalars (P + P), P + (-P), points at infinity, scalars 0, 1, r - 1
+FQ = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+FR = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def g1_neg(pt):  # 96 bytes x || y, little-endian canonical
+    y = int.from_bytes(pt[48:], "little")
+    return pt[:48] + ((FQ - y) % FQ).to_bytes(48, "little")
+
+
+G = z.g1_generator()
+P2, P3 = z.g1_mul(G, (2).to_bytes(32, "little")), z.g1_mul(G, (3).to_bytes(32, "little"))
+pts = [G, G, g1_neg(G), G, None, P2, g1_neg(P2), P3, P3]
+kk = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890AB % FR
+for reps, scal in ((1, [kk] * 9), (1, [kk, kk, kk, FR - 1, 5, 0, 1, FR - 1, FR - 1]), (400, [kk] * 9), (37, [kk, 1, kk, 1, 0, 1, 1, kk, FR - 1])):
+    raw_b = b"".join(pt if pt is not None else bytes(96) for pt in pts * reps)
+    raw_s = b"".join(int(v).to_bytes(32, "little") for v in scal * reps)
+    for prepared in (False, True):
+        bb = ctx.bases_g1(raw_b)
+        if prepared:
+            bb.prepare()
+        h.update(ctx.msm_g1(raw_s, bb))
+        bb.free()
 for lg, count in ((13, 70), (17, 9)):
     r1, wits = bench.relation_and_witness(z, "poseidon", lg, [lg, lg + 1])
     prng = bench.SplitMix64(lg)

@@ -1156,6 +1156,9 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   };
 
   // ---- the accumulation ----
+  // test switch: a lone MSM through the multi-MSM launch too (so that the generic MSM entry points, with their degenerate
+  // inputs -- repeated bases, P + (-P), points at infinity --, reach k_accum_g1_split2 / the MULTI kernel form)
+  static const bool force_multi = getenv("ZKMI_FORCE_MULTI") != nullptr;
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     for (int m = 0; m < nm; m++) {
@@ -1176,7 +1179,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
                            sort.perm, sort.sorted, bk, tot_b, heavy_thr);
     }
-  } else if (nm > 1 && nocall) {
+  } else if ((nm > 1 || force_multi) && nocall) {
     AccumArgs<F, true> set;
     for (int m = 0; m < MSM_MULTI_MAX; m++) {
       const int k = m < nm ? m : 0;
