@@ -331,6 +331,10 @@ int32_t zkmi_update_note_witness_values_host(uint32_t log_n, int32_t op_kind, co
  *   alpha_g1 (96) | beta_g2 (192) | gamma_g2 (192) | delta_g2 (192) | n_pub x gamma_abc_g1 (96 each). */
 int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t toxic[160], zkmi_pk** out_pk,
                            uint8_t* vk_out, uint64_t vk_cap);
+/* Proofs of small domains travel through the batch prover in groups (one digit sort and one accumulation launch per
+ * query for up to 64 proofs).  group = 0: the library's choice (about 2^20 constraints per group), 1: never group,
+ * 2..64: at most that many (clamped to what the key's domain allows).  Applies to keys created on `ctx` AFTER the call. */
+int32_t zkmi_ctx_set_group_size(zkmi_ctx* ctx, uint32_t group);
 /* Load a proving key from host arrays in wire format (drop-in for a key
  * produced by another Groth16 implementation). */
 int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t alpha_g1[96], const uint8_t beta_g1[96],

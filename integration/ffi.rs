@@ -78,6 +78,7 @@ extern "C" {
     pub fn zkmi_fr_reduce(input: *const u8, out: *mut u8) -> i32;
 
     // keys
+    pub fn zkmi_ctx_set_group_size(ctx: *mut zkmi_ctx, group: u32) -> i32;
     pub fn zkmi_groth16_setup(ctx: *mut zkmi_ctx, r1cs: *const zkmi_r1cs, toxic: *const u8, out_pk: *mut *mut zkmi_pk, vk_out: *mut u8, vk_cap: u64) -> i32;
     pub fn zkmi_ark_pk_load(ctx: *mut zkmi_ctx, r1cs: *const zkmi_r1cs, buf: *const u8, len: u64, compressed: i32, check_curve: i32,
                             out_pk: *mut *mut zkmi_pk, out_vk: *mut u8, vk_cap: u64) -> i32;

@@ -8,7 +8,8 @@ OUT=${1:-gpurun_out/accum_ab}
 shift
 mkdir -p "$OUT"
 CFGS=("$@")
-[ ${#CFGS[@]} -eq 0 ] && CFGS=("libzkmi 0 0" "libzkmi 2 2" "libzkmi 3 2" "libzkmi 3 3" "libzkmi_fips 3 2" "libzkmi_fips 3 3")
+# (the switches exist in the A/B library only: csrc/tune.hpp; libzkmi = the product, which ignores them)
+[ ${#CFGS[@]} -eq 0 ] && CFGS=("libzkmi 3 2" "libzkmi_exp 0 0" "libzkmi_exp 2 2" "libzkmi_exp 3 2" "libzkmi_exp 3 3")
 for CFG in "${CFGS[@]}"; do
   set -- $CFG
   LIB=$1; G1=$2; G2=$3

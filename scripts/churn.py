@@ -2,7 +2,7 @@
 
 Random interleaving, on ONE context (plus a short-lived second one), of everything that allocates, re-reserves or
 frees workspaces: trusted setups of sizes 2^13 .. 2^max in shuffled order (big -> small transitions forced), forced
-group sizes 64/32/16/8/1 (ZKMI_GROUP is read per key), batch proofs with partial last groups, single proofs from
+group sizes 64/32/16/8/1 (zkmi_ctx_set_group_size, per key), batch proofs with partial last groups, single proofs from
 device and host witnesses, the unsatisfied-witness error path, generic MSMs (plain, prepared, >= 2^21 terms so the
 sort buffers grow past what a grouped key reserved), NTTs, BN254 calls, key frees in random order.  Every proof is
 compared byte for byte with the first proof ever made from the same (size, witness, r, s) -- keys are re-created
@@ -107,12 +107,9 @@ def main():
         last_setup_lg[0] = lg
         r1, _, _, _ = rel(lg)
         g = rnd.choice([None, None, 64, 32, 16, 8, 1])
-        if g is None:
-            os.environ.pop("ZKMI_GROUP", None)
-        else:
-            os.environ["ZKMI_GROUP"] = str(g)
+        ctx.set_group_size(0 if g is None else g)
         pk, vk = ctx.groth16_setup(r1, toxic(lg))
-        os.environ.pop("ZKMI_GROUP", None)
+        ctx.set_group_size(0)
         keys.append({"lg": lg, "pk": pk, "vk": vk, "group": g})
         stats["setup"] += 1
         if args.verbose:

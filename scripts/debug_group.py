@@ -22,7 +22,7 @@ for rep in range(3):
     grouped = ctx.groth16_prove_batch_dev(pk, [b.data_ptr() for b in bufs], rs, ss)
     bad = [i for i, ((_, pub), pf) in enumerate(zip(cases, grouped)) if not zk.groth16_verify(vk, frs(pub), pf)]
     print("rep", rep, "bad proofs:", bad)
-os.environ["ZKMI_GROUP"] = "1"
+ctx.set_group_size(1)
 pk1, vk1 = ctx.groth16_setup(r1, toxic)
 single = ctx.groth16_prove_batch_dev(pk1, [b.data_ptr() for b in bufs], rs, ss)
 print("differs from one-by-one:", [i for i in range(count) if grouped[i] != single[i]])

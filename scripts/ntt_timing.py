@@ -1,5 +1,5 @@
 """Fr NTT timing on an idle GPU: HIP-event time of the transform's passes (zkmi_prof, phase "ntt") for the public
-entry point, per size.  ZKMI_NTT_RB=0|1|2 selects the pass kernels (see ntt.hip).  Usage: python scripts/ntt_timing.py [lg ...]"""
+entry point, per size.  ZKMI_LIB=zk-apps_amd/libzkmi_exp.so ZKMI_NTT_RB=0|1|2 selects the pass kernels of the A/B library (see ntt.hip).  Usage: python scripts/ntt_timing.py [lg ...]"""
 import sys
 
 sys.path.insert(0, ".")

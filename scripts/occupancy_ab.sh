@@ -4,6 +4,7 @@
 OUT=${1:-gpurun_out/occ_ab}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export ZKMI_LIB=$PWD/zk-apps_amd/libzkmi_exp.so  # the switches exist in the A/B library only (csrc/tune.hpp)
 for CFG in "256 0" "64 0" "256 4" "64 4" "64 2" "64 8"; do
   set -- $CFG
   TAG=b$1_r$2

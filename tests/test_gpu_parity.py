@@ -1358,7 +1358,7 @@ def test_soak_script_short_run():
 def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     """Small domains (the relation's natural size, BASELINE config 0): the batch entry point proves up to 64 proofs as
     ONE group (one digit sort, one accumulation launch per query, batched NTT passes).  70 proofs at N = 2^13 (two
-    groups, the second partial) must equal, byte for byte, a key that never groups (ZKMI_GROUP=1) and verify."""
+    groups, the second partial) must equal, byte for byte, a key that never groups (zkmi_ctx_set_group_size 1) and verify."""
     import os
 
     import torch
@@ -1379,11 +1379,11 @@ def test_grouped_small_domain_prover_matches_one_by_one(ctx, zk):
     pk, vk = ctx.groth16_setup(r1, toxic)
     grouped = ctx.groth16_prove_batch_dev(pk, [b.data_ptr() for b in bufs], rs, ss)
     pk.free()
-    os.environ["ZKMI_GROUP"] = "1"
+    ctx.set_group_size(1)
     try:
         pk1, vk1 = ctx.groth16_setup(r1, toxic)
     finally:
-        del os.environ["ZKMI_GROUP"]
+        ctx.set_group_size(0)
     assert vk1 == vk
     single = ctx.groth16_prove_batch_dev(pk1, [b.data_ptr() for b in bufs], rs, ss)
     pk1.free()

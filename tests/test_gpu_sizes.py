@@ -283,22 +283,37 @@ VARIANTS = [
     {"ZKMI_NTT_LOCAL3": "1", "ZKMI_WITNESS_BATCH": "0"},
     {"ZKMI_SORT_FINE": "0"}, {"ZKMI_SORT_FINE": "2"}, {"ZKMI_SORT_STAGE": "0"},
     {"ZKMI_HEAVY_ON": "0"}, {"ZKMI_HEAVY_ON": "1"},
-    {"ZKMI_ACCUM": "0", "ZKMI_ACCUM_G2": "0"}, {"ZKMI_AUX_SPLIT": "0", "ZKMI_SORT_SIDE": "1"},
+    {"ZKMI_ACCUM": "0", "ZKMI_ACCUM_G2": "0"}, {"ZKMI_ACCUM": "2", "ZKMI_ACCUM_G2": "3"}, {"ZKMI_AUX_SPLIT": "0", "ZKMI_SORT_SIDE": "1"},
+    {"ZKMI_LH_MERGE": "0"}, {"ZKMI_LH_MERGE": "0", "ZKMI_AUX_SPLIT": "0"},
     {"ZKMI_SOLO_FUSE_H": "0", "ZKMI_SOLO_G2_EARLY": "0"}, {"ZKMI_SOLO_MAX_LOG": "12", "ZKMI_G2_TREE_SPLIT": "0"}, {"ZKMI_SPREAD": "0"}, {"ZKMI_SOLO_SPLIT": "0"}, {"ZKMI_FORCE_MULTI": "1"}, {"ZKMI_FORCE_MULTI": "1", "ZKMI_SOLO_SPLIT": "0"},
 ]
+EXP_LIB = os.path.join(ROOT, "zk-apps_amd", "libzkmi_exp.so")
+
+
+def _variant_digest(env_extra, lib=None):
+    env = dict(os.environ, **env_extra)
+    if lib:
+        env["ZKMI_LIB"] = lib
+    else:
+        env.pop("ZKMI_LIB", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "variant_check.py")], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    line = [l for l in p.stdout.splitlines() if l.startswith("VARIANT_DIGEST")]
+    assert p.returncode == 0 and line, (env_extra, lib, p.stdout[-1500:], p.stderr[-3000:])
+    return line[0].split()[1]
 
 
 def test_ab_switches_do_not_change_any_result():
-    """Every A/B switch that selects another kernel or schedule (register-blocked NTT passes, fine-partition / record
-    digit sort, where the heavy-bucket kernels run, first-generation accumulation kernels, stream layout) must give the
-    same bytes: scripts/variant_check.py (NTTs of five sizes in four modes, four MSMs, 79 proofs at 2^13 and 2^17) is run
-    in a child process per variant -- the switches are read once per process -- and the digests are compared."""
-    digests = {}
-    for env_extra in VARIANTS:
-        env = dict(os.environ, **env_extra)
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "variant_check.py")], capture_output=True, text=True, timeout=900,
-                           cwd=ROOT, env=env)
-        line = [l for l in p.stdout.splitlines() if l.startswith("VARIANT_DIGEST")]
-        assert p.returncode == 0 and line, (env_extra, p.stdout[-1500:], p.stderr[-3000:])
-        digests[str(env_extra)] = line[0].split()[1]
-    assert len(set(digests.values())) == 1, digests
+    """The product library has one schedule and reads no tuning switch (csrc/tune.hpp); the A/B library libzkmi_exp.so
+    (`make experiments`) carries the switches and the retired kernels they select (register-blocked NTT passes,
+    record / direct-scatter digit sorts, where the heavy-bucket kernels run, first-generation accumulation kernels, stream
+    layouts, separate L / H bucket sets).  Every variant of it must give the product's bytes: scripts/variant_check.py (NTTs
+    of five sizes in four modes, four MSMs, 79 proofs at 2^13 and 2^17) runs in a child process per variant -- the switches
+    are read once per process -- and the digests are compared.  The product library is run WITH a hostile environment too:
+    it must not react to any of the switches."""
+    assert os.path.exists(EXP_LIB), "zk-apps_amd/libzkmi_exp.so missing: run __graft_entry__.build() (make experiments)"
+    want = _variant_digest({})
+    hostile = {k: v for d in VARIANTS for k, v in d.items()}
+    assert _variant_digest(hostile) == want, "the product library reacted to a tuning variable"
+    digests = {str(v): _variant_digest(v, EXP_LIB) for v in VARIANTS}
+    assert set(digests.values()) == {want}, (want, digests)

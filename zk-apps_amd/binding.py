@@ -724,6 +724,10 @@ class Context:
         return bytes(out)[: 96 * nwin.value], nwin.value, cbits.value
 
     # Groth16
+    def set_group_size(self, group):
+        """proofs per group for keys created next on this context (0 = automatic, 1 = never group)"""
+        self._chk(self.lib.zkmi_ctx_set_group_size(self.h, C.c_uint32(group)))
+
     def groth16_setup(self, r1cs, toxic):
         assert len(toxic) == 160
         cap = 672 + 96 * r1cs.n_pub

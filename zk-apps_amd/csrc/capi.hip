@@ -140,7 +140,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
       hipStreamCreateWithPriority(&c->stream_aux3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_g2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream_front, hipStreamNonBlocking,
-                                  (getenv("ZKMI_FRONT_PRIO") && getenv("ZKMI_FRONT_PRIO")[0] == '0') ? 0 : prio_hi) != hipSuccess ||
+                                  ZK_TUNE("ZKMI_FRONT_PRIO", 1) == 0 ? 0 : prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess) {  // stream_sort / heavy / acc3: lazily
     delete c;
     return ZKMI_ERR_HIP;

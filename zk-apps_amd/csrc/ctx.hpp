@@ -24,7 +24,15 @@ struct zkmi_ctx {
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
   hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
   unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes
-  bool h_fused = false;  // single small proof: the first half queued the H accumulation together with A, B1 and L (groth16.hip)
+  uint32_t group_override = 0;  // zkmi_ctx_set_group_size: proofs per group for keys created next (0 = automatic)
+  // How the H MSM of the proof (group) in ring slot `par` runs: decided ONCE by prove_enqueue_z, consumed by prove_enqueue_h
+  // and prove_finish (groth16.hip).
+  //   H_OWN    its own sort, bucket set and reduction, queued by the second half
+  //   H_INTO_L as H_OWN, but accumulated INTO the L MSM's buckets: L + H leave one reduction (slot of H), L has no result
+  //   H_SORTED one small proof: sorted by the first half behind the transforms, accumulated by the second half
+  //   H_FUSED  one small proof: sorted and accumulated by the first half, in one launch with A, B1 and L
+  enum HMode { H_OWN = 0, H_INTO_L = 1, H_SORTED = 2, H_FUSED = 3 };
+  int h_mode[PROOF_RING] = {H_OWN, H_OWN, H_OWN};
   std::string err;
   zkmi::PhaseTimer prof;
   std::map<int, std::unique_ptr<zkmi::NttDomain>> domains;

@@ -26,6 +26,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
+#include "tune.hpp"
 #include "pairing.hpp"
 #include "r1cs.hpp"
 
@@ -181,23 +182,24 @@ k_fixed_base(const uint32_t* __restrict__ scalars, const Affine<F>* __restrict__
 
 using namespace zkmi;
 
-// Scheduling switches of the prover (measured in DESIGN.md 4.4; both are within noise of each other at N = 2^20):
+// Scheduling switches of the prover -- A/B library only (tune.hpp); the product library compiles the defaults in.
+// Measured in DESIGN.md 4.4 (both are within noise of each other at N = 2^20):
 //   ZKMI_SORT_SIDE=1  digit sorts on their own high-priority stream into ping-pong z buffers (default: main stream)
-//   ZKMI_AUX_SPLIT=0  all five reductions of a proof on one stream (default: three streams, A L | B1 H | B2)
-static bool prover_sort_side() {
-  static const bool v = getenv("ZKMI_SORT_SIDE") && getenv("ZKMI_SORT_SIDE")[0] == '1';
-  return v;
-}
+//   ZKMI_AUX_SPLIT=0  all reductions of a proof on one stream (default: three streams)
+static bool prover_sort_side() { return ZK_TUNE("ZKMI_SORT_SIDE", 0) == 1; }
 // largest domain (log2) whose single proofs take the latency path: h sorted ahead of the accumulations, A, B1, L and H
 // accumulated in one launch (ZKMI_SOLO_MAX_LOG).  Measured, same box: 2^17 5.3 vs 5.4 ms, 2^18 9.3 -> 8.9, 2^19 16.2 -> 14.1,
 // 2^20 20.9 -> 22.9 (there the z accumulations should not wait for the transforms: the default path starts them at once)
 static uint32_t prover_solo_max_log() {
-  static const uint32_t v = getenv("ZKMI_SOLO_MAX_LOG") ? (uint32_t)atoi(getenv("ZKMI_SOLO_MAX_LOG")) : 19u;
-  return v;
+  const int v = ZK_TUNE("ZKMI_SOLO_MAX_LOG", 19);
+  return (uint32_t)(v < 0 ? 0 : v > 28 ? 28 : v);
 }
-static bool prover_aux_split() {
-  static const bool v = !(getenv("ZKMI_AUX_SPLIT") && getenv("ZKMI_AUX_SPLIT")[0] == '0');
-  return v;
+static bool prover_aux_split() { return ZK_TUNE("ZKMI_AUX_SPLIT", 1) != 0; }
+
+// two digit sorts whose bucket arrays can be added bucket by bucket: same digit width, partitions and segment length
+static bool same_bucket_set(const MsmPlan& a, const MsmPlan& b) {
+  return a.shared == b.shared && a.c == b.c && a.nwin == b.nwin && a.nb == b.nb && a.seg_log == b.seg_log &&
+         a.vec_parts == b.vec_parts && a.ndigits == b.ndigits;
 }
 
 struct zkmi_pk {
@@ -290,12 +292,12 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = hipMalloc(&pk->h28, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   if ((e = hipMalloc(&pk->h28_rev, sizeof(Affine<Fq28>) * N)) != hipSuccess) return e;
   // group size: about 2^20 constraints in flight per group, at most 64 proofs (and at most 64 bucket partitions:
-  // a proof above 2^16 constraints has several).  ZKMI_GROUP overrides (1 = never group).
+  // a proof above 2^16 constraints has several).  zkmi_ctx_set_group_size overrides (1 = never group).
   {
     uint32_t g = r->log_n <= 19 ? (1u << (r->log_n >= 14 ? 20 - r->log_n : 6)) : 1u;
     if (g > 64) g = 64;
-    const char* env = getenv("ZKMI_GROUP");
-    if (env && atoi(env) >= 1 && atoi(env) <= 64 && (r->log_n <= 19 || atoi(env) == 1)) g = (uint32_t)atoi(env);
+    const uint32_t forced = ctx->group_override;  // zkmi_ctx_set_group_size
+    if (forced >= 1 && forced <= 64 && (r->log_n <= 19 || forced == 1)) g = forced;
     const uint64_t capv = (1ull << r->log_n) > r->n_vars ? (1ull << r->log_n) : r->n_vars;
     const uint32_t parts = (uint32_t)msm_make_plan_shared(capv).nwin;
     while (g > 1 && g * parts > 64) g >>= 1;
@@ -356,9 +358,8 @@ static hipError_t pk_convert_queries(zkmi_pk* pk) {
   // Precomputed tables 2^(c w) * P_i for every digit position (HBM is 288 GB: ~9 GB of
   // tables at N = 2^20): all digits of a scalar then share ONE bucket set, so the digit
   // width can grow to c = 20 (13 digits instead of 16 -> 19 % fewer bucket insertions)
-  // and the host no longer walks a 255-doubling Horner chain.  ZKMI_MSM_SHARED=0 disables.
-  const char* env = getenv("ZKMI_MSM_SHARED");
-  pk->shared = !(env && env[0] == '0');
+  // and the host no longer walks a 255-doubling Horner chain.  (A/B library: ZKMI_MSM_SHARED=0 keeps the windowed schedule.)
+  pk->shared = ZK_TUNE("ZKMI_MSM_SHARED", 1) != 0;
   if (!pk->shared) pk->gmax = 1;  // groups need the digit tables (their sort emits table indices)
   if (pk->shared) {
     const uint64_t nz = pk->n_vars - 1;
@@ -599,6 +600,12 @@ int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint
   return ZKMI_OK;
 }
 
+int32_t zkmi_ctx_set_group_size(zkmi_ctx* ctx, uint32_t group) {
+  if (!ctx || group > 64) return ZKMI_ERR_BAD_ARG;
+  ctx->group_override = group;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_pk_export_g1_elems(const zkmi_pk* pk, uint8_t out_beta_g1[96], uint8_t out_delta_g1[96]) {
   if (!pk || !out_beta_g1 || !out_delta_g1) return ZKMI_ERR_BAD_ARG;
   g1_to_wire(pk->beta_g1, out_beta_g1);
@@ -673,7 +680,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   if (t) t->begin(PH_NTT, st);
   // evaluations -> coefficients (bit-reversed, scaled by g^i / N) -> evaluations on the coset
   // a, b, c together: two batched passes down, two up (3 x G vectors per launch instead of six launch pairs)
-  static const bool batch_abc = !(getenv("ZKMI_WITNESS_BATCH") && getenv("ZKMI_WITNESS_BATCH")[0] == '0');  // A/B: one transform per launch
+  const bool batch_abc = ZK_TUNE("ZKMI_WITNESS_BATCH", 1) != 0;  // A/B library: 0 = one transform per launch
   if (batch_abc) {
     ZK_HIP(ctx, dom->inverse_to_rev(pk->d_a, dom->rev_coset_n, nullptr, st, 3 * G));
     ZK_HIP(ctx, dom->forward_from_rev(pk->d_a, st, 3 * G));
@@ -734,9 +741,9 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   if (rc != ZKMI_OK) return rc;
   PhaseTimer* t = ctx->timer();
   const int s0 = 4 * par, g2s = par;
-  // ZKMI_HEAVY_ON=1: heavy-bucket kernels on their own side stream (round 2; created on first use); default: at the head
-  // of each MSM's reduction stream, 0: in line on the accumulation streams (msm_impl.hpp run_device)
-  static const bool heavy_side = getenv("ZKMI_HEAVY_ON") && getenv("ZKMI_HEAVY_ON")[0] == '1';
+  // ZKMI_HEAVY_ON=1 (A/B library): heavy-bucket kernels on their own side stream (round 2; created on first use); default:
+  // at the head of each MSM's reduction stream, 0: in line on the accumulation streams (msm_impl.hpp run_device)
+  const bool heavy_side = ZK_TUNE("ZKMI_HEAVY_ON", 2) == 1;
   if (heavy_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_heavy, false));
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
@@ -770,7 +777,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sort[par], 0));
   // one small proof cannot fill the chip with one accumulation (2^14 constraints: 256 waves for 1024 SIMDs): its
   // three G1 accumulations over z run side by side; anything bigger keeps them in line on the main stream
-  static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
+  const bool spread_on = ZK_TUNE("ZKMI_SPREAD", 1) != 0;
   const bool spread = spread_on && G == 1 && pk->log_n <= (solo ? prover_solo_max_log() : 16u) && !sort_side && sh;
   // (B1 borrows the copy stream, idle once the witness of this one proof is up; L gets a stream created on first use)
   // (a lone proof at the end of a batch; a proof by itself -- solo -- takes the fused launch below and needs neither)
@@ -791,7 +798,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     ZK_HIP(ctx, hipEventRecord(ctx->ev_sorth[par], ctx->stream_front));
     // (G2 does not wait: its waves have no LDS and leave the sort's 1024-thread workgroups -- 8-42 registers -- room on
     // every SIMD; same box, ZKMI_SOLO_G2_EARLY=0 against the default: 2^14 2.45 vs 2.37 ms, 2^18 8.9 vs 8.25)
-    static const bool g2_early = !(getenv("ZKMI_SOLO_G2_EARLY") && getenv("ZKMI_SOLO_G2_EARLY")[0] == '0');
+    const bool g2_early = ZK_TUNE("ZKMI_SOLO_G2_EARLY", 1) != 0;
     if (!g2_early) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_g2, ctx->ev_sorth[par], 0));
     ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
     // A, B1, L and H as ONE launch on the main stream, G2 beside it.  (On separate streams the grids did not start
@@ -800,24 +807,36 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     // set unless n_vars is far below N; then H goes by itself (prove_enqueue_h).
     ZK_HIP(ctx, ctx->g2.run_device(sz, pk->b2_tab, ctx->stream_g2, rc2, t, PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
     const MsmPlan &pz = sz.plan, &ph = ctx->sort_h.plan;
-    static const bool fuse_h = !(getenv("ZKMI_SOLO_FUSE_H") && getenv("ZKMI_SOLO_FUSE_H")[0] == '0');  // test switch: H by itself
-    ctx->h_fused = fuse_h && pz.nwin == ph.nwin && pz.nb == ph.nb && pz.seg_log == ph.seg_log && pz.c == ph.c && pz.shared == ph.shared;
+    const bool fuse_h = ZK_TUNE("ZKMI_SOLO_FUSE_H", 1) != 0;  // A/B library test switch: 0 = H by itself
+    const bool fused = fuse_h && same_bucket_set(pz, ph);
+    ctx->h_mode[par] = fused ? zkmi_ctx::H_FUSED : zkmi_ctx::H_SORTED;
     const MsmSort* sorts[4] = {&sz, &sz, &sz, &ctx->sort_h};
     const Affine<Fq28>* tabs[4] = {pk->a_tab, pk->b1_tab, pk->l_tab, pk->h_tab};
     // four reduction chains, four streams: the front and copy streams have nothing left to do for this proof
     const hipStream_t reds[4] = {ra, rb, ctx->stream_front, ctx->stream_copy};
     const int slots4[4] = {s0 + 0, s0 + 1, s0 + 2, s0 + 3};
-    ZK_HIP(ctx, ctx->g1.run_device_multi(sorts, tabs, ctx->h_fused ? 4 : 3, st, reds, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, slots4, sth));
+    ZK_HIP(ctx, ctx->g1.run_device_multi(sorts, tabs, fused ? 4 : 3, st, reds, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, slots4, sth));
     return ZKMI_OK;
   }
+  // L and H only ever appear added together (C = s A + r B1 - rs delta + L + H): when the sorts of z and of h plan the same
+  // bucket set, the L accumulation stops after its redo pass and the H accumulation of the second half continues in L's
+  // bucket array -- one segment-sum / tree-sum pair and one host combine instead of two (0.14 of 8.1 x 10^9 instructions of
+  // a 2^20 proof, which is bound by the instruction issue rate: DESIGN.md 4.10).  A/B library: ZKMI_LH_MERGE=0 keeps
+  // separate bucket sets (and so do the retired accumulation kernels, which have no accumulate-into form).
+  const bool lh_merge_on = ZK_TUNE("ZKMI_LH_MERGE", 1) != 0 && (ZK_TUNE("ZKMI_ACCUM", 3) == 2 || ZK_TUNE("ZKMI_ACCUM", 3) == 3);
+  const uint32_t N = 1u << pk->log_n;
+  const bool lh_merge = lh_merge_on && sh &&
+                        same_bucket_set(sz.plan, G > 1 ? msm_make_plan_shared_batch(N, G) : msm_make_plan_shared(N));
+  ctx->h_mode[par] = lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
   ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 0, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, sb1, rb, t, PH_MSM_ACCUM_G1,
+  // reductions: A and B1 on one stream, L (+ H) on the second, B2 on the third (without the merge: A, L | B1, H | B2)
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, sb1, lh_merge ? ra : rb, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 1, sth));
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, sl, ra, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 2, sth));
+  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, sl, lh_merge ? rb : ra, t, PH_MSM_ACCUM_G1,
+                                 PH_MSM_REDUCE_G1, s0 + 2, sth, -1, lh_merge ? MSM_RUN_NO_REDUCE : 0));
   return ZKMI_OK;
 }
 
@@ -825,14 +844,15 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   const uint32_t N = 1u << pk->log_n;
   // one small proof (the solo case of prove_enqueue_z): h is already sorted (front stream, right behind the transforms) and
   // normally accumulated in the same launch as A, B1 and L; otherwise the H accumulation runs on the copy stream, idle by now
-  static const bool spread_on = !(getenv("ZKMI_SPREAD") && getenv("ZKMI_SPREAD")[0] == '0');
-  const bool spread = solo && spread_on && G == 1 && pk->log_n <= prover_solo_max_log() && !prover_sort_side() && pk->shared;
-  if (spread && ctx->h_fused) return ZKMI_OK;  // accumulated with A, B1 and L
+  (void)solo;  // what the first half decided is in ctx->h_mode[par]
+  const int mode = ctx->h_mode[par];
+  if (mode == zkmi_ctx::H_FUSED) return ZKMI_OK;  // accumulated with A, B1 and L
+  const bool spread = mode == zkmi_ctx::H_SORTED;
   hipStream_t st = spread ? ctx->stream_copy : ctx->stream;
   if (spread) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));  // the sort of h, queued on the front stream
   PhaseTimer* t = ctx->timer();
   const bool sh = pk->shared;
-  static const bool heavy_side = getenv("ZKMI_HEAVY_ON") && getenv("ZKMI_HEAVY_ON")[0] == '1';
+  const bool heavy_side = ZK_TUNE("ZKMI_HEAVY_ON", 2) == 1;
   if (heavy_side) ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_heavy, false));
   const hipStream_t sth = heavy_side ? ctx->stream_heavy : nullptr;
   const bool sort_side = prover_sort_side();
@@ -854,8 +874,12 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
     ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
   }
   const bool aux_split = prover_aux_split();
+  const bool into_l = mode == zkmi_ctx::H_INTO_L;
+  if (into_l && !same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 2]))
+    return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sorts of z and h planned different bucket sets");
+  // (into_l: the same reduction stream as the L accumulation's heavy-bucket and redo kernels)
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, aux_split ? ctx->stream_aux2 : ctx->stream_aux, t,
-                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth));
+                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth, into_l ? 4 * par + 2 : -1));
   return ZKMI_OK;
 }
 
@@ -937,10 +961,11 @@ static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ&
 static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_bytes, const uint8_t* s_bytes, uint32_t G,
                             int par, uint8_t* out_proofs) {
   const int s0 = 4 * par, g2s = par;
+  const bool merged = ctx->h_mode[par] == zkmi_ctx::H_INTO_L;  // acc_h arrives as L + H
   std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
   std::vector<G2XYZZ> acc_b2(G);
   if (G == 1) {
-    static const bool lat_debug = getenv("ZKMI_LAT_DEBUG") != nullptr;
+    const bool lat_debug = debug_level() >= 2;
     const auto t0 = std::chrono::steady_clock::now();
     long tm[6] = {0, 0, 0, 0, 0, 0};
     auto mark = [&](int i) { tm[i] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
@@ -956,7 +981,8 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
     assemble_g2(pk, pre, acc_b2[0], head);
     mark(2);
-    ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
+    if (merged) acc_l[0] = G1XYZZ::infinity();  // its buckets went into the H MSM's reduction
+    else ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2));
     mark(3);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3));
     mark(4);
@@ -971,7 +997,10 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
   } else {
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
-    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_l.data(), s0 + 2));
+    if (merged)
+      for (auto& p : acc_l) p = G1XYZZ::infinity();
+    else
+      ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_l.data(), s0 + 2));
     ZK_HIP(ctx, ctx->g2.finish_host_batch(acc_b2.data(), g2s));
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_h.data(), s0 + 3));
   }
@@ -1008,8 +1037,8 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   if (!ctx || !pk || (!z && !d_z) || !r_bytes || !s_bytes || !out_proof) return ZKMI_ERR_BAD_ARG;
   if (!fr_is_canonical(r_bytes) || !fr_is_canonical(s_bytes)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "r/s >= r");
   const void* src[1] = {z ? static_cast<const void*>(z) : d_z};
-  // ZKMI_LAT_DEBUG=1: host-side timestamps of one proof (queueing the two halves, waiting + assembly) on stderr
-  static const bool lat_debug = getenv("ZKMI_LAT_DEBUG") != nullptr;
+  // ZKMI_DEBUG=2: host-side timestamps of one proof (queueing the two halves, waiting + assembly) on stderr
+  const bool lat_debug = debug_level() >= 2;
   const auto t0 = std::chrono::steady_clock::now();
   auto us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
   int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0, true);
@@ -1186,28 +1215,46 @@ int32_t zkmi_groth16_prove_batch_multi(zkmi_ctx* const* ctxs, const zkmi_pk* con
       if (ctxs[e] == ctxs[d]) return ZKMI_ERR_BAD_ARG;  // a context serves one host thread at a time
     if (pks[d]->n_vars != pks[0]->n_vars || pks[d]->n_pub != pks[0]->n_pub || pks[d]->log_n != pks[0]->log_n)
       return ctxs[d]->fail(ZKMI_ERR_BAD_ARG, "the keys of a multi-device batch must be replicas of one key");
+    // the two arrays are coupled by index only: a swapped or stale entry would run ctxs[d]'s streams over buffers,
+    // tables and pinned flags of another context (another device)
+    if (pks[d]->ctx != ctxs[d] || pks[d]->device != ctxs[d]->device)
+      return ctxs[d]->fail(ZKMI_ERR_BAD_ARG, "pks[d] was not created on ctxs[d]");
+  }
+  // every share's inputs and outputs are laid out BEFORE any thread starts: the library is built without exceptions, so an
+  // allocation that fails inside a worker would abort the host process from a C ABI call
+  struct Share {
+    std::vector<const void*> zz;
+    std::vector<uint8_t> rr, ss, out;
+  };
+  std::vector<Share> sh(n_dev);
+  for (uint32_t d = 0; d < n_dev; d++) {
+    Share& q = sh[d];
+    for (uint32_t i = d; i < n_proofs; i += n_dev) {
+      q.zz.push_back(z[i]);
+      q.rr.insert(q.rr.end(), r_bytes + 32ull * i, r_bytes + 32ull * i + 32);
+      q.ss.insert(q.ss.end(), s_bytes + 32ull * i, s_bytes + 32ull * i + 32);
+    }
+    q.out.resize(192 * q.zz.size());
   }
   std::vector<int32_t> rc(n_dev, ZKMI_OK);
   auto share = [&](uint32_t d) {
     zkmi_ctx* ctx = ctxs[d];
+    Share& q = sh[d];
+    if (q.zz.empty()) return;
     if (hipSetDevice(ctx->device) != hipSuccess) {
       rc[d] = ctx->fail(ZKMI_ERR_HIP, "hipSetDevice");
       return;
     }
-    std::vector<const void*> zz;
-    std::vector<uint8_t> rr, ss;
-    for (uint32_t i = d; i < n_proofs; i += n_dev) {
-      zz.push_back(z[i]);
-      rr.insert(rr.end(), r_bytes + 32ull * i, r_bytes + 32ull * i + 32);
-      ss.insert(ss.end(), s_bytes + 32ull * i, s_bytes + 32ull * i + 32);
-    }
-    if (zz.empty()) return;
-    std::vector<uint8_t> out(192 * zz.size());
-    rc[d] = prove_batch(ctx, pks[d], (uint32_t)zz.size(), zz.data(), z_on_device == 0, rr.data(), ss.data(), out.data());
+    rc[d] = prove_batch(ctx, pks[d], (uint32_t)q.zz.size(), q.zz.data(), z_on_device == 0, q.rr.data(), q.ss.data(), q.out.data());
     if (rc[d] != ZKMI_OK) return;
-    for (size_t k = 0; k < zz.size(); k++) memcpy(out_proofs + 192ull * (d + k * n_dev), out.data() + 192 * k, 192);
+    for (size_t k = 0; k < q.zz.size(); k++) memcpy(out_proofs + 192ull * (d + k * n_dev), q.out.data() + 192 * k, 192);
   };
+  if (n_dev == 1) {
+    share(0);
+    return rc[0];
+  }
   std::vector<std::thread> th;
+  th.reserve(n_dev);
   for (uint32_t d = 1; d < n_dev; d++) th.emplace_back(share, d);
   share(0);  // the calling thread drives device 0
   for (auto& t : th) t.join();

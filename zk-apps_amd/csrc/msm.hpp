@@ -5,6 +5,7 @@
 #include <vector>
 #include "curve.hpp"
 #include "field28.hpp"
+#include "tune.hpp"
 
 namespace zkmi {
 
@@ -64,6 +65,7 @@ struct MsmPlan {
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);
 MsmPlan msm_make_plan_shared(uint64_t n);
+MsmPlan msm_make_plan_shared_batch(uint64_t n, uint32_t batch);  // the plan MsmSort::run_shared_batch(n, .., batch) will use
 
 // Bucket scatter: signed-digit decomposition + counting sort of point indices
 // by (window, bucket).  Shared by every MSM over the same scalar vector.
@@ -109,6 +111,8 @@ template <> struct HostFieldOf<Fq28> { using type = Fq; };
 template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
 template <> struct HostFieldOf<BnFq28> { using type = BnFq; };
 
+enum { MSM_RUN_NO_REDUCE = 1 };  // MsmEngine::run_device flags
+
 template <class F>
 struct MsmEngine {
   using HF = typename HostFieldOf<F>::type;
@@ -150,13 +154,16 @@ struct MsmEngine {
   // (which own buckets the accumulation skips) run on `st_heavy` beside the accumulation when given:
   // with uniform scalars their list is empty, and on `st` the empty launches waited ~0.8 ms each for
   // a free workgroup slot before the next accumulation could start
+  // bucket_slot >= 0 and != slot: add INTO the bucket array of that slot (filled by an earlier run with MSM_RUN_NO_REDUCE)
+  // and reduce the sum of both MSMs; see run_device_multi in msm_impl.hpp
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, hipStream_t st_reduce,
-                        PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0, hipStream_t st_heavy = nullptr);
+                        PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0, hipStream_t st_heavy = nullptr,
+                        int bucket_slot = -1, int flags = 0);
   // nm <= 4 MSMs of one plan shape (sorts[m] may repeat: several tables over one sort), each with its own slot and
   // reduction stream; the G1 call-free kernels accumulate them in one launch (one small proof: A, B1, L and H side by side)
   hipError_t run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
                               const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce, const int* slots,
-                              hipStream_t st_heavy = nullptr);
+                              hipStream_t st_heavy = nullptr, const int* bucket_slots = nullptr, int flags = 0);
   // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points

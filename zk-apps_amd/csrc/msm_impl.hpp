@@ -41,18 +41,6 @@ namespace zkmi {
 static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
 constexpr uint32_t MSM_STAGE_PTS = 4096;  // k_treesum slices of one slot (small plans only)
-#ifndef ZKMI_ACCUM_DEFAULT
-#define ZKMI_ACCUM_DEFAULT 3
-#endif
-#ifndef ZKMI_ACCUM_G2_DEFAULT
-#define ZKMI_ACCUM_G2_DEFAULT 2
-#endif
-#ifndef ZKMI_ACCUM_BLOCK_DEFAULT
-#define ZKMI_ACCUM_BLOCK_DEFAULT 64
-#endif
-#ifndef ZKMI_ACCUM_ROUNDS_DEFAULT
-#define ZKMI_ACCUM_ROUNDS_DEFAULT 0
-#endif
 constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
 template <class T>
@@ -74,6 +62,11 @@ __device__ __forceinline__ void store_vec(T* p, const T& v) {
   for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+#ifdef ZKMI_EXPERIMENTS
+// ---- retired accumulation kernels (A/B library only: ZKMI_ACCUM=0|1, ZKMI_ACCUM_G2=0|1) ----
 // G1 (14-limb coordinates): 248 VGPRs -> 2 waves per SIMD.  G2 needs ~330 registers
 // (accumulator 112 + point 56 + columns 56 + temporaries) and runs at 1 wave per SIMD with
 // cheap AGPR spills; forcing 2 waves sends 350+ values to scratch and is 2x slower.
@@ -111,8 +104,6 @@ k_accum(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
 // into one of two LDS buffers.  Order inside an iteration: wait -> read point j from LDS -> issue the
 // loads of point j+1 and of index j+2 -> mixed addition (no memory operation inside it).
 // LDS: 2 buffers x 256 threads x 112 B = 56 KB per block, two blocks per CU (VGPR-limited anyway).
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // BW = waves per workgroup.  One-wave workgroups (BW = 1) free their slot the moment the wave retires; a
 // 4-wave workgroup can only start once all four SIMDs of a CU have a free slot at the same time.
 // The loop strides the load-ordered bucket list by the grid size: with a grid of one wave per bucket group
@@ -166,6 +157,7 @@ k_accum_g1_glds(const Affine<F>* __restrict__ bases, const uint32_t* __restrict_
     store_vec(buckets + b, acc);
   }
 }
+#endif  // ZKMI_EXPERIMENTS
 
 // G2 accumulation with every Fq2 value split across a lane pair (field28.hpp Fq2P):
 // two adjacent lanes own one bucket; per-lane state is that of a G1 addition, so the
@@ -188,6 +180,7 @@ __device__ __forceinline__ void st_comp(Fq28* p, const Fq28& v) {
   for (int i = 0; i < 7; i++) q[i] = make_uint2((uint32_t)v.l[2 * i], (uint32_t)v.l[2 * i + 1]);
 }
 
+#ifdef ZKMI_EXPERIMENTS
 template <int BW>
 __global__ void __launch_bounds__(64 * BW, 2)
 k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
@@ -218,6 +211,7 @@ k_accum_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __res
     st_comp(dst + 6 + comp, acc.zzz.v);
   }
 }
+#endif  // ZKMI_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------
 // Call-free accumulation kernels.  XYZZ::madd keeps its rare doubling case in an out-of-line function;
@@ -293,7 +287,15 @@ struct AccumArgs<F, true> {
   __device__ __forceinline__ uint32_t* redo() const { return redo_[blockIdx.y]; }
   __device__ __forceinline__ const SortView& sort() const { return sort_[blockIdx.y]; }
 };
-template <class F, int W, int BW, bool MULTI = false>
+// INTO: the bucket array already holds the sums of an earlier MSM over the same bucket set (another query whose result is
+// only ever ADDED to this one's: the prover's L and H queries both end up in C).  The accumulator then
+// starts from the bucket's value instead of the first entry, an empty entry list leaves the bucket alone, and one
+// reduction serves both MSMs.  A bucket the earlier MSM left EMPTY (exact zeros; probability e^-(mean load)) needs no
+// test of its own: with acc = (0, 0, 0, 0) the first addition computes P = x zz - X = 0, which is the "needs the complete
+// group law" exit below -- the bucket goes to the redo pass, whose complete addition starts from infinity.
+// (Any early exit through the redo list IN FRONT of the loop made the register allocator spill 120 dwords inside the
+// loop; this form spills 24 -- the plain kernel's 0 is a lucky draw at exactly the 168 registers of three waves per SIMD.)
+template <class F, int W, int BW, bool MULTI = false, bool INTO = false>
 __global__ void __launch_bounds__(64 * BW, W)
 k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
   const Affine<F>* __restrict__ const bases = args.bases();
@@ -330,12 +332,16 @@ k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
   // first entry that is not the point at infinity starts the accumulator (plain loads: runs once per bucket)
   for (;; j++) {
     if (j >= end) {
-      store_vec(buckets + b, XYZZ<F>::infinity());
+      if constexpr (!INTO) store_vec(buckets + b, XYZZ<F>::infinity());  // (INTO: nothing to add, the bucket keeps its sum)
       return;
     }
     const uint32_t v = sorted[j];
     Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
     if (affine_is_zero_words(p)) continue;
+    if constexpr (INTO) {
+      acc = load_vec(buckets + b);  // entry j itself is added by the loop below
+      break;
+    }
     if (v >> 31) p.y = p.y.neg();
     acc.x = p.x;
     acc.y = p.y;
@@ -361,7 +367,9 @@ k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
     }
     if (affine_is_zero_words(p)) continue;
     if (!madd_generic(acc, p, 0u - (v >> 31))) {
-      redo[1 + atomicAdd(redo, 1u)] = b;  // doubling or cancellation: k_accum_redo recomputes the bucket
+      // doubling or cancellation: k_accum_redo recomputes the bucket (INTO: from the value it still holds -- nothing
+      // has been written)
+      redo[1 + atomicAdd(redo, 1u)] = b;
       return;
     }
   }
@@ -556,12 +564,13 @@ template <class F>
 __global__ void __launch_bounds__(64)
 k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
              const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
-             XYZZ<F>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket) {
+             XYZZ<F>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket, uint32_t into) {
   const uint32_t n = redo[0];
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t b = redo[1 + k];
     const uint32_t beg = begin[b], end = beg + count[b];
-    XYZZ<F> acc = XYZZ<F>::infinity();
+    // into: the accumulation was adding to an earlier MSM's bucket sums and left the listed buckets untouched
+    XYZZ<F> acc = into ? load_vec(buckets + b) : XYZZ<F>::infinity();
     for (uint32_t j = beg; j < end; j++) {
       const uint32_t v = sorted[j];
       Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
@@ -608,12 +617,17 @@ __global__ void __launch_bounds__(MSM_TREE_T)
 k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
               const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
-              XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket) {
+              XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t into) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   __shared__ uint32_t is_last;
   const uint32_t n_heavy = heavy[0];
   const uint32_t r = blockIdx.x;
+  // into: the bucket's sum is added to what an earlier MSM left in the bucket (complete addition, one thread)
+  auto put = [&](uint32_t b, XYZZ<F> v) {
+    if (into) v.add(load_vec(buckets + b));
+    store_vec(buckets + b, v);
+  };
   for (uint32_t h = blockIdx.y; h < n_heavy; h += gridDim.y) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
@@ -640,7 +654,7 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
     }
     acc = block_tree_sum(acc, sh);
     if (nsplit == 1) {
-      if (threadIdx.x == 0) store_vec(buckets + b, acc);
+      if (threadIdx.x == 0) put(b, acc);
     } else {
       if (threadIdx.x == 0) {
         store_vec(heavy_partial + (size_t)h * MSM_HSPLIT + r, acc);
@@ -654,7 +668,7 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
         if (threadIdx.x < nsplit) v = load_vec(heavy_partial + (size_t)h * MSM_HSPLIT + threadIdx.x);
         v = block_tree_sum(v, sh);
         if (threadIdx.x == 0) {
-          store_vec(buckets + b, v);
+          put(b, v);
           ticket[h] = 0;
         }
       }
@@ -1054,21 +1068,36 @@ static inline int msm_seg_bits(const MsmPlan& pl) {
 template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
                                     hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot,
-                                    hipStream_t st_heavy) {
+                                    hipStream_t st_heavy, int bucket_slot, int flags) {
   const MsmSort* sp = &sort;
-  return run_device_multi(&sp, &d_bases, 1, st, &st_reduce, prof, ph_accum, ph_reduce, &slot, st_heavy);
+  return run_device_multi(&sp, &d_bases, 1, st, &st_reduce, prof, ph_accum, ph_reduce, &slot, st_heavy,
+                          bucket_slot >= 0 ? &bucket_slot : nullptr, flags);
 }
 
 // nm MSMs of the same plan shape (sorts[m] may repeat: different tables over one digit sort): one fused accumulation
 // launch where the kernel has a fused form (the call-free G1 kernels), otherwise nm launches in line; each MSM keeps
 // its own slot and reduction stream.  All sorts must be complete on `st` (stream order or events) when this is called.
+//
+// Two MSMs whose results are only ever added (the prover's L and H queries: C = ... + L + H) can share ONE bucket set and one
+// reduction: the first runs with MSM_RUN_NO_REDUCE (accumulation, heavy buckets and redo list only; its slot's `done` event
+// is NOT recorded and it has no host result), the second names the first one's slot in bucket_slots[m] -- its kernels then
+// add INTO that bucket array (k_accum_g1_nc<.., INTO>, k_accum_heavy / k_accum_redo with into = 1) behind the first one's
+// redo_done event, and its reduction yields the sum of both.  Both sorts must plan the same bucket set (checked by the
+// caller: the bucket arrays are indexed by bucket id, and the ids mean the same digit values only under equal plans).
 template <class F>
 hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
                                           const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce,
-                                          const int* slots, hipStream_t st_heavy) {
+                                          const int* slots, hipStream_t st_heavy, const int* bucket_slots, int flags) {
   if (nm < 1 || nm > MSM_MULTI_MAX) return hipErrorInvalidValue;
-  for (int m = 0; m < nm; m++)
+  const bool no_reduce = (flags & MSM_RUN_NO_REDUCE) != 0;
+  bool any_into = false;
+  for (int m = 0; m < nm; m++) {
     if (slots[m] < 0 || slots[m] >= nslots) return hipErrorInvalidValue;
+    if (bucket_slots && (bucket_slots[m] < 0 || bucket_slots[m] >= nslots)) return hipErrorInvalidValue;
+    any_into = any_into || (bucket_slots && bucket_slots[m] != slots[m]);
+  }
+  // the accumulate-into forms exist for the call-free G1 kernels, one MSM per launch
+  if (any_into && (nm != 1 || std::is_same<F, Fq2_28>::value)) return hipErrorInvalidValue;
   const MsmPlan& pl = sorts[0]->plan;  // bucket count, windows, segment length: common to all (checked); heavy_thr is per sort
   for (int m = 1; m < nm; m++) {
     const MsmPlan& q = sorts[m]->plan;
@@ -1077,46 +1106,43 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   const uint32_t tot_b = pl.nwin * pl.nb;
   const int T = 256;
   hipError_t e;
-  // Heavy and light buckets are disjoint, so the heavy-bucket kernels only have to see the sort complete.  Where they
-  // run (ZKMI_HEAVY_ON, read once): 0 = in line on the accumulation stream; 1 = on `st_heavy` beside the accumulation
-  // (round 2: a normal-priority side stream); 2 (default) = at the head of the REDUCTION's stream.  With uniform
-  // scalars the heavy list is empty, but an empty 512-workgroup launch still has to be placed: on a normal-priority
-  // stream it queued behind the next accumulation's workgroups (0.9 ms G1 / 9.8 ms G2 average in the round-2 trace)
-  // and every reduction waited for it.  The reduction streams have high priority, so there the launch is placed as
-  // soon as any workgroup retires, and no cross-stream event sits between it and the reduction.
-  static const int heavy_on = [] {
-    const char* e = getenv("ZKMI_HEAVY_ON");
-    return e ? atoi(e) : 2;
-  }();
-  // ZKMI_ACCUM: 0 = the first-generation kernels (madd with an out-of-line doubling path), 2/3 = the call-free
-  // kernels at 2 / 3 waves per SIMD (default: see DESIGN.md 4.1 for the measurements behind it)
-  static const int accum_mode = [] {
-    const char* e = getenv("ZKMI_ACCUM");
-    return e ? atoi(e) : ZKMI_ACCUM_DEFAULT;
-  }();
-  // the G2 kernel has its own switch (its lane-split additions need more registers per lane than G1's)
-  static const int accum_mode_g2 = [] {
-    const char* e = getenv("ZKMI_ACCUM_G2");
-    return e ? atoi(e) : ZKMI_ACCUM_G2_DEFAULT;
-  }();
+  // Heavy and light buckets are disjoint, so the heavy-bucket kernels only have to see the sort complete.  They run at the
+  // head of the REDUCTION's stream.  With uniform scalars the heavy list is empty, but an empty 512-workgroup launch still
+  // has to be placed: on a normal-priority stream it queued behind the next accumulation's workgroups (0.9 ms G1 / 9.8 ms
+  // G2 average in the round-2 trace) and every reduction waited for it.  The reduction streams have high priority, so
+  // there the launch is placed as soon as any workgroup retires, and no cross-stream event sits between it and the
+  // reduction.  (A/B library, ZKMI_HEAVY_ON: 0 = in line on the accumulation stream; 1 = on `st_heavy`, round 2's side stream.)
+  const int heavy_on = ZK_TUNE("ZKMI_HEAVY_ON", 2);
+  // The product's accumulation kernels are the call-free ones at 3 (G1) / 2 (G2) waves per SIMD.  A/B
+  // library: ZKMI_ACCUM / ZKMI_ACCUM_G2 = 0 | 1 select the retired generations (madd with an out-of-line doubling path),
+  // 2 | 3 the call-free kernels at 2 / 3 waves; ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup and ZKMI_ACCUM_ROUNDS = R
+  // (every wave walks R load-ordered bucket groups) apply to the retired kernels.
+  const int accum_mode = ZK_TUNE("ZKMI_ACCUM", 3);
+  const int accum_mode_g2 = ZK_TUNE("ZKMI_ACCUM_G2", 2);
   const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
   const bool nocall = mode == 2 || mode == 3;
-  // ZKMI_ACCUM_BLOCK = 64 | 256 threads per workgroup; ZKMI_ACCUM_ROUNDS = R > 0: grid of ceil(groups / R) waves, every
-  // wave walks R load-ordered bucket groups (0 = one wave per group, dispatched dynamically)
-  static const int accum_block = [] {
-    const char* e = getenv("ZKMI_ACCUM_BLOCK");
-    return (e && atoi(e) == 64) ? 64 : (e && atoi(e) == 256) ? 256 : ZKMI_ACCUM_BLOCK_DEFAULT;
-  }();
-  static const int accum_rounds = [] {
-    const char* e = getenv("ZKMI_ACCUM_ROUNDS");
-    return e ? atoi(e) : ZKMI_ACCUM_ROUNDS_DEFAULT;
-  }();
+#ifdef ZKMI_EXPERIMENTS
+  const int accum_block = ZK_TUNE("ZKMI_ACCUM_BLOCK", 64) == 256 ? 256 : 64;
+  const int accum_rounds = ZK_TUNE("ZKMI_ACCUM_ROUNDS", 0);
   auto striped = [&](uint32_t threads_needed, uint32_t block) {
     uint32_t blocks = (threads_needed + block - 1) / block;
     if (accum_rounds > 1) blocks = (blocks + accum_rounds - 1) / accum_rounds;
     return blocks ? blocks : 1u;
   };
-  auto bk_of = [&](int m) { return buckets + (size_t)slots[m] * cap_buckets; };
+#else
+  if (!nocall) return hipErrorInvalidValue;  // (unreachable: the defaults above are compiled in)
+#endif
+  if (any_into && !nocall) return hipErrorInvalidValue;
+  auto bslot_of = [&](int m) { return bucket_slots ? bucket_slots[m] : slots[m]; };
+  auto into_of = [&](int m) { return bslot_of(m) != slots[m]; };
+  auto bk_of = [&](int m) { return buckets + (size_t)bslot_of(m) * cap_buckets; };
+  // everything the reductions below would refuse is refused here, before the first launch: an early return between the
+  // accumulation and k_accum_redo would leave a redo list behind that the slot's next MSM appends to
+  {
+    const uint32_t spw = pl.nb >> pl.seg_log;
+    if ((uint64_t)pl.nwin * spw > seg_cap || (uint64_t)(2 + msm_seg_bits(pl)) * pl.nwin > SLOT_PTS || tot_b > cap_buckets)
+      return hipErrorInvalidValue;
+  }
   // [0] length, [1 ..] list, [cap_buckets + 1] ticket (k_accum_redo)
   auto redo_of = [&](int m) { return this->redo + (size_t)slots[m] * (cap_buckets + 2); };
 
@@ -1135,7 +1161,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     else
       hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP);
+                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u);
   };
   for (int m = 0; m < nm; m++) {
     slot_plan[slots[m]] = sorts[m]->plan;
@@ -1144,6 +1170,13 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     const bool side = !on_reduce && heavy_on != 0 && st_heavy && st_heavy != st;
     heavy_first[m] = side || on_reduce;
     heavy_stream[m] = on_reduce ? st_reduce : side ? st_heavy : st;
+    if (into_of(m)) {
+      // the bucket array is complete once the first MSM's redo pass has run (it follows that MSM's accumulation and
+      // heavy-bucket kernels on its reduction stream)
+      if ((e = hipStreamWaitEvent(st, redo_done[bslot_of(m)], 0)) != hipSuccess) return e;
+      if (heavy_stream[m] != st && (e = hipStreamWaitEvent(heavy_stream[m], redo_done[bslot_of(m)], 0)) != hipSuccess) return e;
+      if (st_reduce != st && st_reduce != heavy_stream[m] && (e = hipStreamWaitEvent(st_reduce, redo_done[bslot_of(m)], 0)) != hipSuccess) return e;
+    }
     if (heavy_first[m]) {
       if ((e = hipEventRecord(pre[slots[m]], st)) != hipSuccess) return e;
       if ((e = hipStreamWaitEvent(heavy_stream[m], pre[slots[m]], 0)) != hipSuccess) return e;
@@ -1156,9 +1189,10 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   };
 
   // ---- the accumulation ----
-  // test switch: a lone MSM through the multi-MSM launch too (so that the generic MSM entry points, with their degenerate
-  // inputs -- repeated bases, P + (-P), points at infinity --, reach k_accum_g1_split2 / the MULTI kernel form)
-  static const bool force_multi = getenv("ZKMI_FORCE_MULTI") != nullptr;
+  // A/B library test switch ZKMI_FORCE_MULTI: a lone MSM through the multi-MSM launch too (so that the generic MSM entry
+  // points, with their degenerate inputs -- repeated bases, P + (-P), points at infinity --, reach k_accum_g1_split2 / the
+  // MULTI kernel form)
+  const bool force_multi = ZK_TUNE("ZKMI_FORCE_MULTI", 0) != 0;
   if (prof) prof->begin(ph_accum, st);
   if constexpr (std::is_same<F, Fq2_28>::value) {
     for (int m = 0; m < nm; m++) {
@@ -1166,20 +1200,26 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       const uint32_t heavy_thr = sort.plan.heavy_thr;
       XYZZ<F>* const bk = bk_of(m);
       uint32_t* const redo = redo_of(m);
-      if (mode == 3)
+#ifdef ZKMI_EXPERIMENTS
+      if (mode == 3) {
         hipLaunchKernelGGL((k_accum_g2_nc<3, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
                            sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
-      else if (mode == 2)
-        hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
-                           sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
-      else if (accum_block == 64)
-        hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
-                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
-      else
-        hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
-                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+        continue;
+      }
+      if (mode != 2) {
+        if (accum_block == 64)
+          hipLaunchKernelGGL(k_accum_g2_split<1>, dim3(striped(2 * tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                             sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+        else
+          hipLaunchKernelGGL(k_accum_g2_split<4>, dim3(striped(2 * tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
+                             sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+        continue;
+      }
+#endif
+      hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                         sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
     }
-  } else if ((nm > 1 || force_multi) && nocall) {
+  } else if ((nm > 1 || (force_multi && !any_into)) && nocall) {
     AccumArgs<F, true> set;
     for (int m = 0; m < MSM_MULTI_MAX; m++) {
       const int k = m < nm ? m : 0;
@@ -1188,35 +1228,46 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       set.redo_[m] = redo_of(k);
       set.sort_[m] = view_of(k);
     }
-    // small plans (one small proof): two lanes per bucket (ZKMI_SOLO_SPLIT=0: one)
-    static const bool split2 = !(getenv("ZKMI_SOLO_SPLIT") && getenv("ZKMI_SOLO_SPLIT")[0] == '0');
+    // small plans (one small proof): two lanes per bucket (A/B library: ZKMI_SOLO_SPLIT=0: one)
+    const bool split2 = ZK_TUNE("ZKMI_SOLO_SPLIT", 1) != 0;
     if (split2 && tot_b <= (1u << 16))
       hipLaunchKernelGGL((k_accum_g1_split2<F, 1>), dim3((2 * tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
-    else if (accum_mode == 3)
-      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
-    else
+#ifdef ZKMI_EXPERIMENTS
+    else if (accum_mode != 3)
       hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
+#endif
+    else
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, true>), dim3((tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
   } else {
-    const dim3 grid((tot_b + T - 1) / T);
     for (int m = 0; m < nm; m++) {
       const MsmSort& sort = *sorts[m];
-      const uint32_t heavy_thr = sort.plan.heavy_thr;
       XYZZ<F>* const bk = bk_of(m);
       uint32_t* const redo = redo_of(m);
       const AccumArgs<F, false> one = {d_bases[m], bk, redo, view_of(m)};
-      if (accum_mode == 3)
-        hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
-      else if (accum_mode == 2)
-        hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
-      else if (accum_mode == 1)
-        hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases[m], sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
-                           heavy_thr);
-      else if (accum_block == 64)
-        hipLaunchKernelGGL((k_accum_g1_glds<F, 1>), dim3(striped(tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
-                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
-      else
-        hipLaunchKernelGGL((k_accum_g1_glds<F, 4>), dim3(striped(tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
-                           sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+      if (into_of(m)) {
+        hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, false, true>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
+        continue;
+      }
+#ifdef ZKMI_EXPERIMENTS
+      if (accum_mode != 3) {
+        const uint32_t heavy_thr = sort.plan.heavy_thr;
+        const dim3 grid((tot_b + T - 1) / T);
+        if (accum_mode == 2)
+          hipLaunchKernelGGL((k_accum_g1_nc<F, 2, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
+        else if (accum_mode == 1)
+          hipLaunchKernelGGL(k_accum<F>, grid, dim3(T), 0, st, d_bases[m], sort.begin, sort.count, sort.perm, sort.sorted, bk, tot_b,
+                             heavy_thr);
+        else if (accum_block == 64)
+          hipLaunchKernelGGL((k_accum_g1_glds<F, 1>), dim3(striped(tot_b, 64)), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                             sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+        else
+          hipLaunchKernelGGL((k_accum_g1_glds<F, 4>), dim3(striped(tot_b, 256)), dim3(256), 0, st, d_bases[m], sort.begin, sort.count,
+                             sort.perm, sort.sorted, bk, tot_b, heavy_thr);
+        continue;
+      }
+#endif
+      (void)sort;
+      hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
     }
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets the accumulation launch(es) only (roofline leg of bench.py)
@@ -1225,7 +1276,6 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
   const uint32_t tot_segs = pl.nwin * segs_per_win;
   const int seg = 1 << pl.seg_log;
-  if (tot_segs > seg_cap || (uint64_t)(2 + msm_seg_bits(pl)) * pl.nwin > SLOT_PTS) return hipErrorInvalidValue;
   const int plain_job = pl.shared ? 1 + msm_seg_bits(pl) : -1;
   const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
   // small plans: the job lists are cut into slices of two segments per thread or lane pair (k_treesum_final adds the slices)
@@ -1264,11 +1314,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
                            redo, redo + cap_buckets + 1);
       else
         hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
-                           redo + cap_buckets + 1);
+                           redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
       // the list reads the sort: the next sort must wait for this kernel too
       if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;
       sort.readers.push_back(redo_done[slot]);
     }
+    if (no_reduce) continue;  // a later MSM adds into these buckets and reduces them (bucket_slots)
     if (prof) prof->begin(ph_reduce, st_reduce);
     XYZZ<F>* const ssum = segsum + (size_t)slot * seg_cap;
     XYZZ<F>* const sw = segw + (size_t)slot * seg_cap;
@@ -1289,13 +1340,14 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         hipLaunchKernelGGL(k_treesum_final_g2_split<0>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf / 2, st_reduce, stg, nchunk, dp);
       } else {
         // big plans: the same lane-pair kernel, 128 pairs per job (the unsplit form's 330-register additions made this the
-        // slowest link of a proof's tail: 16 + 7 dependent additions of 45-60 us); ZKMI_G2_TREE_SPLIT=0: the unsplit kernel
-        static const bool tree_split = !(getenv("ZKMI_G2_TREE_SPLIT") && getenv("ZKMI_G2_TREE_SPLIT")[0] == '0');
-        if (tree_split)
-          hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+        // slowest link of a proof's tail: 16 + 7 dependent additions of 45-60 us); A/B library, ZKMI_G2_TREE_SPLIT=0: the unsplit kernel
+#ifdef ZKMI_EXPERIMENTS
+        if (ZK_TUNE("ZKMI_G2_TREE_SPLIT", 1) == 0)
+          hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                              ssum, sw, segs_per_win, dp, plain_job, stg);
         else
-          hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
+#endif
+          hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                              ssum, sw, segs_per_win, dp, plain_job, stg);
       }
     } else {

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "msm_impl.hpp"
+#include "tune.hpp"
 
 namespace zkmi {
 
@@ -681,7 +682,7 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
   // segments to fill the chip
   p.seg_log = buckets <= (1u << 14) ? 1 : buckets <= (1u << 15) ? 2 : buckets <= (1u << 16) ? 3 : 4;
   {
-    static const int seg_env = getenv("ZKMI_SEG_LOG") ? atoi(getenv("ZKMI_SEG_LOG")) : 0;  // A/B: segment length of big plans
+    const int seg_env = ZK_TUNE("ZKMI_SEG_LOG", 0);  // A/B library: segment length of big plans
     // (the segment arrays hold max(buckets / 16, 2^16) entries: msm_impl.hpp msm_max_segments)
     if (seg_env >= 1 && seg_env <= 7 && (buckets >> seg_env) <= (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16))) p.seg_log = seg_env;
   }
@@ -701,12 +702,9 @@ MsmPlan msm_make_plan_c(uint64_t n, int c) {
   return p;
 }
 MsmPlan msm_make_plan(uint64_t n) {
-  // ZKMI_WINDOW_BITS: tuning override (5..16), read once
-  static const int forced = [] {
-    const char* e = getenv("ZKMI_WINDOW_BITS");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 5 && v <= 16) ? v : 0;
-  }();
+  // ZKMI_WINDOW_BITS (A/B library): tuning override (5..16)
+  const int v = ZK_TUNE("ZKMI_WINDOW_BITS", 0);
+  const int forced = (v >= 5 && v <= 16) ? v : 0;
   return msm_make_plan_c(n, forced ? forced : pick_window(n));
 }
 
@@ -751,6 +749,15 @@ MsmPlan msm_make_plan_shared(uint64_t n) {
   return p;
 }
 
+// plan of MsmSort::run_shared_batch: `batch` vectors of n scalars, vector v owns partitions [v * vec_parts, (v + 1) * vec_parts)
+MsmPlan msm_make_plan_shared_batch(uint64_t n, uint32_t batch) {
+  MsmPlan p = msm_make_plan_shared(n);
+  p.vec_parts = p.nwin;
+  p.nwin = (int)(batch * (uint32_t)p.vec_parts);
+  plan_set_heavy(p, n * (uint64_t)p.ndigits * batch);
+  return p;
+}
+
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
 uint64_t msm_max_buckets(uint64_t n) {
@@ -777,10 +784,10 @@ static uint64_t msm_max_entries(uint64_t n) {
   return best;
 }
 
-// more, smaller (chunk, window) tiles for big inputs: see shared_chunks below (ZKMI_WIN_CHUNKS=m forces the multiplier)
-static uint32_t chunk_multiplier(uint64_t n, const char* env_name, bool windowed) {
-  const char* e = getenv(env_name);
-  const int v = e ? atoi(e) : 0;
+// more, smaller (chunk, window) tiles for big inputs: see shared_chunks below (A/B library: ZKMI_WIN_CHUNKS=m /
+// ZKMI_REC_CHUNKS=m force the multiplier)
+static uint32_t chunk_multiplier(uint64_t n, bool windowed) {
+  const int v = windowed ? ZK_TUNE("ZKMI_WIN_CHUNKS", 0) : ZK_TUNE("ZKMI_REC_CHUNKS", 0);
   if (v >= 1 && v <= 64) return (uint32_t)v;
   if (n < (1ull << 22)) return 1u;
   if (windowed) return 4u;  // measured: 2^24 sort 8.9 -> 5.8 ms, 2^25 17.6 -> 12.3; no gain beyond 4x
@@ -788,7 +795,7 @@ static uint32_t chunk_multiplier(uint64_t n, const char* env_name, bool windowed
 }
 
 static uint32_t pick_chunks(const MsmPlan& p) {
-  uint64_t nch = (uint64_t)((256 + p.nwin - 1) / p.nwin) * chunk_multiplier(p.n, "ZKMI_WIN_CHUNKS", true);  // ~1 tile per CU x multiplier
+  uint64_t nch = (uint64_t)((256 + p.nwin - 1) / p.nwin) * chunk_multiplier(p.n, true);  // ~1 tile per CU x multiplier
   const uint64_t max_by_n = (p.n + 1023) / 1024;
   if (nch > max_by_n) nch = max_by_n ? max_by_n : 1;
   return nch ? (uint32_t)nch : 1;
@@ -833,7 +840,7 @@ void MsmSort::release() {
 // (2^24 terms: sort 10.0 -> 6.1 ms with 4x, 2^26: 39.4 -> 26.4 ms with 16x; at 2^20 the extra histogram traffic costs more than it saves: 0.63 -> 1.39 ms
 // with 16x).  ZKMI_REC_CHUNKS=m forces the multiplier.
 static uint32_t shared_chunks(uint32_t P, uint64_t n) {
-  const uint32_t mult = chunk_multiplier(n, "ZKMI_REC_CHUNKS", false);
+  const uint32_t mult = chunk_multiplier(n, false);
   uint64_t nch = (uint64_t)((256 + P - 1) / P) * (P > 1 ? mult : 1);
   const uint64_t max_by_n = (n + 1023) / 1024;
   if (nch > max_by_n) nch = max_by_n ? max_by_n : 1;
@@ -1011,7 +1018,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
   // 0.87 ms at 2^21; inside the proof pipeline +4.8 % proofs/s at N = 2^20.  Beyond that the digit width stays at 20 bits
   // (2^19 buckets) while the records grow with n, every extra stage round re-reads the partition's records, and the record
   // sort wins again (2^22: 3.3 vs 2.0 ms, 2^24: 42 vs 6 ms).  ZKMI_SORT_FINE=0 / =2: never / whenever it is applicable.
-  static const int fine_mode = getenv("ZKMI_SORT_FINE") ? atoi(getenv("ZKMI_SORT_FINE")) : 1;
+  const int fine_mode = ZK_TUNE("ZKMI_SORT_FINE", 1);
   const uint32_t NP = tot_b >> FINE_LOG;
   const bool fine_fits = NP <= FINE_MAX_PARTS && (uint64_t)plan.ndigits * n / (NP ? NP : 1) <= 2 * FINE_ROUND &&
                          plan.ndigits <= (int)FPASS_MAXD;
@@ -1024,7 +1031,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
                        rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
     hipLaunchKernelGGL(k_fpart_scan_rows, dim3(NP), dim3(64), 0, st, blkcnt, nblk, NP, fpart);
     hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart);
-    static const bool stage_on = !(getenv("ZKMI_SORT_STAGE") && getenv("ZKMI_SORT_STAGE")[0] == '0');
+    const bool stage_on = ZK_TUNE("ZKMI_SORT_STAGE", 1) != 0;
     const size_t stage_bytes = sizeof(uint32_t) * 2 * 1024 * (size_t)plan.ndigits;
     if (stage_on && NP <= 512 && plan.ndigits <= (int)FPASS_MAXD)
       hipLaunchKernelGGL(k_fpart_write_staged<512>, dim3(nblk), dim3(1024), stage_bytes, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP,
@@ -1088,12 +1095,9 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
     const hipError_t er = wait_readers(st);
     if (er != hipSuccess) return er;
   }
-  plan = msm_make_plan_shared(n);
-  const uint32_t vparts = (uint32_t)plan.nwin;
-  if (batch == 0 || (uint64_t)batch * vparts > 64) return hipErrorInvalidValue;
-  plan.vec_parts = (int)vparts;
-  plan.nwin = (int)(batch * vparts);
-  plan_set_heavy(plan, n * (uint64_t)plan.ndigits * batch);
+  if (batch == 0 || (uint64_t)batch * msm_make_plan_shared(n).nwin > 64) return hipErrorInvalidValue;
+  plan = msm_make_plan_shared_batch(n, batch);
+  const uint32_t vparts = (uint32_t)plan.vec_parts;
   const uint32_t nb = plan.nb, P = batch * vparts;
   int nb_log = 0;
   while ((1u << nb_log) < nb) nb_log++;
@@ -1118,7 +1122,7 @@ hipError_t MsmSort::run_shared_batch(const uint32_t* d_scalars, uint64_t n, uint
       }
     }
   }
-  static const bool dbg = getenv("ZKMI_DEBUG") != nullptr;
+  const bool dbg = debug_level() >= 1;
   auto chk = [&](const char* what) {
     if (!dbg) return;
     const hipError_t le = hipGetLastError();

@@ -24,6 +24,7 @@
 #include <type_traits>
 #include <utility>
 #include "ntt.hpp"
+#include "tune.hpp"
 
 namespace zkmi {
 
@@ -147,7 +148,9 @@ k_ntt_pass(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0, in
   }
 }
 
+#ifdef ZKMI_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------
+// (A/B library only: measured in round 3, not adopted -- DESIGN.md 4.2)
 // Register-blocked pass (round 3).  Same tiles, same twists and the same stage order as k_ntt_pass, but a thread
 // owns E = 2^LOGE tile elements per ROUND and runs up to LOGE butterfly stages on them in registers (radix-8
 // sub-butterflies for LOGE = 3: 12 products between two barriers instead of one).  A 2048-element tile is a
@@ -319,6 +322,7 @@ k_ntt_pass_rb(F* __restrict__ data, const F* __restrict__ tw, int log_n, int t0,
     }
   }
 }
+#endif  // ZKMI_EXPERIMENTS
 
 template <class F>
 __global__ void __launch_bounds__(256)
@@ -454,24 +458,20 @@ hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
 
 // stages [0, log_n) split into passes of <= 10 stages; pass k of a DIT transform
 // covers the low stages first, of a DIF transform the high stages first
-// ZKMI_NTT_RB (read once) selects the pass kernels:
-//   0 = the round-2 form: k_ntt_pass, one butterfly per thread and barrier, short strided passes in 2-column tiles
-//   3 = (default) the same kernel, but a short pass (S < 10: the third pass of N >= 2^21) takes 2^(11-S) adjacent
-//       columns per tile when that still leaves >= 512 tiles: 2048-element tiles with 1024 busy threads instead of
-//       8-element tiles in 64-thread workgroups (N = 2^22: 1.62 -> 1.1 ms per transform)
+// The product's pass kernel is k_ntt_pass (one butterfly per thread and barrier); a short pass (S < 10: the third pass of
+// N >= 2^21) takes 2^(11-S) adjacent columns per tile when that still leaves >= 512 tiles: 2048-element tiles with 1024
+// busy threads instead of 8-element tiles in 64-thread workgroups (N = 2^22: 1.62 -> 1.1 ms per transform).  That is mode 3
+// of the A/B library's ZKMI_NTT_RB switch:
+//   0 = the round-2 form: short strided passes in 2-column tiles
 //   1 / 2 = register-blocked passes k_ntt_pass_rb with 8 / 4 elements per thread (256- / 512-thread workgroups),
 //       2048-element tiles wherever the transform has them.  Measured in round 3 (profiles/r03/ntt_variants.txt): equal
 //       to the plain kernel at N = 2^20 alone (0.25 ms per transform), slower below 2^18 (fewer, larger workgroups),
 //       and the 8-element form costs the prover 2-3 % (one 256-VGPR wave per SIMD plus 105 KB of LDS leaves room for
-//       one accumulation wave instead of three beside it).  Kept selectable; not the default.
-static int ntt_rb_mode() {
-  static const int v = [] {
-    const char* e = getenv("ZKMI_NTT_RB");
-    return e ? atoi(e) : 3;
-  }();
-  return v;
-}
+//       one accumulation wave instead of three beside it)
+//   4 / 5 = one-wave workgroups on 1024- / 512-element tiles (5: three passes of <= 7 stages at N = 2^20)
+static int ntt_rb_mode() { return ZK_TUNE("ZKMI_NTT_RB", 3); }
 
+#ifdef ZKMI_EXPERIMENTS
 template <class F, bool DIF, bool LTW, int LOGE, int LOGR = 0, bool ONEW = false>
 static void launch_rb(dim3 grid, uint32_t tile_n, int S, hipStream_t stream, F* buf, const F* tw, int log_n, int t0, int Q,
                       const F* post, uint32_t* canon_out) {
@@ -480,6 +480,7 @@ static void launch_rb(dim3 grid, uint32_t tile_n, int S, hipStream_t stream, F* 
   hipLaunchKernelGGL((k_ntt_pass_rb<F, DIF, LTW, LOGE, LOGR, ONEW>), grid, dim3(tile_n >> (LOGE + LOGR)), words * sizeof(uint32_t), stream,
                      buf, tw, log_n, t0, S, Q, post, canon_out);
 }
+#endif
 
 template <class F, bool DIF>
 static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint32_t* canon_out,
@@ -523,7 +524,7 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
   // Plans of three passes (N > 2^20) gather a twiddle per butterfly (it comes out of L2); the local-twiddle + twist scheme
   // also covers them since round 3 (the twist of a middle pass is a power of the root of order 2^(t0+S)) but measured 5 %
   // slower there (2^21: 0.549 vs 0.518 ms): ZKMI_NTT_LOCAL3=1 selects it; mode 5 always uses it.
-  static const bool local3 = getenv("ZKMI_NTT_LOCAL3") && getenv("ZKMI_NTT_LOCAL3")[0] == '1';
+  const bool local3 = ZK_TUNE("ZKMI_NTT_LOCAL3", 0) == 1;
   const bool local_tw = np <= 2 || mode == 5 || local3;
   for (int k = 0; k < np; k++) {
     const Pass& p = DIF ? passes[np - 1 - k] : passes[k];
@@ -533,6 +534,7 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     const F* pp = last ? post : nullptr;
     uint32_t* co = last ? canon_out : nullptr;
     const dim3 grid(nblk, batch);
+#ifdef ZKMI_EXPERIMENTS
     if (rb == 5) {  // tile_n == 512 by construction (log_n >= 9)
       launch_rb<F, DIF, true, 2, 1, true>(grid, tile_n, p.S, stream, buf, tw, log_n, p.t0, p.Q, pp, co);  // 4 elements x 2 units per thread
       continue;
@@ -552,6 +554,7 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
       }
       continue;
     }
+#endif
     const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(F);
     if (tile_n >= 1024) {
       if (local_tw)
@@ -631,6 +634,7 @@ hipError_t ntt_mul_table(F* d, const F* table, uint32_t n, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef ZKMI_EXPERIMENTS
 template <class F>
 static hipError_t rb_enable_big_lds() {
   const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass_rb<F, true, true, 3>),  reinterpret_cast<const void*>(k_ntt_pass_rb<F, false, true, 3>),
@@ -646,6 +650,7 @@ static hipError_t rb_enable_big_lds() {
   }
   return hipSuccess;
 }
+#endif
 
 hipError_t ntt_enable_big_lds() {
   const void* fns[] = {reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, true, 1024>),
@@ -660,9 +665,13 @@ hipError_t ntt_enable_big_lds() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
+#ifdef ZKMI_EXPERIMENTS
   hipError_t e = rb_enable_big_lds<Fr28>();
   if (e == hipSuccess) e = rb_enable_big_lds<BnFr28>();
   return e;
+#else
+  return hipSuccess;
+#endif
 }
 
 template struct NttDomainT<Fr28>;
