@@ -63,25 +63,73 @@ class SplitMix64:
                 return v.to_bytes(32, "little")
 
 
+def withdraw_input(z, seed):
+    """The semantic inputs of one withdraw (zkmi_note_update), drawn from SplitMix64(seed); examples/bench_prove.c
+    draws the same ones in the same order."""
+    rng = SplitMix64(seed)
+    f = lambda: int.from_bytes(rng.fr_bytes(), "little")
+    tok = (f(), f())
+    bal = (rng.next() >> 1, rng.next() >> 1)
+    amount = bal[0] >> 3
+    user = f()
+    return z.note_update(amount, tok[0], user, (f(), f(), f()), (f(), f(), f()), [rng.next() & 1 for _ in range(10)],
+                         [f() for _ in range(10)], user, (tok[0], bal[0], tok[1], bal[1]))
+
+
 def relation_and_witness(z, relation, log_n, seeds):
-    """(r1cs, [witness bytes per seed]).  "poseidon": the reference's update_note relation with real
-    Poseidon-5 hashing (withdraw), padded to 2^log_n; "chain": the hash-free stand-in of the first builds."""
+    """(r1cs, [witness bytes per seed]), assignments generated on the HOST.  "poseidon": the reference's update_note
+    relation with real Poseidon-5 hashing (withdraw), padded to 2^log_n; "chain": the hash-free stand-in of the first builds."""
     if relation == "chain":
         return z.shielder_r1cs(log_n), [z.shielder_witness(log_n, s) for s in seeds]
     r1 = z.update_note_r1cs(log_n, 1)
-    wits = []
-    for s in seeds:
-        rng = SplitMix64(s)
-        f = lambda: int.from_bytes(rng.fr_bytes(), "little")
-        tok = (f(), f())
-        bal = (rng.next() >> 1, rng.next() >> 1)
-        amount = bal[0] >> 3
-        user = f()
-        inp = z.note_update(amount, tok[0], user, (f(), f(), f()), (f(), f(), f()), [rng.next() & 1 for _ in range(10)],
-                            [f() for _ in range(10)], user, (tok[0], bal[0], tok[1], bal[1]))
-        w, _, _ = z.update_note_witness(log_n, 1, inp)
-        wits.append(w)
-    return r1, wits
+    return r1, [z.update_note_witness(log_n, 1, withdraw_input(z, s))[0] for s in seeds]
+
+
+MAX_DISTINCT = 64  # distinct resident assignments per rank (32 MiB each at 2^20); longer runs cycle through them
+
+
+def resident_witnesses(z, ctx, relation, log_n, seeds):
+    """(r1cs, [device tensors]): one DISTINCT assignment per seed, resident in HBM before the timed region.  The
+    update_note relation generates them on the device (zkmi_update_note_witness_batch_dev: SURVEY.md 8f-1), the chain
+    stand-in on the host."""
+    if relation == "chain":
+        r1, wits = relation_and_witness(z, relation, log_n, seeds)
+        return r1, [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
+    r1 = z.update_note_r1cs(log_n, 1)
+    bufs = [torch.empty(32 << log_n, dtype=torch.uint8, device="cuda") for _ in seeds]
+    st = ctx.update_note_witness_batch_dev(log_n, 1, [withdraw_input(z, s) for s in seeds], [b.data_ptr() for b in bufs])
+    assert all(x == 0 for x in st), st
+    return r1, bufs
+
+
+def source_revision():
+    """What was measured: the last commit that touched the kernels / C ABI ('+dirty' when the tree differs from it) where
+    a git checkout is present, and always a digest of those sources themselves (the GPU box receives a snapshot without
+    .git) -- the same digest scripts/pmc_summary.py stamps into the PMC summary, so a profile that is older than the
+    library shows."""
+    out = {"git": None, "csrc_sha256_16": csrc_digest()}
+    try:
+        h = subprocess.run(["git", "log", "-1", "--format=%h", "--", "zk-apps_amd/csrc", "include"], cwd=ROOT, capture_output=True,
+                           text=True, timeout=10).stdout.strip()
+        d = subprocess.run(["git", "status", "--porcelain", "--", "zk-apps_amd/csrc", "include"], cwd=ROOT, capture_output=True,
+                           text=True, timeout=10).stdout.strip()
+        out["git"] = (h + ("+dirty" if d else "")) or None
+    except Exception:
+        pass
+    return out
+
+
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel / C-ABI sources, file names included, in sorted order"""
+    h = hashlib.sha256()
+    for d in ("zk-apps_amd/csrc", "include"):
+        base = os.path.join(ROOT, d)
+        for name in sorted(os.listdir(base)):
+            path = os.path.join(base, name)
+            if os.path.isfile(path) and name.endswith((".hip", ".hpp", ".h", "Makefile")):
+                h.update(name.encode() + b"\0")
+                h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_kernel_twins(z, ctx, log_n):
@@ -113,8 +161,8 @@ def cpu_kernel_twins(z, ctx, log_n):
 
 
 def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
-    """In-repo C++ oracle prover ("port") on the host cores, on a bounded sample:
-    one full proof at 2^sample_log_n, scaled linearly in N to 2^full_log_n."""
+    """In-repo C++ oracle prover ("port") on the host cores, on a bounded sample: one full proof at 2^sample_log_n
+    (default: the full size, N = 2^20), scaled linearly in N to 2^full_log_n when smaller."""
     from oracle import cpp as ocpp  # the checker; only this leg may touch oracle/
 
     ocpp.build()
@@ -136,9 +184,7 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
     }
     mats = [r1.export(m) for m in range(3)]
     r, s = rng.fr_bytes(), rng.fr_bytes()
-    t0 = time.time()
-    proof_cpu = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, key, wit, r, s)
-    dt = time.time() - t0
+    proof_cpu, dt = ocpp.groth16_prove_timed(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, key, wit, r, s)
     proof_gpu = ctx.groth16_prove(pk, wit, r, s)
     pk.free()
     scale = float(1 << (full_log_n - sample_log_n))
@@ -148,9 +194,9 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
         "unit": "proofs/s",
         "cores": ocpp.threads(),
         "kind": "port",
-        "sample": f"one full proof at N=2^{sample_log_n} with the in-repo C++ oracle prover "
-                  f"(arkworks-algorithm restatement, not arkworks) took {dt:.2f} s on {ocpp.threads()} threads; "
-                  f"scaled x{int(scale)} (linear in N) to N=2^{full_log_n}",
+        "sample": f"one full proof at N=2^{sample_log_n} with the in-repo C++ oracle prover (arkworks-algorithm restatement, "
+                  f"not arkworks; MSMs split over (window x point-chunk) tasks, one fork per NTT stage) took {dt:.2f} s on "
+                  f"{ocpp.threads()} threads" + (f"; scaled x{int(scale)} (linear in N) to N=2^{full_log_n}" if scale != 1 else ""),
         "proof_bytes_match_gpu": proof_cpu == proof_gpu,
         "kernel_twins_at_full_size": twins,
     }
@@ -192,6 +238,10 @@ def pmc_traffic(path, kernel):
     # wave-instructions of one proof = sum over the per-proof kernels of (avg per dispatch x dispatches per proof);
     # the summary's metadata row says how many proofs its passes ran
     meta = next((r for r in rows if r.get("kernel") == "__meta__"), None)
+    if meta and meta.get("csrc_sha256_16"):
+        # the sources the profiled library was built from against the sources this run measures
+        pmc_traffic.source["profiled_csrc_sha256_16"] = meta["csrc_sha256_16"]
+        pmc_traffic.source["same_sources_as_this_run"] = meta["csrc_sha256_16"] == csrc_digest()
     if meta and meta.get("proofs"):
         one_time = ("k_build_table", "k_fixed_base", "k_bases_convert", "k_bitrev_points", "k_power_table", "k_bitrev_copy")
         tot = 0.0
@@ -422,7 +472,7 @@ def main():
                     help="proofs = BASELINE configs[1]/[2] (headline); msm26 = configs[3], one 2^26-point G1 MSM split over the ranks")
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--msm-log-n", type=int, default=26)
-    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=20)
     ap.add_argument("--no-secondary", action="store_true", help="skip the H2D-inclusive and whole-MSM measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
@@ -468,19 +518,20 @@ def main():
 
     # --- one-time preparation (not timed): relation, trusted setup on the GPU --
     t0 = time.time()
-    r1, wits = relation_and_witness(z, args.relation, log_n, [0x5A4B0000 + 16 * rank + i for i in range(2)])
+    # one DISTINCT assignment and one fresh (r, s) per proof of the run (warm-up included), all resident before the timed
+    # region; seeds differ per rank.  (Rounds 1-3 alternated two assignments and two blinding pairs.)
+    n_distinct = min(args.steps + args.warmup, MAX_DISTINCT)
+    r1, d_wits = resident_witnesses(z, ctx, args.relation, log_n, [0x5A4B0000 + 4096 * rank + i for i in range(n_distinct)])
     rng = SplitMix64(0x5A4B0001)
     toxic = b"".join(rng.fr_bytes() for _ in range(5))
     pk, vk = ctx.groth16_setup(r1, toxic)
     setup_s = time.time() - t0
-    # two witnesses per rank (distinct seeds per rank), resident in HBM
-    d_wits = [torch.frombuffer(bytearray(w), dtype=torch.uint8).cuda() for w in wits]
-    rs = [(rng.fr_bytes(), rng.fr_bytes()) for _ in range(2)]
+    rs = [(rng.fr_bytes(), rng.fr_bytes()) for _ in range(n_distinct)]
     torch.cuda.synchronize()
 
     def run(first, count):
         """`count` proofs as one pipelined batch (three in flight on the GPU)."""
-        idx = [(first + i) % 2 for i in range(count)]
+        idx = [(first + i) % n_distinct for i in range(count)]
         return ctx.groth16_prove_batch_dev(pk, [d_wits[j].data_ptr() for j in idx], [rs[j][0] for j in idx], [rs[j][1] for j in idx])
 
     if args.warmup:
@@ -488,13 +539,16 @@ def main():
 
     ctx.prof_enable(True)
     ctx.prof_reset()
-    proofs, elapsed = timed_region(ctx, use_dist, lambda: run(0, args.steps))
+    proofs, elapsed = timed_region(ctx, use_dist, lambda: run(args.warmup, args.steps))
     proof = proofs[-1] if proofs else None
     ctx.prof_enable(False)
 
-    # correctness of what was timed: the last proof must pass the pairing verifier
-    last = (args.steps - 1) % 2
-    verified = z.groth16_verify(vk, wits[last][32 : 32 * r1.n_pub], proof) if proof is not None else False
+    # correctness of what was timed: the first and the last proof must pass the pairing verifier (publics = z[1 .. n_pub))
+    def publics_of(j):
+        return bytes(d_wits[j][32 : 32 * r1.n_pub].cpu().numpy().tobytes())
+
+    first_j, last_j = args.warmup % n_distinct, (args.warmup + args.steps - 1) % n_distinct
+    verified = bool(proofs) and z.groth16_verify(vk, publics_of(last_j), proof) and z.groth16_verify(vk, publics_of(first_j), proofs[0])
 
     phases = {k: ctx.prof_get(k) for k in pkg.PHASES}
     n_msm = r1.n_vars - 1
@@ -561,6 +615,8 @@ def main():
             else "hash-free chain stand-in",
             "curve": "BLS12-381",
             "independent_proofs_per_rank": args.steps,
+            "distinct_witnesses_per_rank": min(args.steps, n_distinct),
+            "fresh_r_s_per_proof": True,
             "proofs_in_flight_per_gpu": 3,
         },
         "verified_by_pairing": bool(verified),
@@ -569,12 +625,13 @@ def main():
         "phase_ms_per_proof": {k: v[0] / args.steps for k, v in phases.items()},
         "roofline": roofline,
         "hip_versions": dict(zip(("build", "runtime"), z.hip_versions())),
+        "source_revision": source_revision(),
     }
     if rank == 0 and not args.no_secondary:
         # PCIe-inclusive rate (SURVEY.md 8d "end-to-end proofs/s includes witness upload"): the same K proofs from
         # PINNED HOST witnesses; upload i+1 runs on the copy stream while proofs i-1 and i compute.  Never `value`.
-        h_wits = [torch.frombuffer(bytearray(w), dtype=torch.uint8).pin_memory() for w in wits]
-        idx = [i % 2 for i in range(args.steps)]
+        h_wits = [w.cpu().pin_memory() for w in d_wits]
+        idx = [(args.warmup + i) % n_distinct for i in range(args.steps)]
         ctx.groth16_prove_batch_host(pk, [h_wits[j].data_ptr() for j in idx[:2]], [rs[j][0] for j in idx[:2]], [rs[j][1] for j in idx[:2]])
         ctx.sync()
         t0 = time.perf_counter()
@@ -591,7 +648,8 @@ def main():
         for i in range(5):
             ctx.sync()
             t0 = time.perf_counter()
-            one = ctx.groth16_prove_dev(pk, d_wits[i % 2].data_ptr(), rs[i % 2][0], rs[i % 2][1])
+            j = (args.warmup + (i % 2) * 4) % n_distinct  # i = 4 ends on the batch's first proof
+            one = ctx.groth16_prove_dev(pk, d_wits[j].data_ptr(), rs[j][0], rs[j][1])
             lat.append(time.perf_counter() - t0)
         out["single_proof_latency_ms"] = {"median": 1e3 * sorted(lat)[2], "min": 1e3 * min(lat),
                                           "same_bytes_as_batch": one == proofs[0] if args.steps >= 1 else None,
@@ -609,6 +667,13 @@ def main():
             "frac": pmc_traffic.total_valu * out["value"] / world / VALU_ISSUE_PEAK,
             "note": "sum over all kernels of SQ_INSTS_VALU per proof (PMC summary) x proofs/s per GPU",
         }
+    if "valu_issue" in out["roofline"]:
+        # the roofline that actually bounds the dominant kernel, as an object of its own: `roofline` keeps the HBM figures
+        # BASELINE.json's metric asks for (bound = "hbm"), a consumer that classifies kernels by `bound` reads this one
+        vi = out["roofline"]["valu_issue"]
+        out["roofline_valu"] = {"kernel": out["roofline"]["kernel"], "bound": "valu", "achieved": vi["achieved"], "peak": vi["peak"],
+                                "unit": vi["unit"], "frac": vi["frac"],
+                                "whole_proof_frac": out["roofline"].get("valu_issue_whole_proof", {}).get("frac")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n, args.relation)
     if rank == 0:

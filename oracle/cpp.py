@@ -74,17 +74,27 @@ def witness_map(n_vars, n_pub, nc, log_n, mats, z, nthreads=0):
     return bytes(out)
 
 
-def groth16_prove(n_vars, n_pub, nc, log_n, mats, pk, z, r, s, nthreads=0):
-    """pk: dict of wire-format byte strings (alpha_g1, beta_g1, beta_g2, delta_g1,
+def groth16_prove_timed(n_vars, n_pub, nc, log_n, mats, pk, z, r, s, nthreads=0):
+    """(proof bytes, seconds spent inside the C++ prover): the marshalling of matrices and key into ctypes buffers --
+    Python work a native host would not do -- stays outside the clock.
+    pk: dict of wire-format byte strings (alpha_g1, beta_g1, beta_g2, delta_g1,
     delta_g2, a_query, b_g1_query, b_g2_query, h_query, l_query)."""
+    import time
+
     rp, cl, vl, keep = _csr_args(mats)
     out = (C.c_uint8 * 192)()
     names = ["alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"]
     bufs = [_buf(pk[k]) for k in names]
-    lib().oracle_groth16_prove(
-        C.c_uint32(n_vars), C.c_uint32(n_pub), C.c_uint32(nc), C.c_uint32(log_n), rp, cl, vl, *bufs, _buf(z), _buf(r), _buf(s), out, C.c_int(nthreads)
-    )
-    return bytes(out)
+    zb, rb, sb = _buf(z), _buf(r), _buf(s)
+    fn = lib().oracle_groth16_prove
+    t0 = time.perf_counter()
+    fn(C.c_uint32(n_vars), C.c_uint32(n_pub), C.c_uint32(nc), C.c_uint32(log_n), rp, cl, vl, *bufs, zb, rb, sb, out, C.c_int(nthreads))
+    dt = time.perf_counter() - t0
+    return bytes(out), dt
+
+
+def groth16_prove(n_vars, n_pub, nc, log_n, mats, pk, z, r, s, nthreads=0):
+    return groth16_prove_timed(n_vars, n_pub, nc, log_n, mats, pk, z, r, s, nthreads)[0]
 
 
 def groth16_setup(n_vars, n_pub, nc, log_n, mats, toxic, nthreads=0):

@@ -11,16 +11,19 @@
 //            + Cooley-Tukey), coset generator 7              [SURVEY row a6]
 //   * MSM  : ark_ec 0.4.2 VariableBaseMSM::msm_bigint — unsigned c-bit windows,
 //            c = 3 if n < 32 else floor(log2(n)*69/100)+2, one bucket set per
-//            window, running-sum reduction, windows in parallel  [rows a8/a9]
+//            window, running-sum reduction; (window, point-chunk) tasks in parallel  [rows a8/a9]
 //   * prove: ark_groth16 0.4 create_proof_with_assignment + LibsnarkReduction
 //            witness map                                       [rows a7/a10]
 // Deliberately different from the product: 64-bit limbs (unsigned __int128),
-// Jacobian coordinates, unsigned digits, window-parallel threading.
+// Jacobian coordinates, unsigned digits, (window x point-chunk) threading.
 //
 // Build: g++ -O3 -march=native -std=c++17 -shared -fPIC -pthread
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <thread>
 #include <vector>
 
@@ -204,7 +207,43 @@ static void write_affine(const Jac<F>& p, uint8_t* b) {
   x.to_bytes(b); y.to_bytes(b + Wire<F>::H);
 }
 
-static int n_threads() { unsigned n = std::thread::hardware_concurrency(); return n ? (int)n : 1; }
+// Threads worth starting = CPUs this process may actually use: logical CPUs, cut down by the affinity mask and by the
+// cgroup CPU quota (a container on a 256-thread host with cpu.max = "1600000 100000" gets 16 CPUs' worth of time; 256
+// runnable threads then burn the quota in a fraction of each period and the whole group is throttled: measured 0.49 s
+// against 0.23 s for a 2^18-term MSM).  bench.py reports this number as `cores`.
+static int n_threads() {
+  long n = (long)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const long a = CPU_COUNT(&set);
+    if (a >= 1 && a < n) n = a;
+  }
+  auto quota = [](const char* path, const char* path_period) -> double {
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;
+    char a[64] = {0}, b[64] = {0};
+    const int got = fscanf(f, "%63s %63s", a, b);
+    fclose(f);
+    if (got < 1 || !strcmp(a, "max") || atof(a) <= 0) return 0;
+    double period = got >= 2 ? atof(b) : 0;
+    if (period <= 0 && path_period) {
+      FILE* g = fopen(path_period, "r");
+      if (g) {
+        if (fscanf(g, "%63s", b) == 1) period = atof(b);
+        fclose(g);
+      }
+    }
+    return period > 0 ? atof(a) / period : 0;
+  };
+  double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                                  // cgroup v2
+  if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");  // cgroup v1
+  if (q > 0) {
+    const long c = (long)(q + 0.999);
+    if (c >= 1 && c < n) n = c;
+  }
+  return (int)n;
+}
 
 template <class Fn>
 static void parallel_for(size_t n, int threads, Fn fn) {
@@ -224,19 +263,61 @@ static int ark_window(size_t n) {
   return lg * 69 / 100 + 2;
 }
 
+// Work split: arkworks' msm_bigint hands whole WINDOWS to rayon, which keeps at most ceil(255 / c) = 17 threads busy at
+// n = 2^20 -- on a 256-thread host that understates what a CPU can do.  Here the points are cut into chunks as well: a
+// task = (window, chunk) with its own bucket set, the chunk sums of a window are added afterwards.  The window width
+// follows from the thread count (more tasks -> fewer points per bucket set -> narrower windows): with one thread per
+// window it is arkworks' own rule.  The result is the same group element either way.
+struct MsmSplit {
+  int c, nwin, nchunk;
+};
+static MsmSplit msm_split(size_t n, int threads) {
+  const int c_ark = ark_window(n);
+  MsmSplit best = {c_ark, (255 + c_ark - 1) / c_ark, 1};
+  if (threads <= 1 || n < 4096) return best;
+  // time ~ rounds of tasks x (insertions of a task + 3 additions per bucket of its running-sum reduction); the search
+  // covers arkworks' own width (one chunk) and every narrower width with up to 4 tasks per thread
+  double best_cost = -1;
+  for (int c = 6; c <= c_ark; c++) {
+    const int nwin = (255 + c - 1) / c;
+    const int max_chunk = (4 * threads + nwin - 1) / nwin;
+    for (int nchunk = 1; nchunk <= max_chunk; nchunk++) {
+      if (nchunk > 1 && n / (size_t)nchunk < (size_t(1) << c)) break;  // at least one point per bucket
+      const size_t tasks = (size_t)nwin * nchunk;
+      const double rounds = (double)((tasks + threads - 1) / threads);
+      const double cost = rounds * ((double)n / nchunk + 3.0 * (double)(size_t(1) << c));
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        best = {c, nwin, nchunk};
+      }
+    }
+  }
+  return best;
+}
+
 template <class F>
 static Jac<F> msm(const uint8_t* scalars, const uint8_t* bases, size_t n, int threads) {
-  const int c = ark_window(n);
-  const int num_bits = 255;
-  const int nwin = (num_bits + c - 1) / c;
+  const MsmSplit sp = msm_split(n, threads);
+  const int c = sp.c, nwin = sp.nwin, nchunk = sp.nchunk;
   std::vector<F> bx(n), by(n);
   std::vector<uint8_t> binf(n);
-  parallel_for(n, threads, [&](size_t i) { bool inf; read_affine<F>(bases + (size_t)Wire<F>::W * i, &bx[i], &by[i], &inf); binf[i] = inf; });
-  std::vector<Jac<F>> wsum(nwin, Jac<F>::inf());
-  parallel_for((size_t)nwin, threads, [&](size_t w) {
+  {
+    const size_t par = n >= 4096 ? (size_t)threads : 1;
+    parallel_for(par, (int)par, [&](size_t t) {
+      for (size_t i = n * t / par; i < n * (t + 1) / par; i++) {
+        bool inf;
+        read_affine<F>(bases + (size_t)Wire<F>::W * i, &bx[i], &by[i], &inf);
+        binf[i] = inf;
+      }
+    });
+  }
+  std::vector<Jac<F>> part((size_t)nwin * nchunk, Jac<F>::inf());
+  parallel_for((size_t)nwin * nchunk, threads, [&](size_t task) {
+    const size_t w = task / nchunk, q = task % nchunk;
+    const size_t lo = n * q / nchunk, hi = n * (q + 1) / nchunk;
     std::vector<Jac<F>> buckets((size_t(1) << c) - 1, Jac<F>::inf());
     const int bit = (int)w * c;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = lo; i < hi; i++) {
       if (binf[i]) continue;
       const uint64_t* k = reinterpret_cast<const uint64_t*>(scalars + 32 * i);
       uint64_t limbs[5] = {k[0], k[1], k[2], k[3], 0};
@@ -248,12 +329,12 @@ static Jac<F> msm(const uint8_t* scalars, const uint8_t* bases, size_t n, int th
     }
     Jac<F> run = Jac<F>::inf(), acc = Jac<F>::inf();
     for (size_t b = buckets.size(); b-- > 0;) { run = run.add(buckets[b]); acc = acc.add(run); }
-    wsum[w] = acc;
+    part[task] = acc;
   });
   Jac<F> total = Jac<F>::inf();
   for (int w = nwin - 1; w >= 0; w--) {
     for (int i = 0; i < c; i++) total = total.dbl();
-    total = total.add(wsum[w]);
+    for (int q = 0; q < nchunk; q++) total = total.add(part[(size_t)w * nchunk + q]);
   }
   return total;
 }

@@ -6,8 +6,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -41,7 +44,11 @@ def main():
             row[c + "_dispatches"] = len(vals)
         rows.append(row)
     rows.sort(key=lambda r: -r.get("SQ_INSTS_VALU_avg_per_dispatch", 0) * r.get("SQ_INSTS_VALU_dispatches", 0))
-    rows.insert(0, {"kernel": "__meta__", "proofs": proofs, "passes": dirs})
+    # the digest of the kernel sources the profiled library was built from (bench.py prints the same digest of the
+    # sources it runs: a summary older than the library shows as a mismatch in roofline.traffic_source)
+    import bench
+
+    rows.insert(0, {"kernel": "__meta__", "proofs": proofs, "passes": dirs, "csrc_sha256_16": bench.csrc_digest()})
     json.dump(rows, open(out_path, "w"), indent=1)
     print("wrote", out_path, len(rows), "kernels")
 

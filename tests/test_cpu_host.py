@@ -745,6 +745,35 @@ def _build_c_example(tmp_path):
     return exe
 
 
+def _build_c_bench(tmp_path):
+    """examples/bench_prove.c: plain C that also calls the HIP runtime directly (hipMalloc), linked against /opt/rocm --
+    the runtime libzkmi.so was built for; no Python, no PyTorch in that process."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bench_prove")
+    lib_dir = os.path.join(root, "zk-apps_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", os.path.join(root, "examples", "bench_prove.c"), "-L" + lib_dir, "-lzkmi",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_c_bench_builds_and_fails_loudly_without_gpu(tmp_path):
+    """examples/bench_prove.c (the torch-free twin of bench.py + scripts/churn.py) compiles with -Wall -Werror against the
+    header; without a GPU it stops at zkmi_ctx_create."""
+    import subprocess
+
+    import torch
+
+    exe = _build_c_bench(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the GPU test")
+    p = subprocess.run([exe, "--proofs", "1"], capture_output=True, text=True)
+    assert p.returncode == 2 and "no CPU fallback" in p.stderr
+
+
 def test_c_example_builds_against_the_header_and_fails_loudly_without_gpu(tmp_path):
     """include/zkmi.h is plain C: examples/prove_withdraw.c compiles with gcc -Wall -Werror and links
     libzkmi.so; on a machine without a GPU it stops at zkmi_ctx_create (no CPU fallback)."""

@@ -1,5 +1,7 @@
 """GPU parity tests proper: HIP path (through the C ABI) vs the oracle, on the
 committed golden fixtures and on seeded inputs.  Bit-exact (integer work)."""
+import os
+
 import pytest
 
 from conftest import golden
@@ -1086,6 +1088,43 @@ def test_c_example_proves_and_verifies(tmp_path):
     assert "proof of the withdraw: verified" in p.stdout
     assert "amount tampered: rejected" in p.stdout
     assert "-> -6 (ZKMI_ERR_ACCOUNT_UPDATE = -6)" in p.stdout
+
+
+def test_c_bench_under_the_native_runtime_matches_the_python_path(ctx, zk, tmp_path):
+    """examples/bench_prove.c in a fresh process WITHOUT Python or PyTorch: libzkmi.so bound to the /opt/rocm runtime it
+    was built for (every other GPU test runs on the PyTorch wheel's bundled HIP runtime, which the binding preloads).
+    Short form of profiles/r04's run: 6 + 1 proofs at 2^14 from device-generated assignments, every proof verified by
+    pairing inside the program, 80 churn operations (setups 2^13..2^17, forced group sizes, batches, single and
+    host-witness proofs, error path, MSMs, NTTs, second contexts); the dumped proof bytes must equal this process's
+    proofs from the same seeds."""
+    import json
+    import subprocess
+
+    import bench
+    from test_cpu_host import _build_c_bench
+
+    exe = _build_c_bench(tmp_path)
+    dump = str(tmp_path / "proofs.bin")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ZKMI_")}
+    p = subprocess.run([exe, "--log-n", "14", "--proofs", "6", "--warmup", "1", "--churn", "80", "--dump", dump], capture_output=True,
+                       text=True, timeout=1200, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "same release" in p.stdout and "clean" in p.stdout
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["failed"] == 0 and line["verified_by_pairing"] == 7 and line["hip_build"] // 100000 == line["hip_runtime"] // 100000
+    # the same seven proofs through the Python binding (bench.py's generator: seeds 0x5A4B0000 + i, toxic + (r, s) drawn
+    # from SplitMix64(0x5A4B0001))
+    r1, wits = bench.relation_and_witness(zk, "poseidon", 14, [0x5A4B0000 + i for i in range(7)])
+    rng = bench.SplitMix64(0x5A4B0001)
+    toxic = b"".join(rng.fr_bytes() for _ in range(5))
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    want = b""
+    for w in wits:
+        r, s = rng.fr_bytes(), rng.fr_bytes()
+        want += ctx.groth16_prove(pk, w, r, s)
+    pk.free()
+    r1.free()
+    assert open(dump, "rb").read() == want
 
 
 # ---- the headline configuration inside the suite (BASELINE configs 1 and 2) ----------------------
