@@ -383,8 +383,9 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     """BASELINE config 3: one G1 MSM of 2^msm_log_n points, split by POINTS over the ranks (SURVEY.md 8e's preferred
     partition; BASELINE.json words it as a windows split -- see DESIGN.md section 6 for why points).  Every rank sorts and
     accumulates its n / world points with the window width planned from the global n and emits one partial sum per window;
-    the ranks all-gather those nwin x 96 bytes over RCCL and every rank adds and Horner-combines them (EC addition is
-    not an RCCL reduction op: this IS the all-reduce).  A step = one whole MSM; value = algorithmic GB/s of the job."""
+    the ranks all-gather the device-resident partial sums over RCCL (zkmi_msm_g1_allgather_combine: ncclAllGather of
+    ncclUint8 behind the C ABI) and every rank adds and Horner-combines them (EC addition is not an RCCL reduction op: this
+    IS the all-reduce).  A step = one whole MSM; value = algorithmic GB/s of the job."""
     par = __import__("zk_apps_amd.parallel", fromlist=["x"])
     n = 1 << args.msm_log_n
     a, b = par.shard_units(n, rank, world)
@@ -408,10 +409,25 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         wtot += sum(x << (8 * k) for k, x in enumerate(v[1]))
     bases = ctx.bases_g1_synthetic_range(a, m)
 
+    # the exchange behind the C ABI: zkmi_comm (RCCL; torch.distributed only carries rank 0's 128-byte id), partial sums
+    # all-gathered from HBM on the reduction stream, combined on every rank -- also at one rank (a world of 1)
+    # (RCCL prints a version banner on STDOUT when its first communicator comes up: sent to stderr, stdout carries the one JSON line)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if use_dist:
+            comm = par.rccl_comm(z, ctx)
+        else:
+            comm = ctx.comm_init(1, 0, z.comm_unique_id())
+        one_ = ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)  # first collective (workspaces, RCCL channels)
+        del one_
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+
     def one():
-        windows, nwin, cbits = ctx.msm_g1_windows_dev(raw.data_ptr(), m, bases, n)
-        parts = par.allgather_bytes(windows) if use_dist else [windows]
-        return z.msm_g1_combine(b"".join(parts), len(parts), nwin, cbits)
+        return ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
 
     for _ in range(max(1, args.warmup)):  # the first call allocates the workspaces
         one()
@@ -427,6 +443,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+    comm.free()
     phases = {k: ctx.prof_get(k) for k in pkg.PHASES}
     ms_tot, launches = phases["msm_accum_g1"]
     avg_ms = ms_tot / max(1, launches)

@@ -44,6 +44,7 @@ extern "C" {
 #define ZKMI_ERR_ACCOUNT_UPDATE (-6)  /* = ZkpError::AccountUpdateError */
 #define ZKMI_ERR_OPERATION_COMBINE (-7) /* = ZkpError::OperationCombineError */
 #define ZKMI_ERR_UNSATISFIED (-8)     /* witness does not satisfy the relation */
+#define ZKMI_ERR_RCCL (-9)            /* RCCL missing or a collective failed (see zkmi_last_error) */
 
 typedef struct zkmi_ctx zkmi_ctx;
 typedef struct zkmi_bases_g1 zkmi_bases_g1;
@@ -123,6 +124,24 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
                                 uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin, uint32_t* out_window_bits);
 int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uint32_t nwin, uint32_t window_bits,
                             uint8_t out_affine[96]);
+
+/* The same exchange behind the C ABI, one process per GPU over RCCL ("ncclAllGather, dtype ncclUint8,
+ * + local EC summation and Horner combine on each rank"): the rank's partial sums stay in HBM, are all-gathered on the
+ * reduction stream and combined on every rank.  libzkmi.so resolves RCCL at first use (the copy already in the process,
+ * else librccl.so.1): nothing here is needed to load the library on a host without RCCL.
+ *   zkmi_comm_unique_id   rank 0 draws the 128-byte id (ncclGetUniqueId); the HOST distributes the bytes to all ranks
+ *   zkmi_comm_init        every rank: ncclCommInitRank on ctx's device (collective call)
+ *   zkmi_comm_from_nccl   wrap an ncclComm_t the host created itself (same RCCL instance; not destroyed with the handle)
+ *   zkmi_msm_g1_allgather_combine  this rank's n terms (plan from plan_n = the GLOBAL number of terms, equal on all ranks),
+ *                         all-gather, combination: the FULL result on every rank.  Collective: all ranks call it.
+ * ZKMI_ERR_RCCL: RCCL not found, or a call failed (zkmi_last_error). */
+typedef struct zkmi_comm zkmi_comm;
+int32_t zkmi_comm_unique_id(uint8_t out_id[128]);
+int32_t zkmi_comm_init(zkmi_ctx* ctx, uint32_t n_ranks, uint32_t rank, const uint8_t id[128], zkmi_comm** out);
+int32_t zkmi_comm_from_nccl(zkmi_ctx* ctx, void* nccl_comm, uint32_t n_ranks, uint32_t rank, zkmi_comm** out);
+int32_t zkmi_comm_destroy(zkmi_comm* comm);
+int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
+                                      const zkmi_bases_g1* bases, uint64_t plan_n, uint8_t out_affine[96]);
 
 /* Same split driven from ONE process holding one ctx per GPU (SURVEY.md §8b
  * "zkmi_msm_g1_multi", BASELINE config 3): device d holds counts[d] scalars at

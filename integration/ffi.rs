@@ -23,6 +23,7 @@ pub const ZKMI_MAX_TREE_HEIGHT: usize = 32;
 #[repr(C)] pub struct zkmi_r1cs { _p: [u8; 0] }
 #[repr(C)] pub struct zkmi_bases_g1 { _p: [u8; 0] }
 #[repr(C)] pub struct zkmi_bases_g2 { _p: [u8; 0] }
+#[repr(C)] pub struct zkmi_comm { _p: [u8; 0] }
 
 /// = `Scalar { bytes: [u8; 32] }` (mocked_zk/src/scalar.rs:1-6), little-endian
 #[repr(C)] #[derive(Clone, Copy)] pub struct zkmi_scalar { pub bytes: [u8; 32] }
@@ -146,4 +147,11 @@ extern "C" {
     pub fn zkmi_msm_g1_windows_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g1, plan_n: u64,
                                    out_windows_affine: *mut u8, out_nwin: *mut u32, out_window_bits: *mut u32) -> i32;
     pub fn zkmi_msm_g1_combine(windows_affine: *const u8, n_ranks: u32, nwin: u32, window_bits: u32, out_affine: *mut u8) -> i32;
+    // the same exchange over RCCL, one process per GPU (rank 0 draws the id, the host distributes its 128 bytes)
+    pub fn zkmi_comm_unique_id(out_id: *mut u8) -> i32;
+    pub fn zkmi_comm_init(ctx: *mut zkmi_ctx, n_ranks: u32, rank: u32, id: *const u8, out: *mut *mut zkmi_comm) -> i32;
+    pub fn zkmi_comm_from_nccl(ctx: *mut zkmi_ctx, nccl_comm: *mut core::ffi::c_void, n_ranks: u32, rank: u32, out: *mut *mut zkmi_comm) -> i32;
+    pub fn zkmi_comm_destroy(comm: *mut zkmi_comm) -> i32;
+    pub fn zkmi_msm_g1_allgather_combine(ctx: *mut zkmi_ctx, comm: *mut zkmi_comm, d_scalars: *const core::ffi::c_void, n: u64,
+                                         bases: *const zkmi_bases_g1, plan_n: u64, out_affine: *mut u8) -> i32;
 }

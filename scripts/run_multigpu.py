@@ -133,6 +133,24 @@ def main():
                               % (args.msm_log_n, world), "matches_closed_form_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
                               "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
         assert okt.item() == 1
+        # the same exchange behind the C ABI: zkmi_comm (RCCL communicator created from rank 0's 128-byte id) +
+        # zkmi_msm_g1_allgather_combine (ncclAllGather of the device-resident partial sums, combination on every rank)
+        comm = par.rccl_comm(z, ctx)
+        ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)  # untimed
+        barrier()
+        t0 = time.perf_counter()
+        got_c = ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        okt = torch.tensor([1 if got_c == want and got_c == got else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        comm.free()
+        if rank == 0:
+            print(json.dumps({"config": 3, "workload": "the same MSM through zkmi_msm_g1_allgather_combine (RCCL behind the C ABI)",
+                              "matches_closed_form_and_python_path_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
+                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
+        assert okt.item() == 1
         # the same split against PREPARED bases (an SRS serves many MSMs: zkmi_bases_g1_prepare once per rank): every
         # rank's share is then one point (shared-bucket schedule), the ranks all-gather 96 bytes each and add
         bases.prepare()

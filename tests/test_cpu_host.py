@@ -233,8 +233,14 @@ def test_msm_plans_are_consistent(zk):
                     continue
                 assert zk.lib.zkmi_msm_plan_query(C.c_uint64(n), C.c_int32(shared), out) == 0
                 c, nd, parts, nb, seg_log, heavy = list(out)
-                assert 4 <= c <= 22 and nd * c >= 255 and nb <= 1 << 15 and (nb & (nb - 1)) == 0
+                assert 4 <= c <= 22 and nd * c >= 255 and (nb & (nb - 1)) == 0
                 assert (1 << seg_log) <= nb and heavy >= 1
+                # a tile histogram holds 2^15 counters: shared plans cut the bucket set into partitions of that size, and
+                # so does the windowed plan of >= 2^24 terms (20-bit windows = 16 partitions each, at most 256 groups)
+                if shared or n < 1 << 24:
+                    assert nb <= 1 << 15
+                else:
+                    assert c == 20 and nb == 1 << 19 and parts * (nb >> 15) <= 256
                 if shared:
                     assert parts * nb == 1 << (c - 1) and parts <= 64
                     if lg <= 26:

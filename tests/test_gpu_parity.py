@@ -344,6 +344,47 @@ def test_msm_g1_point_split_matches_full(ctx, zk):
         x.free()
 
 
+def test_msm_g1_big_window_plan_on_small_slices(ctx, zk):
+    """The windowed schedule of >= 2^24 terms uses 20-bit windows, each sorted as 16 partitions of 2^15 buckets
+    (MsmSort::run_windowed_big).  A rank of a point-split MSM runs that plan on its slice whatever the slice's size: here
+    two slices of 2^17 terms under the plan of a 2^24-term MSM -- uniform scalars (every bucket nearly empty), the
+    witness-like mix (one bucket holds 20 % of the points: the cooperative kernel), and scalars drawn from 600 values
+    (7 800 buckets above the heavy threshold: the wide tail launch of the cooperative kernel) -- must combine to the
+    result of the 16-bit plan, which is compared with the C++ oracle."""
+    import torch
+
+    from oracle import cpp as ocpp
+
+    assert zk.msm_plan_query(1 << 24)[0] == 20 and zk.msm_plan_query((1 << 24) - 1)[0] == 16
+    n = 1 << 18
+    half = n // 2
+    b = ctx.bases_g1_synthetic(n)
+    pts = b.read(0, n)
+    lo = ctx.bases_g1(pts[: 96 * half], check=False)
+    hi = ctx.bases_g1(pts[96 * half :], check=False)
+    g = torch.Generator().manual_seed(77)
+    uni = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    uni[:, 31] &= 0x3F
+    mix = uni.clone()
+    kind = torch.rand(n, generator=g)
+    mix[kind < 0.4] = 0
+    one = (kind >= 0.4) & (kind < 0.6)
+    mix[one] = 0
+    mix[one, 0] = 1
+    few = uni[:600][torch.randint(0, 600, (n,), generator=g)]
+    for name, sc in (("uniform", uni), ("witness-like", mix), ("600 values", few)):
+        d = sc.contiguous().cuda()
+        torch.cuda.synchronize()
+        full = ctx.msm_g1_dev(d.data_ptr(), n, b)
+        assert full == ocpp.msm_g1(sc.numpy().tobytes(), pts), name
+        w0, nwin, cb = ctx.msm_g1_windows_dev(d.data_ptr(), half, lo, 1 << 24)
+        w1, nwin1, cb1 = ctx.msm_g1_windows_dev(d[half:].data_ptr(), half, hi, 1 << 24)
+        assert (nwin, cb, nwin1, cb1) == (13, 20, 13, 20), name
+        assert zk.msm_g1_combine(w0 + w1, 2, nwin, cb) == full, name
+    for x in (b, lo, hi):
+        x.free()
+
+
 def test_msm_g1_multi_ctx_matches_full(ctx, zk):
     """zkmi_msm_g1_multi: one process, one ctx per slice (second ctx on GPU 1 when the box has one,
     otherwise a second ctx on GPU 0); uneven slices, result == unsplit MSM == closed form."""
@@ -1310,6 +1351,26 @@ def test_multigpu_script_world1():
     c2, c3 = out[0], out[1]
     assert c2["config"] == 2 and c2["all_verified"] and c2["proofs_gathered"] == 6
     assert c3["config"] == 3 and c3["matches_closed_form_on_every_rank"]
+    # the exchange behind the C ABI (zkmi_comm + zkmi_msm_g1_allgather_combine over RCCL) == the Python exchange == closed form
+    assert out[2]["matches_closed_form_and_python_path_on_every_rank"]
+
+
+def test_rccl_exchange_behind_the_c_abi_world1(ctx, zk):
+    """zkmi_comm_unique_id / zkmi_comm_init / zkmi_msm_g1_allgather_combine in THIS process (a world of one rank, no
+    torch.distributed involved): the RCCL all-gather of the device-resident partial sums + combination gives the plain
+    MSM's result, under the 16-bit plan and under the partitioned 20-bit plan of a 2^24-term global size."""
+    import torch
+
+    n = (1 << 17) + 77
+    raw, tot, wtot = _torch_scalars(n, 21)
+    b = ctx.bases_g1_synthetic(n)
+    want = ctx.msm_g1_dev(raw.data_ptr(), n, b)
+    assert want == _closed_form_g1(tot, wtot)
+    comm = ctx.comm_init(1, 0, zk.comm_unique_id())
+    assert ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), n, b, n) == want
+    assert ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), n, b, 1 << 24) == want
+    comm.free()
+    b.free()
 
 
 def test_multigpu_script_world2():
@@ -1321,6 +1382,7 @@ def test_multigpu_script_world2():
     out = _run_multigpu(2, ["--log-n", "16", "--proofs", "6", "--msm-log-n", "20"])
     assert out[0]["all_verified"] and out[0]["proofs_gathered"] == 6 and out[0]["n_gpus"] == 2
     assert out[1]["matches_closed_form_on_every_rank"] and out[1]["n_gpus"] == 2
+    assert out[2]["matches_closed_form_and_python_path_on_every_rank"] and out[2]["n_gpus"] == 2
 
 
 def test_arkworks_key_layout_load_and_write(ctx, zk):

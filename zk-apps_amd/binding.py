@@ -237,6 +237,18 @@ class Zkmi:
         self._chk(self.lib.zkmi_pairing(_buf(p), _buf(q), out))
         return bytes(out)
 
+    def msm_plan_query(self, n, shared=False):
+        """(digit bits, digits, windows | partitions, buckets per window | partition, log2 segment length, heavy threshold)"""
+        out = (C.c_uint32 * 6)()
+        self._chk(self.lib.zkmi_msm_plan_query(C.c_uint64(n), C.c_int32(1 if shared else 0), out))
+        return tuple(out)
+
+    def comm_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0 calls; the host layer hands them to every rank)"""
+        out = (C.c_uint8 * 128)()
+        self._chk(self.lib.zkmi_comm_unique_id(out))
+        return bytes(out)
+
     def msm_g1_combine(self, windows, n_ranks, nwin, window_bits):
         out = (C.c_uint8 * 96)()
         self._chk(self.lib.zkmi_msm_g1_combine(_buf(windows), C.c_uint32(n_ranks), C.c_uint32(nwin), C.c_uint32(window_bits), out))
@@ -545,6 +557,18 @@ class R1cs:
             self.h = None
 
 
+class Comm:
+    """zkmi_comm: an RCCL communicator behind the C ABI (include/zkmi.h)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zkmi_comm_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """One HIP device + stream + resident workspaces (zkmi_ctx)."""
 
@@ -714,6 +738,18 @@ class Context:
 
     def poseidon_merkle_roots_dev(self, d_leaves, d_shape, d_paths, depth, n, d_roots, field=0):
         self._chk(self.lib.zkmi_poseidon_merkle_roots_dev(self.h, C.c_int32(field), C.c_void_p(d_leaves), C.c_void_p(d_shape), C.c_void_p(d_paths), C.c_uint32(depth), C.c_uint64(n), C.c_void_p(d_roots)))
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        """RCCL communicator of this context's device (collective: every rank calls it with rank 0's id)."""
+        h = C.c_void_p()
+        self._chk(self.lib.zkmi_comm_init(self.h, C.c_uint32(n_ranks), C.c_uint32(rank), _buf(unique_id), C.byref(h)))
+        return Comm(self, h)
+
+    def msm_g1_allgather_combine(self, comm, dptr, n, bases, plan_n):
+        """This rank's slice of a point-split MSM + the RCCL exchange + combination (collective); the full result."""
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_allgather_combine(self.h, comm.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, C.c_uint64(plan_n), out))
+        return bytes(out)
 
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
         out = (C.c_uint8 * (96 * 64))()

@@ -1,0 +1,198 @@
+// zkmi — the exchange step of a point-split MSM over RCCL, behind the C ABI (BASELINE config 3).
+//
+// One process per GPU; every rank runs the bucket method over its slice of the points with the window plan of the GLOBAL
+// size and leaves per-(window, job) partial sums in HBM.  RCCL has no reduction over an elliptic-curve group law, so the
+// "all-reduce" of BASELINE.json is an all-gather of the raw partials (ncclUint8, 16 x 13 x 192 B = 40 KB per rank at
+// 2^26 terms) followed by the same combination on every rank: windows_from_partials per rank, one addition per window and
+// rank, Horner over the windows.  The gather runs on the reduction stream, straight behind the tree sums, from the device
+// buffer the reduction wrote -- no host round trip in front of the collective.
+//
+// libzkmi.so does NOT link RCCL: the five entry points it needs are resolved at first use, from an RCCL already in the
+// process (the host's own: a communicator handed to zkmi_comm_from_nccl must belong to the library whose ncclAllGather is
+// called on it) or else from librccl.so.1.  A host without RCCL can load the library and use everything but this file.
+#include <dlfcn.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "ctx.hpp"
+
+namespace {
+
+// the slice of rccl.h this file uses (the header is not needed at build time; values from rccl.h of ROCm 7.2:
+// NCCL_UNIQUE_ID_BYTES = 128, ncclUint8 = 1, ncclSuccess = 0)
+typedef void* nccl_comm_t;
+struct nccl_unique_id {
+  char internal[128];
+};
+typedef int (*fn_get_unique_id)(nccl_unique_id*);
+typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, nccl_unique_id, int);
+typedef int (*fn_comm_destroy)(nccl_comm_t);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
+typedef const char* (*fn_error_string)(int);
+
+struct Rccl {
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_all_gather all_gather = nullptr;
+  fn_error_string error_string = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    // an RCCL that is already mapped wins (dlopen by SONAME returns the loaded object; RTLD_NOLOAD first so that a process
+    // that brought its own copy under another path is honoured through the global scope as well)
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      x.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "librccl.so.1");
+      return x;
+    }
+    x.get_unique_id = reinterpret_cast<fn_get_unique_id>(dlsym(h, "ncclGetUniqueId"));
+    x.comm_init_rank = reinterpret_cast<fn_comm_init_rank>(dlsym(h, "ncclCommInitRank"));
+    x.comm_destroy = reinterpret_cast<fn_comm_destroy>(dlsym(h, "ncclCommDestroy"));
+    x.all_gather = reinterpret_cast<fn_all_gather>(dlsym(h, "ncclAllGather"));
+    x.error_string = reinterpret_cast<fn_error_string>(dlsym(h, "ncclGetErrorString"));
+    x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_gather;
+    if (!x.ok) x.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    return x;
+  }();
+  return r;
+}
+
+}  // namespace
+
+struct zkmi_comm {
+  zkmi_ctx* ctx = nullptr;
+  nccl_comm_t comm = nullptr;
+  uint32_t n_ranks = 0, rank = 0;
+  bool owned = false;         // created by zkmi_comm_init (destroyed with the handle) / borrowed from the host
+  void* d_gather = nullptr;   // n_ranks x partial bytes, device
+  uint64_t gather_cap = 0;
+};
+
+using namespace zkmi;
+
+static int32_t rccl_fail(zkmi_ctx* ctx, int code, const char* where) {
+  const Rccl& r = rccl();
+  const std::string msg = std::string(where) + ": " + (r.error_string ? r.error_string(code) : "RCCL error");
+  if (ctx) ctx->err = msg;
+  return ZKMI_ERR_RCCL;
+}
+
+extern "C" {
+
+int32_t zkmi_comm_unique_id(uint8_t out_id[128]) {
+  if (!out_id) return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ZKMI_ERR_RCCL;
+  nccl_unique_id id;
+  if (r.get_unique_id(&id) != 0) return ZKMI_ERR_RCCL;
+  memcpy(out_id, id.internal, 128);
+  return ZKMI_OK;
+}
+
+int32_t zkmi_comm_init(zkmi_ctx* ctx, uint32_t n_ranks, uint32_t rank, const uint8_t id[128], zkmi_comm** out) {
+  ZK_ENTER(ctx);
+  if (!id || !out || n_ranks == 0 || rank >= n_ranks) return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
+  nccl_unique_id uid;
+  memcpy(uid.internal, id, 128);
+  nccl_comm_t c = nullptr;
+  const int rc = r.comm_init_rank(&c, (int)n_ranks, uid, (int)rank);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
+  zkmi_comm* k = new (std::nothrow) zkmi_comm();
+  if (!k) {
+    (void)r.comm_destroy(c);
+    return ZKMI_ERR_BAD_ARG;
+  }
+  k->ctx = ctx;
+  k->comm = c;
+  k->n_ranks = n_ranks;
+  k->rank = rank;
+  k->owned = true;
+  *out = k;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_comm_from_nccl(zkmi_ctx* ctx, void* nccl_comm, uint32_t n_ranks, uint32_t rank, zkmi_comm** out) {
+  ZK_ENTER(ctx);
+  if (!nccl_comm || !out || n_ranks == 0 || rank >= n_ranks) return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
+  zkmi_comm* k = new (std::nothrow) zkmi_comm();
+  if (!k) return ZKMI_ERR_BAD_ARG;
+  k->ctx = ctx;
+  k->comm = nccl_comm;
+  k->n_ranks = n_ranks;
+  k->rank = rank;
+  k->owned = false;
+  *out = k;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_comm_destroy(zkmi_comm* comm) {
+  if (!comm) return ZKMI_ERR_BAD_ARG;
+  if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+  if (comm->d_gather) (void)hipFree(comm->d_gather);
+  if (comm->owned && comm->comm && rccl().ok) (void)rccl().comm_destroy(comm->comm);
+  delete comm;
+  return ZKMI_OK;
+}
+
+// This rank's slice of a point-split MSM (n scalars at d_scalars against `bases`, window plan of plan_n = the global
+// number of terms: every rank must pass the same), exchange, combination: out_affine receives the FULL result on every rank.
+int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
+                                      const zkmi_bases_g1* bases, uint64_t plan_n, uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
+  if (!comm || comm->ctx != ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || plan_n > MSM_MAX_TERMS ||
+      (n && !d_scalars))
+    return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
+  if (plan_n < n) plan_n = n;
+  ZK_HIP(ctx, ctx->sort.reserve(plan_n));
+  ZK_HIP(ctx, ctx->g1.reserve(plan_n));
+  const MsmPlan pl = msm_make_plan(plan_n);  // one window width on every rank
+  ctx->sort.plan_override = pl.c;
+  const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+  ctx->sort.plan_override = 0;
+  if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  // the reduction (slot 0, on stream_aux) has left partials_per_msm points in the device array `partial`
+  const MsmPlan& sp = ctx->g1.slot_plan[0];
+  const int pts = MsmEngine<Fq28>::partials_per_msm(sp);
+  const uint64_t bytes = sizeof(G1XYZZ) * (uint64_t)pts;
+  if (comm->gather_cap < bytes * comm->n_ranks) {
+    if (comm->d_gather) (void)hipFree(comm->d_gather);
+    comm->d_gather = nullptr;
+    comm->gather_cap = 0;
+    ZK_HIP(ctx, hipMalloc(&comm->d_gather, bytes * comm->n_ranks));
+    comm->gather_cap = bytes * comm->n_ranks;
+  }
+  const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
+  if (rc != 0) {
+    (void)ctx->drain();
+    return rccl_fail(ctx, rc, "ncclAllGather");
+  }
+  std::vector<G1XYZZ> all((size_t)pts * comm->n_ranks);
+  ZK_HIP(ctx, hipMemcpyAsync(all.data(), comm->d_gather, bytes * comm->n_ranks, hipMemcpyDeviceToHost, ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<G1XYZZ> sum(sp.nwin, G1XYZZ::infinity()), win(sp.nwin);
+  for (uint32_t k = 0; k < comm->n_ranks; k++) {
+    MsmEngine<Fq28>::windows_from_partials(sp, all.data() + (size_t)k * pts, win.data());
+    for (int w = 0; w < sp.nwin; w++) sum[w].add(win[w]);
+  }
+  const G1XYZZ res = msm_combine_windows<Fq>(sum.data(), sp.nwin, sp.c);
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+}  // extern "C"

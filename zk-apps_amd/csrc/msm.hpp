@@ -42,6 +42,9 @@ enum Phase {
 // and shared mode packs (digit * n + point) below the sign bit, so both need 16 n < 2^32.
 constexpr uint64_t MSM_MAX_TERMS = (1ull << 28) - 1;
 
+constexpr int MSM_BIG_WINDOW = 20;  // window bits of the windowed schedule from 2^24 terms on (msm_sort.hip pick_window)
+constexpr int MSM_MAX_WINDOW = 22;  // widest window the partitioned sort supports (16 windows x 16.. partitions <= 256 groups)
+
 struct MsmPlan {
   int c = 0;        // digit bits (signed digits)
   int nwin = 0;     // windowed: number of windows;  shared: number of 2^15-bucket partitions
@@ -61,6 +64,13 @@ struct MsmPlan {
   // batched shared sort (MsmSort::run_shared_batch): nwin = vectors x vec_parts, vector v owns partitions
   // [v * vec_parts, (v + 1) * vec_parts)
   int vec_parts = 1;
+  // windowed plans with more than 2^15 buckets per window (c > 16, MsmSort::run_windowed_big): the partial TOP window only
+  // has digits below 2^15 -- every scalar would land in one of its 2^(c-1-15) partitions, in buckets 30 x the mean load.
+  // Its entries are spread over all 2^top_spread_log partitions of the window by point index instead (bucket = (point mod
+  // 2^top_spread_log) * 2^15 + |digit| - 1); the reduction weights a bucket by its index + 1 = partition * 2^15 + |digit|,
+  // and the partition's share of that weight sits in the top top_spread_log bits of the SEGMENT index, whose bit sums
+  // the host simply leaves out for this window (MsmEngine::finish_host_windows).
+  int top_spread_log = 0;
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);
@@ -95,6 +105,7 @@ struct MsmSort {
   hipError_t reserve(uint64_t n, bool shared_too = false);
   hipError_t allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared);
   hipError_t run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
+  hipError_t run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);  // c > 16, called by run()
   // shared-bucket mode: sorted[] entries are table indices (digit * n + point) | sign << 31
   hipError_t run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof);
   // `batch` scalar vectors over the same bases, one bucket set each (small domains: msm_sort.hip)
@@ -168,6 +179,8 @@ struct MsmEngine {
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
   hipError_t finish_host_windows(XYZZ<HF>* out_windows, int slot = 0);
+  static void windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows);
+  static int partials_per_msm(const MsmPlan& pl);  // XYZZ<HF> points a reduction writes per MSM (device `partial`, slot-major)
   // batched shared sort (MsmSort::run_shared_batch): one result per scalar vector
   hipError_t finish_host_batch(XYZZ<HF>* out, int slot = 0);
 };

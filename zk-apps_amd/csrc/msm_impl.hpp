@@ -617,18 +617,23 @@ __global__ void __launch_bounds__(MSM_TREE_T)
 k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
               const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
-              XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t into) {
+              XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t into, uint32_t h_first,
+              uint32_t h_limit) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   __shared__ uint32_t is_last;
-  const uint32_t n_heavy = heavy[0];
+  // list entries [h_first, min(length, h_limit)): one launch takes the whole list, or -- plans whose partial top window
+  // puts thousands of buckets above the threshold (windowed c = 20: 2^14 buckets of 4 500 points at 2^26 terms) -- the
+  // first MSM_HEAVY_CAP entries go to a (MSM_HSPLIT, 8) grid and the rest to a second launch with one workgroup per
+  // list entry (a (MSM_HSPLIT, 8) grid would walk them with 8 workgroups)
+  const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;
   const uint32_t r = blockIdx.x;
   // into: the bucket's sum is added to what an earlier MSM left in the bucket (complete addition, one thread)
   auto put = [&](uint32_t b, XYZZ<F> v) {
     if (into) v.add(load_vec(buckets + b));
     store_vec(buckets + b, v);
   };
-  for (uint32_t h = blockIdx.y; h < n_heavy; h += gridDim.y) {
+  for (uint32_t h = h_first + blockIdx.y; h < n_heavy; h += gridDim.y) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
     uint32_t nsplit = 1;
@@ -893,14 +898,15 @@ __global__ void __launch_bounds__(MSM_TREE_T, 2)
 k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
                        const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
                        const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets,
-                       XYZZ<Fq2_28>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket) {
+                       XYZZ<Fq2_28>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t h_first,
+                       uint32_t h_limit) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
   __shared__ uint32_t is_last;
   const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
-  const uint32_t n_heavy = heavy[0];
+  const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;  // list range [h_first, h_limit): see k_accum_heavy
   const uint32_t r = blockIdx.x;
-  for (uint32_t h = blockIdx.y; h < n_heavy; h += gridDim.y) {
+  for (uint32_t h = h_first + blockIdx.y; h < n_heavy; h += gridDim.y) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
     uint32_t nsplit = 1;
@@ -1154,14 +1160,24 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   auto launch_heavy = [&](int m) {
     const MsmSort& sort = *sorts[m];
     XYZZ<F>* const hp = heavy_partial + (size_t)slots[m] * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
-    if constexpr (std::is_same<F, Fq2_28>::value)
+    const bool wide_tail = !pl.shared && pl.c > 16;  // partitioned big windows: see k_accum_heavy
+    if constexpr (std::is_same<F, Fq2_28>::value) {
       hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP);
-    else
+                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, 0u, wide_tail ? MSM_HEAVY_CAP : 0xffffffffu);
+      if (wide_tail)
+        hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
+                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
+                           heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, MSM_HEAVY_CAP, 0xffffffffu);
+    } else {
       hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u);
+                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u, 0u, wide_tail ? MSM_HEAVY_CAP : 0xffffffffu);
+      if (wide_tail)
+        hipLaunchKernelGGL(k_accum_heavy<F>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
+                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
+                           heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u, MSM_HEAVY_CAP, 0xffffffffu);
+    }
   };
   for (int m = 0; m < nm; m++) {
     slot_plan[slots[m]] = sorts[m]->plan;
@@ -1286,6 +1302,11 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     nchunk = segs_per_win / per_block;
     if (nchunk > MSM_TREE_T) nchunk = MSM_TREE_T;
     if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS) nchunk = 1;
+  } else if (!pl.shared && pl.c > 16) {
+    // partitioned big windows: 2^(c-5) segments per (window, job) list on ONE workgroup are a chain of 2^(c-12) dependent
+    // additions (5 ms at c = 20); sliced, as many slices as the stage holds (16 at 13 windows x 16 jobs)
+    nchunk = MSM_TREE_T;
+    while (nchunk > 1 && ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS || nchunk * per_block > segs_per_win)) nchunk >>= 1;
   }
   for (int m = 0; m < nm; m++) {
     const MsmSort& sort = *sorts[m];
@@ -1370,15 +1391,26 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
 
 template <class F>
 hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
-  const MsmPlan& pl = slot_plan[slot];
-  const int seg_bits = msm_seg_bits(pl);
-  const int njobs = 1 + seg_bits + (pl.shared ? 1 : 0);
   hipError_t e = hipEventSynchronize(done[slot]);
   if (e != hipSuccess) return e;
-  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS;
+  windows_from_partials(slot_plan[slot], h_partial + (size_t)slot * SLOT_PTS, out_windows);
+  return hipSuccess;
+}
+
+// the per-(window, job) sums a reduction leaves behind -> one sum per window (host arithmetic).  `h` may come from this
+// device's pinned slot or from another rank's copy of the same array (comm.hip: the all-gathered partials of a point split).
+template <class F>
+int MsmEngine<F>::partials_per_msm(const MsmPlan& pl) { return pl.nwin * (1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0)); }
+template <class F>
+void MsmEngine<F>::windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows) {
+  const int seg_bits = msm_seg_bits(pl);
+  const int njobs = 1 + seg_bits + (pl.shared ? 1 : 0);
   for (int w = 0; w < pl.nwin; w++) {
     XYZZ<HF> u = XYZZ<HF>::infinity();
-    for (int j = seg_bits - 1; j >= 0; j--) {
+    // (top window of a partitioned big-window plan: the top bits of the segment index number the partition its entries
+    // were spread to, not the digit -- MsmPlan::top_spread_log)
+    const int bits = (w == pl.nwin - 1 && pl.top_spread_log > 0) ? seg_bits - pl.top_spread_log : seg_bits;
+    for (int j = bits - 1; j >= 0; j--) {
       u.dbl_inplace();
       u.add(h[(size_t)w * njobs + 1 + j]);
     }
@@ -1386,7 +1418,6 @@ hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
     u.add(h[(size_t)w * njobs]);
     out_windows[w] = u;
   }
-  return hipSuccess;
 }
 
 // shared buckets: partition q of a vector holds buckets q*nb + j (digit value q*nb + j + 1):

@@ -125,14 +125,23 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
 // Scanning every scalar's digits once per partition costs P x the digit extraction.  With
 // P > 1 the digits are extracted ONCE into (table index, local bucket) records grouped by
 // partition; the LDS-histogram passes then stream their own partition's records.
-template <bool WRITE>
+// WIN = false: shared-bucket plan, P partitions of ONE bucket set, entries are table indices (digit * n + point).
+// WIN = true: windowed plan with more than 2^15 buckets per window (c > 16: big inputs, where fewer, wider digits pay
+// for their bigger bucket sets): digit w owns its own bucket set, cut into ppw = 2^(c-1-nb_log) partitions -- partition
+// w * ppw + (bucket >> nb_log) of P = nwin * ppw -- and entries are plain point indices.  Either way every scalar is
+// read ONCE per pass for all its digits (the plain windowed sort reads it once per window and pass).
+constexpr uint32_t PART_MAX = 256;  // record groups of one sort: partitions (shared) / windows x partitions (windowed)
+template <bool WRITE, bool WIN = false>
 __global__ void __launch_bounds__(1024)
 k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P,
             uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry,
             uint32_t* __restrict__ rec_bkt) {
-  __shared__ uint32_t cnt[64];
-  if (threadIdx.x < 64) cnt[threadIdx.x] = (WRITE && threadIdx.x < P) ? blkcnt[blockIdx.x * P + threadIdx.x] : 0u;
+  __shared__ uint32_t cnt[PART_MAX];
+  if (threadIdx.x < PART_MAX) cnt[threadIdx.x] = (WRITE && threadIdx.x < P) ? blkcnt[blockIdx.x * P + threadIdx.x] : 0u;
   __syncthreads();
+  const uint32_t ppw = WIN ? ((1u << (c - 1)) >> nb_log) : 0u;
+  // the top window's digits are < 2^nb_log: its entries go to partition (point mod ppw) instead of partition 0 (MsmPlan::top_spread_log)
+  const int w_top = WIN ? ndigits - 1 : -1;
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
   for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
@@ -143,10 +152,10 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
       const uint32_t d = digit_of(k, w, c, neg);
       if (d == 0) continue;
       const uint32_t bkt = d - 1;
-      const uint32_t q = bkt >> nb_log;
+      const uint32_t q = WIN ? (uint32_t)w * ppw + (w == w_top ? (i & (ppw - 1u)) : (bkt >> nb_log)) : bkt >> nb_log;
       const uint32_t pos = atomicAdd(&cnt[q], 1u);
       if (WRITE) {
-        rec_entry[pos] = ((uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
+        rec_entry[pos] = (WIN ? i : (uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
         rec_bkt[pos] = bkt & (nb - 1u);
       }
     }
@@ -158,9 +167,9 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
 }
 
 // blkcnt[blk][q] -> first record slot of (blk, q); part_total[q] = records of partition q
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(PART_MAX)
 k_part_scan(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t P, uint32_t* __restrict__ part_total) {
-  __shared__ uint32_t tot[64];
+  __shared__ uint32_t tot[PART_MAX];
   const uint32_t q = threadIdx.x;
   uint32_t s = 0;
   if (q < P)
@@ -660,6 +669,11 @@ static int pick_window(uint64_t n) {
   if (n <= (1u << 11)) return 8;
   if (n <= (1u << 14)) return 10;
   if (n <= (1u << 17)) return 13;
+  // From 2^24 terms on a wider digit pays for its bigger bucket sets: c = 20 is 13 windows (12 full ones and a 15-bit top
+  // window) instead of 16, i.e. 13 n instead of 16 n insertions, against 13 x 2^19 instead of 16 x 2^15 buckets to
+  // reduce (~3.5 insertion-equivalents each): -10 % at 2^24, -17 % at 2^26.  c = 21 / 22 cost the same within 1 % with
+  // two / four times the bucket memory.  A window of 2^19 buckets is sorted as 16 partitions of 2^15 (run_windowed_big).
+  if (n >= (1ull << 24)) return MSM_BIG_WINDOW;
   return 16;  // 2^15 buckets = 128 KiB of LDS counters per (window, chunk) tile
 }
 
@@ -699,12 +713,14 @@ MsmPlan msm_make_plan_c(uint64_t n, int c) {
   p.nb = 1u << (p.c - 1);
   p.n = n;
   plan_set_heavy(p, n * (uint64_t)p.nwin);
+  // (for every c in 17..22 the top window covers at most 15 bits: 0, 3, 8, 15, 3, 13)
+  if (c > 16) p.top_spread_log = c - 1 - 15;
   return p;
 }
 MsmPlan msm_make_plan(uint64_t n) {
-  // ZKMI_WINDOW_BITS (A/B library): tuning override (5..16)
+  // ZKMI_WINDOW_BITS (A/B library): tuning override (5..16, and 17..22 = the partitioned windows of run_windowed_big)
   const int v = ZK_TUNE("ZKMI_WINDOW_BITS", 0);
-  const int forced = (v >= 5 && v <= 16) ? v : 0;
+  const int forced = (v >= 5 && v <= MSM_MAX_WINDOW) ? v : 0;
   return msm_make_plan_c(n, forced ? forced : pick_window(n));
 }
 
@@ -758,6 +774,10 @@ MsmPlan msm_make_plan_shared_batch(uint64_t n, uint32_t batch) {
   return p;
 }
 
+// windowed plans with more than 2^15 buckets per window: partitions per window and in total (run_windowed_big)
+static inline uint32_t big_parts_per_window(const MsmPlan& p) { return p.nb >> 15; }
+static inline bool plan_is_big(const MsmPlan& p) { return !p.shared && p.c > 16; }
+
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
 uint64_t msm_max_buckets(uint64_t n) {
@@ -801,12 +821,13 @@ static uint32_t pick_chunks(const MsmPlan& p) {
   return nch ? (uint32_t)nch : 1;
 }
 
+static uint32_t shared_chunks(uint32_t P, uint64_t n);
 static uint64_t msm_max_hist(uint64_t n) {
   uint64_t best = 0;
   for (uint64_t step : PLAN_STEPS) {
     uint64_t m = step < n ? step : n;
     MsmPlan p = msm_make_plan(m);
-    uint64_t v = (uint64_t)p.nwin * p.nb * pick_chunks(p);
+    uint64_t v = (uint64_t)p.nwin * p.nb * (plan_is_big(p) ? shared_chunks((uint32_t)p.nwin * big_parts_per_window(p), m) : pick_chunks(p));
     if (v > best) best = v;
     if (step >= n) break;
   }
@@ -852,7 +873,8 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   const uint64_t forced = (uint64_t)(255 / 16 + 1) * (1u << 15);
   if (nbk < forced) nbk = forced;  // allow plan_override = 16 for any n
   if (16 * n > ne) ne = 16 * n;
-  shared_too = shared_too || has_shared;
+  // (the record buffers serve the shared-bucket sorts and the partitioned windows of big windowed plans alike)
+  shared_too = shared_too || has_shared || plan_is_big(msm_make_plan(n));
   if (shared_too) {
     // shared-bucket plan for the same n (only the prover uses it)
     const MsmPlan sp = msm_make_plan_shared(n);
@@ -883,7 +905,7 @@ hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared
   if ((e = hipMalloc(&count, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&begin, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
   if ((e = hipMalloc(&perm, sizeof(uint32_t) * nbk)) != hipSuccess) return e;
-  if ((e = hipMalloc(&part_total, sizeof(uint32_t) * 64)) != hipSuccess) return e;
+  if ((e = hipMalloc(&part_total, sizeof(uint32_t) * PART_MAX)) != hipSuccess) return e;
   if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2) * (256 + 1))) != hipSuccess) return e;  // row 0: offsets, rows 1..: per-block key counts
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * FPART_BLOCKS * FINE_MAX_PARTS)) != hipSuccess) return e;  // also 256 x 64 of the coarse form
   if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 2 * FINE_MAX_PARTS)) != hipSuccess) return e;
@@ -942,6 +964,7 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
     if (er != hipSuccess) return er;
   }
   plan = plan_override ? msm_make_plan_c(n, plan_override) : msm_make_plan(n);
+  if (plan_is_big(plan)) return run_windowed_big(d_scalars, n, st, prof);
   const uint32_t nb = plan.nb, nwin = (uint32_t)plan.nwin;
   const uint32_t tot_b = nwin * nb;
   const uint32_t nch = pick_chunks(plan);
@@ -977,6 +1000,58 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
                      blockhist, sorted);
+  if (prof) prof->end(PH_MSM_SORT, st);
+  return hipGetLastError();
+}
+
+// Windowed plan with c > 16 (`plan` is set by run()): window w owns 2^(c-1) buckets = ppw partitions of 2^15, the
+// LDS-histogram tiles work on (chunk, window x partition).  The digits of ALL windows are extracted in one record
+// pre-pass (two reads of the scalars in total, where the plain windowed sort reads them twice per window), the records
+// of a (window, partition) group are then counted and scattered like the partitions of the shared-bucket record sort.
+// sorted[] is packed group by group; bucket ids are window-major (w * 2^(c-1) + |digit| - 1), which is what the
+// reductions of the windowed schedule expect.
+hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
+  const uint32_t nb = 1u << 15, nwin = (uint32_t)plan.nwin;
+  const int nb_log = 15;
+  const uint32_t P = nwin * big_parts_per_window(plan);
+  const uint32_t tot_b = nwin * plan.nb;
+  const uint32_t nch = shared_chunks(P, n);
+  if (P > PART_MAX || (uint64_t)nwin * n > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist || !rec_entry)
+    return hipErrorInvalidValue;
+  RecodeConst rc;
+  for (int j = 0; j < 9; j++) rc.m[j] = 0;
+  for (uint32_t w = 0; w < nwin; w++) {
+    const uint64_t v = (1ull << (plan.c - 1)) - 1;
+    const int bit = (int)w * plan.c, limb = bit >> 5, sh = bit & 31;
+    if (limb < 9) {
+      uint64_t carry = v << sh;  // c <= 22, sh <= 31: fits 64 bits
+      for (int j = limb; j < 9 && carry; j++) {
+        const uint64_t sum = (uint64_t)rc.m[j] + (uint32_t)carry;
+        rc.m[j] = (uint32_t)sum;
+        carry = (carry >> 32) + (sum >> 32);
+      }
+    }
+  }
+  if (prof) prof->begin(PH_MSM_SORT, st);
+  uint32_t nblk = (uint32_t)((n + 4095) / 4096);
+  if (nblk > 256) nblk = 256;
+  if (!nblk) nblk = 1;
+  const uint32_t chunk = (uint32_t)((n + nblk - 1) / nblk);
+  hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
+                     chunk, rc, blkcnt, rec_entry, rec_bkt);
+  hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
+  hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
+                     chunk, rc, blkcnt, rec_entry, rec_bkt);
+  const size_t lds = sizeof(uint32_t) * nb;
+  const dim3 grid(nch, P);
+  hipLaunchKernelGGL(k_bucket_pass_rec<false>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist, sorted);
+  hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
+  hipLaunchKernelGGL(k_window_scan, dim3(P), dim3(1024), 0, st, count, begin, nb, (uint32_t)n, (const uint32_t*)part_total);
+  const uint64_t tot_h = (uint64_t)tot_b * nch;
+  hipLaunchKernelGGL(k_bucket_bases, dim3((unsigned)((tot_h + 255) / 256)), dim3(256), 0, st, blockhist, begin, nb, nch, (uint32_t)tot_h);
+  hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
+  if (e0 != hipSuccess) return e0;
+  hipLaunchKernelGGL(k_bucket_pass_rec<true>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist, sorted);
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
@@ -1056,7 +1131,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     chunk_a = (uint32_t)((n + nblk_a - 1) / nblk_a);
     hipLaunchKernelGGL(k_part_pass<false>, dim3(nblk_a), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
                        nb, nb_log, P, chunk_a, rc, blkcnt, rec_entry, rec_bkt);
-    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(64), 0, st, blkcnt, nblk_a, P, part_total);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk_a, P, part_total);
     hipLaunchKernelGGL(k_part_pass<true>, dim3(nblk_a), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits,
                        nb, nb_log, P, chunk_a, rc, blkcnt, rec_entry, rec_bkt);
     hipLaunchKernelGGL(k_bucket_pass_rec<false>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist,

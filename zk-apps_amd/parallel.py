@@ -37,6 +37,17 @@ def msm_g1_combine_ranks(zk, windows_local: bytes, nwin: int, window_bits: int, 
 
 
 def msm_g1_split_dev(zk, ctx, d_scalars_ptr, n_local, bases_local, n_global, group=None):
-    """Rank-local slice of a point-split MSM on the GPU + the exchange step."""
+    """Rank-local slice of a point-split MSM on the GPU + the exchange step (host bytes through torch.distributed:
+    what the gloo CPU test exercises; on GPUs prefer rccl_comm + ctx.msm_g1_allgather_combine below)."""
     windows, nwin, cbits = ctx.msm_g1_windows_dev(d_scalars_ptr, n_local, bases_local, n_global)
     return msm_g1_combine_ranks(zk, windows, nwin, cbits, group=group)
+
+
+def rccl_comm(zk, ctx, group=None):
+    """A zkmi_comm (RCCL communicator behind the C ABI, include/zkmi.h) spanning the ranks of `group`: rank 0 draws the
+    unique id, torch.distributed only carries its 128 bytes; the MSM exchange itself never touches Python --
+    ctx.msm_g1_allgather_combine(comm, ...) gathers the device-resident partial sums with ncclAllGather and combines."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [zk.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return ctx.comm_init(world, rank, box[0])
