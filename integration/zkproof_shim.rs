@@ -46,12 +46,37 @@ fn op(o: &OpPub) -> zkmi_op_pub {
     };
     zkmi_op_pub { kind, amount: amount.to_le_bytes(), token: sc(&token), user: sc(&user) }
 }
-/// prover randomness r || s: two field elements below r (top two bits cleared)
+/// the scalar-field modulus r of BLS12-381, little-endian
+const FR_MODULUS_LE: [u8; 32] = [
+    0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+    0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73,
+];
+/// one element UNIFORM on [0, r): rejection sampling of 255-bit strings (acceptance 0.45), as Fr::rand does --
+/// Groth16's zero-knowledge argument needs the blinding scalars uniform on the whole field, and clearing the top two
+/// bits would only ever reach the lower 55 % of it
+fn fresh_fr() -> [u8; 32] {
+    loop {
+        let mut v = [0u8; 32];
+        getrandom::getrandom(&mut v).expect("os randomness");
+        v[31] &= 0x7f;
+        // v < r, compared from the most significant byte down
+        let mut below = false;
+        for i in (0..32).rev() {
+            if v[i] != FR_MODULUS_LE[i] {
+                below = v[i] < FR_MODULUS_LE[i];
+                break;
+            }
+        }
+        if below {
+            return v;
+        }
+    }
+}
+/// prover randomness r || s: two independent uniform field elements
 fn fresh_rs() -> [u8; 64] {
     let mut rs = [0u8; 64];
-    getrandom::getrandom(&mut rs).expect("os randomness");
-    rs[31] &= 0x3f;
-    rs[63] &= 0x3f;
+    rs[..32].copy_from_slice(&fresh_fr());
+    rs[32..].copy_from_slice(&fresh_fr());
     rs
 }
 

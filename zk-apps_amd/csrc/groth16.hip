@@ -1051,6 +1051,8 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
     // whatever was queued before the failure still reads the caller's witness and the key: wait for it
     const std::string msg = ctx->err;
     (void)ctx->drain();
+    (void)ctx->g1.reset_transients();  // an MSM abandoned between its accumulation and its redo pass leaves a list behind
+    (void)ctx->g2.reset_transients();
     ctx->err = msg;
   }
   return rc;
@@ -1156,6 +1158,8 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   auto bail = [&](int32_t code) {
     const std::string msg = ctx->err;
     (void)ctx->drain();
+    (void)ctx->g1.reset_transients();
+    (void)ctx->g2.reset_transients();
     ctx->err = msg;
     return code;
   };

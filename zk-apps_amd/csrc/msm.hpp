@@ -154,6 +154,10 @@ struct MsmEngine {
     destroy_events();
   }
   void release();         // frees the buffers (a re-allocation may follow); events stay valid
+  // The redo lists and the heavy-bucket tickets are zeroed once at allocation and every complete MSM leaves zeros behind
+  // (k_accum_redo / k_accum_heavy clear them).  An MSM that was abandoned half-way -- a prover error path, after
+  // ctx->drain() -- may not have: re-zero them so that the slot's next MSM does not append to a stale list.
+  hipError_t reset_transients();
   void destroy_events();
   bool has_shared = false;
   hipError_t reserve(uint64_t n, bool shared_too = false);

@@ -1007,6 +1007,14 @@ void MsmEngine<F>::release() {
 uint64_t msm_max_buckets(uint64_t n);
 
 template <class F>
+hipError_t MsmEngine<F>::reset_transients() {
+  if (!redo || !heavy_ticket) return hipSuccess;
+  hipError_t e = hipMemset(redo, 0, sizeof(uint32_t) * (cap_buckets + 2) * nslots);
+  if (e != hipSuccess) return e;
+  return hipMemset(heavy_ticket, 0, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots);
+}
+
+template <class F>
 void MsmEngine<F>::destroy_events() {
   for (int i = 0; i < SLOTS; i++) {
     hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
