@@ -1,13 +1,15 @@
 #!/bin/bash
 # Regenerates every file under profiles/<round>/ in one command, on the GPU box, from the repo root:
 #
-#     bash scripts/profile.sh r03            # -> gpurun_out/prof_r03/{trace,pmc_*}/..., summaries in profiles/r03/
+#     bash scripts/profile.sh r04            # -> gpurun_out/prof_r04/{trace,pmc_*}/..., summaries in profiles/r04/
+# Run it LAST in a round, after the final commit that touches zk-apps_amd/csrc: the PMC summary is stamped with the digest
+# of those sources and bench.py compares it with the sources it runs (roofline.traffic_source.same_sources_as_this_run).
 #
 # rocprofv3 is always given the program itself after `--` (python3 bench.py ...), tracing and counter
 # collection are separate runs, and the counters are split over passes that fit the hardware slots
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: /opt/skills/guides/MI355X_MICROARCH.md, PMC slots).
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 OUT=gpurun_out/prof_$ROUND
 DST=profiles/$ROUND
 STEPS_TRACE=${STEPS_TRACE:-8}
@@ -42,6 +44,11 @@ python3 scripts/pmc_summary.py "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" $
 grep -h '^{' "$OUT/trace.log" | tail -1 > "$DST/bench_line_under_trace.json"
 # the complete line again, now with traffic / instruction counts from the fresh PMC summary
 python3 bench.py --pmc-summary "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" > "$DST/bench_line_full.json" 2> "$OUT/bench_full.err"
+# 4. BASELINE configs[3] behind the bench contract, and the torch-free twin of the headline run under the native HIP runtime
+python3 bench.py --workload msm26 > "$DST/bench_line_msm26_n1.json" 2> "$OUT/bench_msm26.err"
+gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/bench_prove.c -Lzk-apps_amd -lzkmi -L/opt/rocm/lib -lamdhip64 \
+  -Wl,-rpath,$PWD/zk-apps_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/bench_prove && \
+  ZKMI_BACKTRACE=1 timeout 900 /tmp/bench_prove --log-n 20 --proofs 20 --warmup 2 --churn ${CHURN_OPS:-2000} > "$DST/c_bench_native_runtime.log" 2>&1
 # gpurun only brings gpurun_out/ back: leave a copy of the summaries there
 mkdir -p "gpurun_out/profiles_$ROUND" && cp -r "$DST/." "gpurun_out/profiles_$ROUND/"
 ls -la "$DST"
