@@ -733,7 +733,10 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
 // main stream always has a full accumulation to run instead of waiting for it.
 // solo = nothing else of this context is in flight or will be queued before the second half (zkmi_groth16_prove[_dev]): the
 // second half's sort of h may then be queued by the first half
-static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par, bool solo = false) {
+// followed = the first half of ANOTHER group will be queued between this group's two halves (every group of a batch but
+// the last): only then do L and H share a bucket set (see below)
+static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par, bool solo = false,
+                               bool followed = false) {
   const uint32_t nv = pk->n_vars;
   hipStream_t st = ctx->stream;
   // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the MSMs over z
@@ -825,7 +828,12 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // separate bucket sets (and so do the retired accumulation kernels, which have no accumulate-into form).
   const bool lh_merge_on = ZK_TUNE("ZKMI_LH_MERGE", 1) != 0 && (ZK_TUNE("ZKMI_ACCUM", 3) == 2 || ZK_TUNE("ZKMI_ACCUM", 3) == 3);
   const uint32_t N = 1u << pk->log_n;
-  const bool lh_merge = lh_merge_on && sh &&
+  // Only where another group's first half separates the two halves: the H accumulation must wait for L's heavy-bucket
+  // and redo kernels, which sit on the reduction stream and are not placed while accumulation waves fill the SIMDs
+  // (section 4.10).  Inside a batch they have long run by the time H is due; with H directly behind L -- one proof, the last
+  // group of a batch -- the main stream would stall until the chip has drained: one 2^20 proof 18.9 -> 20.4 ms
+  // (profiles/r04/experiments/lh_merge_single_proof_latency_ab.txt).
+  const bool lh_merge = lh_merge_on && sh && followed &&
                         same_bucket_set(sz.plan, G > 1 ? msm_make_plan_shared_batch(N, G) : msm_make_plan_shared(N));
   ctx->h_mode[par] = lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
@@ -1172,7 +1180,7 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
     return prove_finish(ctx, pk, r_bytes + 32ull * first(g), s_bytes + 32ull * first(g), count(g), (int)(g % RING),
                         out_proofs + 192ull * first(g));
   };
-  auto enqueue_z = [&](uint32_t g) { return prove_enqueue_z(ctx, pk, d_z + first(g), host, count(g), (int)(g % RING)); };
+  auto enqueue_z = [&](uint32_t g) { return prove_enqueue_z(ctx, pk, d_z + first(g), host, count(g), (int)(g % RING), false, g + 1 < n_groups); };
   int32_t rc = enqueue_z(0);
   if (rc != ZKMI_OK) return bail(rc);
   for (uint32_t g = 0; g < n_groups; g++) {
