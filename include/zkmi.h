@@ -164,6 +164,11 @@ int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatch
 /* Host-executed self-test of the scalar multiplications of proof assembly (fixed-base tables for delta, joint
  * two-scalar multiplication) against plain double-and-add in G1 and G2; *out_mismatches must be 0. */
 int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
+/* Test hook for the bucket set two MSMs share (the prover's L and H queries): sum_i a_i P_i + sum_i b_i P_i
+ * with the first MSM's accumulation left unreduced and the second one's kernels adding INTO its bucket array, one
+ * reduction for both (prepared bases run the shared-bucket schedule, others the windowed one).  Scalars in HBM. */
+int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, const void* d_scalars_b, uint64_t n,
+                                      const zkmi_bases_g1* bases, uint8_t out_affine[96]);
 
 /* ---- group / encoding helpers (host) -------------------------------------- */
 int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]);

@@ -781,6 +781,61 @@ def test_msm_degenerate_bases_and_scalars(ctx, group):
         b.free()
 
 
+def test_msm_two_queries_through_one_bucket_set(ctx, zk):
+    """The mechanism behind the prover's L + H merge, exercised on inputs a proving key never produces:
+    MSM(a) left unreduced in its bucket array, MSM(b) accumulated INTO it, one reduction -- against the C++ oracle's MSM over
+    the concatenation.  a is sparse (90 % zero scalars: most buckets are EMPTY when b's kernel arrives and take the redo
+    pass from infinity) with a heavy bucket (5 % ones); b repeats a's non-zero scalars on the same points (P + P across the
+    two MSMs: the doubling exit of the accumulate-into kernel), holds a 20 %-heavy bucket of its own (the cooperative kernel
+    adds into the bucket) and opposite points (P - P: cancellation).  Windowed plan, and prepared bases (shared-bucket plan)."""
+    import torch
+
+    from oracle import cpp as ocpp
+
+    n = 1 << 14
+    g = torch.Generator().manual_seed(99)
+    base = ctx.bases_g1_synthetic(n)
+    pts = bytearray(base.read(0, n))
+    base.free()
+    # points 1000..1999 repeat points 0..999; points 2000..2499 are the NEGATIVES of points 0..499 (y -> p - y)
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    for i in range(1000):
+        pts[96 * (1000 + i) : 96 * (1001 + i)] = pts[96 * i : 96 * (i + 1)]
+    for i in range(500):
+        y = int.from_bytes(pts[96 * i + 48 : 96 * i + 96], "little")
+        pts[96 * (2000 + i) : 96 * (2000 + i) + 48] = pts[96 * i : 96 * i + 48]
+        pts[96 * (2000 + i) + 48 : 96 * (2001 + i)] = (P - y).to_bytes(48, "little")
+    pts = bytes(pts)
+    uni = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    uni[:, 31] &= 0x3F
+    a = uni.clone()
+    kind = torch.rand(n, generator=g)
+    a[kind < 0.90] = 0
+    one = (kind >= 0.90) & (kind < 0.95)
+    a[one] = 0
+    a[one, 0] = 1
+    b = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    b[:, 31] &= 0x3F
+    b[:1000] = a[:1000]            # same scalar on the same point in both MSMs
+    b[1000:2000] = a[:1000]        # ... and on its repeated copy
+    a[2000:2500] = b[:500]         # a adds s P, b adds s P: with the negated copies below everything cancels pairwise
+    b[2000:2500] = b[:500]
+    heavy = torch.rand(n, generator=g) < 0.20
+    heavy[:2500] = False
+    b[heavy] = 0
+    b[heavy, 0] = 7
+    want = ocpp.msm_g1(a.numpy().tobytes() + b.numpy().tobytes(), pts + pts)
+    da, db = a.contiguous().cuda(), b.contiguous().cuda()
+    torch.cuda.synchronize()
+    for prepared in (False, True):
+        bs = ctx.bases_g1(pts, check=False)
+        if prepared:
+            bs.prepare()
+        assert ctx.selftest_msm_g1_sum2_dev(da.data_ptr(), db.data_ptr(), n, bs) == want, prepared
+        assert ctx.selftest_msm_g1_sum2_dev(db.data_ptr(), da.data_ptr(), n, bs) == want, prepared  # roles swapped
+        bs.free()
+
+
 # ---- BN254 MSM / NTT / KZG commit (SURVEY.md §8f-3) ---------------------------------------------
 
 

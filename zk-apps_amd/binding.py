@@ -751,6 +751,12 @@ class Context:
         self._chk(self.lib.zkmi_msm_g1_allgather_combine(self.h, comm.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, C.c_uint64(plan_n), out))
         return bytes(out)
 
+    def selftest_msm_g1_sum2_dev(self, dptr_a, dptr_b, n, bases):
+        """MSM(a) + MSM(b) over the same bases through ONE shared bucket set (test hook of the L + H merge)."""
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_selftest_msm_g1_sum2_dev(self.h, C.c_void_p(dptr_a), C.c_void_p(dptr_b), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
         out = (C.c_uint8 * (96 * 64))()
         nwin, cbits = C.c_uint32(), C.c_uint32()

@@ -443,6 +443,35 @@ int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkm
   return zkmi_msm_g2_dev(ctx, ctx->d_tmp, n, bases, out_affine);
 }
 
+int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, const void* d_scalars_b, uint64_t n,
+                                      const zkmi_bases_g1* bases, uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
+  if (!ctx || !bases || !out_affine || !d_scalars_a || !d_scalars_b || n == 0 || n > bases->n || n > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
+  const bool shared = bases->tab != nullptr && n == bases->n;
+  ZK_HIP(ctx, ctx->sort.reserve(n, shared));
+  ZK_HIP(ctx, ctx->sort_h.reserve(n, shared));
+  ZK_HIP(ctx, ctx->g1.reserve(n, shared));
+  const uint32_t* a = static_cast<const uint32_t*>(d_scalars_a);
+  const uint32_t* b = static_cast<const uint32_t*>(d_scalars_b);
+  if (shared) {
+    ZK_HIP(ctx, ctx->sort.run_shared(a, n, ctx->stream, ctx->timer()));
+    ZK_HIP(ctx, ctx->sort_h.run_shared(b, n, ctx->stream, ctx->timer()));
+  } else {
+    ZK_HIP(ctx, ctx->sort.run(a, n, ctx->stream, ctx->timer()));
+    ZK_HIP(ctx, ctx->sort_h.run(b, n, ctx->stream, ctx->timer()));
+  }
+  const Affine<Fq28>* pts = shared ? bases->tab : bases->d28;
+  // first MSM: slot 0, no reduction; second: slot 1, adds into slot 0's buckets and reduces both (same reduction stream)
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pts, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 0, nullptr,
+                                 -1, MSM_RUN_NO_REDUCE));
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, pts, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 1, nullptr, 0));
+  G1XYZZ res;
+  ZK_HIP(ctx, ctx->g1.finish_host(&res, 1));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
 int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
                                 uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin,
                                 uint32_t* out_window_bits) {
