@@ -627,22 +627,34 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
   // first MSM_HEAVY_CAP entries go to a (MSM_HSPLIT, 8) grid and the rest to a second launch with one workgroup per
   // list entry (a (MSM_HSPLIT, 8) grid would walk them with 8 workgroups)
   const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;
-  const uint32_t r = blockIdx.x;
   // into: the bucket's sum is added to what an earlier MSM left in the bucket (complete addition, one thread)
   auto put = [&](uint32_t b, XYZZ<F> v) {
     if (into) v.add(load_vec(buckets + b));
     store_vec(buckets + b, v);
   };
-  for (uint32_t h = h_first + blockIdx.y; h < n_heavy; h += gridDim.y) {
+  // Work items = (bucket, sub-range) pairs, numbered through the list and dealt round-robin to ALL workgroups of the grid.
+  // (Rounds 1-3 gave grid row y the buckets y, y + 8, ... and column x the sub-range x: the 64 buckets of a group of small
+  // proofs -- one per proof, ~600 points = 2 sub-ranges each -- were walked 8 at a time by 2 of the 64 columns: 5.8 ms per
+  // launch at 2^14, a quarter of the group's kernel time; dealt flat the same list is one round of 128 workgroups.)
+  const uint32_t n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+  uint32_t item0 = 0;  // number of the bucket's first work item
+  // (a launch for the entries beyond the split capacity -- one item per bucket -- strides the list directly)
+  const bool tail = h_first >= MSM_HEAVY_CAP;
+  for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
     uint32_t nsplit = 1;
     if (h < MSM_HEAVY_CAP) {
       // as many sub-ranges as the bucket can feed: ~4 points per thread before the tree (a bucket of 400 points on
-      // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group)
+      // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group).
+      // (8 points per thread -- one workgroup, no partials and no second tree for the 600 bit variables of a small
+      // proof -- measured no better: 2^14 2 501 against 2 554-2 573 proofs/s.)
       nsplit = (count[b] + 4 * MSM_TREE_T - 1) / (4 * MSM_TREE_T);
       nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
     }
+    // this workgroup's sub-range of the bucket, if any: item0 + r = wg (mod n_wg); nsplit <= MSM_HSPLIT <= n_wg, so at most one
+    const uint32_t r = tail ? 0u : (wg + n_wg - item0 % n_wg) % n_wg;
+    item0 += nsplit;
     if (r >= nsplit) continue;  // block-uniform
     if (nsplit > 1) {
       const uint32_t len = (count[b] + nsplit - 1) / nsplit;
@@ -905,8 +917,10 @@ k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t*
   __shared__ uint32_t is_last;
   const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
   const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;  // list range [h_first, h_limit): see k_accum_heavy
-  const uint32_t r = blockIdx.x;
-  for (uint32_t h = h_first + blockIdx.y; h < n_heavy; h += gridDim.y) {
+  const uint32_t n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;  // flat deal of (bucket, sub-range) items
+  uint32_t item0 = 0;
+  const bool tail = h_first >= MSM_HEAVY_CAP;
+  for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
     const uint32_t b = heavy[1 + h];
     uint32_t beg = begin[b], end = beg + count[b];
     uint32_t nsplit = 1;
@@ -914,6 +928,8 @@ k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t*
       nsplit = (count[b] + 4 * npair - 1) / (4 * npair);
       nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
     }
+    const uint32_t r = tail ? 0u : (wg + n_wg - item0 % n_wg) % n_wg;
+    item0 += nsplit;
     if (r >= nsplit) continue;  // block-uniform
     if (nsplit > 1) {
       const uint32_t len = (count[b] + nsplit - 1) / nsplit;
