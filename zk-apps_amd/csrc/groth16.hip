@@ -148,6 +148,19 @@ k_quotient(Fr28* __restrict__ a, const Fr28* __restrict__ b, const Fr28* __restr
   st28(a + i, (ld28(a + i) * ld28(b + i) - ld28(c + i)) * zinv);
 }
 
+// the device-resident assignments of a group, gathered back to back: ONE launch of one-wave workgroups instead of one
+// blit kernel per proof (1 300 __amd_rocclr_copyBuffer launches of 512 threads took 9.6 % of a 2^14 run's kernel time:
+// each waited for SIMDs that accumulation waves kept full, section 4.10)
+struct ZPtrSet {
+  const uint4* p[64];
+};
+__global__ void __launch_bounds__(64)
+k_gather_z(ZPtrSet src, uint4* __restrict__ dst, uint32_t vec16) {  // vec16 = 16-byte words per assignment
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= vec16) return;
+  dst[(size_t)blockIdx.y * vec16 + i] = src.p[blockIdx.y][i];
+}
+
 // out[p] = in[rev(p)]: bases of the H MSM follow the bit-reversed coefficient order
 template <class A>
 __global__ void __launch_bounds__(256)
@@ -230,6 +243,9 @@ struct zkmi_pk {
   // per proof in flight (ring of zkmi_ctx::PROOF_RING): witness in canonical words (digit source of the
   // A/B/L MSMs) and h coefficients in canonical words, bit-reversed order (digit source of the H MSM)
   Fr* d_z[zkmi_ctx::PROOF_RING] = {};
+  // where the assignment(s) of the proof (group) in flight in ring slot `par` actually lie: d_z[par], or -- one
+  // device-resident assignment -- the caller's own buffer (no copy at all; it stays valid for the duration of the call)
+  mutable const Fr* z_cur[zkmi_ctx::PROOF_RING] = {};
   uint32_t* d_h[zkmi_ctx::PROOF_RING] = {};
   Fr28 *d_zm = nullptr, *d_a = nullptr;  // limb form (field28.hpp), front stream only; d_a holds a, b, c of a group back to back
   uint32_t* d_unsat = nullptr;  // per proof in flight: set by k_check_sat
@@ -647,17 +663,28 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // The copy runs on the copy stream: with a pinned host witness the upload of proof i+1 (32 B per variable
   // over PCIe) proceeds while the compute streams still work on proofs i-1 and i; the ring of witness
   // buffers makes that safe.  Canonicity (< r) is checked on the device, not in a host loop.
-  for (uint32_t b = 0; b < G; b++)
-    ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par] + (size_t)b * nv, src[b], 32ull * nv,
-                               host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream_copy));
+  pk->z_cur[par] = pk->d_z[par];
+  if (host) {
+    for (uint32_t b = 0; b < G; b++)
+      ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par] + (size_t)b * nv, src[b], 32ull * nv, hipMemcpyHostToDevice, ctx->stream_copy));
+  } else if (G == 1 && (reinterpret_cast<uintptr_t>(src[0]) & 15u) == 0) {
+    pk->z_cur[par] = static_cast<const Fr*>(src[0]);  // read in place: the caller's buffer outlives the call
+  } else if (G <= 64 && [&] { for (uint32_t b = 0; b < G; b++) if (reinterpret_cast<uintptr_t>(src[b]) & 15u) return false; return true; }()) {
+    ZPtrSet ps;
+    for (uint32_t b = 0; b < 64; b++) ps.p[b] = static_cast<const uint4*>(src[b < G ? b : 0]);
+    hipLaunchKernelGGL(k_gather_z, dim3((2 * nv + 63) / 64, G), dim3(64), 0, ctx->stream_copy, ps, reinterpret_cast<uint4*>(pk->d_z[par]), 2 * nv);
+  } else {
+    for (uint32_t b = 0; b < G; b++)
+      ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par] + (size_t)b * nv, src[b], 32ull * nv, hipMemcpyDeviceToDevice, ctx->stream_copy));
+  }
   ZK_HIP(ctx, hipEventRecord(ctx->ev_z[par], ctx->stream_copy));
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_z[par], 0));
   if (st != ctx->stream) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z[par], 0));
   if (t) t->begin(PH_WITNESS, st);
   ZK_HIP(ctx, hipMemsetAsync(pk->d_unsat + par, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 63) / 64), dim3(64), 0, st,
-                     reinterpret_cast<const uint32_t*>(pk->d_z[par]), G * nv, pk->d_unsat + par);
-  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->d_z[par]), pk->d_zm, G * nv, st));
+                     reinterpret_cast<const uint32_t*>(pk->z_cur[par]), G * nv, pk->d_unsat + par);
+  ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->z_cur[par]), pk->d_zm, G * nv, st));
   MatSet ms;
   for (int m = 0; m < 3; m++) {
     ms.rowptr[m] = pk->d_rowptr[m];
@@ -752,7 +779,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // MSMs over the assignment z[1..): one digit sort, four bucket passes.  Every
   // MSM's reduction runs on the aux stream behind its accumulation and leaves the
   // per-window partials in a pinned host slot + an event.
-  const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->d_z[par] + 1);
+  const uint32_t* zs = reinterpret_cast<const uint32_t*>(pk->z_cur[par] + 1);
   const bool sh = pk->shared;
   // ZKMI_SORT_SIDE=1: the digit sort runs on its own (high-priority) stream into one of two buffer sets, so the sort
   // of proof i+1 overlaps the accumulations of proof i instead of standing between two accumulations on the main
