@@ -409,7 +409,29 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         v = t.cpu().tolist()
         tot += sum(x << (8 * k) for k, x in enumerate(v[0]))
         wtot += sum(x << (8 * k) for k, x in enumerate(v[1]))
-    bases = ctx.bases_g1_synthetic_range(a, m)
+    if args.split == "windows":
+        # every rank over ALL points: rebuild the other ranks' scalars (same generators) and keep the whole base sequence
+        parts = []
+        for k in range(world):
+            ak, bk = par.shard_units(n, k, world)
+            if k == rank:
+                parts.append(raw)
+            else:
+                gk = torch.Generator(device="cuda").manual_seed(0x5A4B0003 + k)
+                t = torch.randint(0, 256, (bk - ak, 32), dtype=torch.uint8, device="cuda", generator=gk)
+                t[:, 31] &= 0x3F
+                parts.append(t)
+        raw = torch.cat(parts).contiguous() if world > 1 else raw
+        del parts
+        m = n
+        bases = ctx.bases_g1_synthetic(n)
+    else:
+        bases = ctx.bases_g1_synthetic_range(a, m)
+
+    def one():
+        if args.split == "windows":
+            return ctx.msm_g1_window_split_allgather(comm, raw.data_ptr(), n, bases)
+        return ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
 
     # the exchange behind the C ABI: zkmi_comm (RCCL; torch.distributed only carries rank 0's 128-byte id), partial sums
     # all-gathered from HBM on the reduction stream, combined on every rank -- also at one rank (a world of 1)
@@ -422,7 +444,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
             comm = par.rccl_comm(z, ctx)
         else:
             comm = ctx.comm_init(1, 0, z.comm_unique_id())
-        one_ = ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)  # first collective (workspaces, RCCL channels)
+        one_ = one()  # first collective (workspaces, RCCL channels)
         del one_
     finally:
         import ctypes
@@ -430,9 +452,6 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         ctypes.CDLL(None).fflush(None)  # the banner sits in the C library's stdout buffer: flush it while fd 1 is still stderr
         os.dup2(saved, 1)
         os.close(saved)
-
-    def one():
-        return ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
 
     for _ in range(max(1, args.warmup)):  # the first call allocates the workspaces
         one()
@@ -467,8 +486,8 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         "vs_baseline": None,
         "dtype": "int: signed 28-bit limbs in 32-bit words, 64-bit column accumulators (Fq 381-bit Montgomery)",
         "data": "synthetic",
-        "config": {"workload": "single G1 MSM of 2^%d points (BASELINE configs[3]), split by points over %d GPU(s), RCCL all-gather of "
-                               "per-window partial sums + local combine" % (args.msm_log_n, world),
+        "config": {"workload": "single G1 MSM of 2^%d points (BASELINE configs[3]), split by %s over %d GPU(s), RCCL all-gather of "
+                               "per-window partial sums + local combine" % (args.msm_log_n, args.split, world),
                    "points_per_rank": m, "curve": "BLS12-381", "scalars": "uniform < 2^254", "bases": "P_i = G + i*[0xC0FFEE]G"},
         "matches_closed_form_on_every_rank": ok,
         "points_per_s": n / sec,
@@ -494,6 +513,9 @@ def main():
                     help="proofs = BASELINE configs[1]/[2] (headline); msm26 = configs[3], one 2^26-point G1 MSM split over the ranks")
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--msm-log-n", type=int, default=26)
+    ap.add_argument("--split", choices=["points", "windows"], default="points",
+                    help="msm26: how the MSM is cut over the ranks -- by POINTS (SURVEY.md 8e's preferred partition, 1/N of the scalars and "
+                         "bases per rank; default) or by WINDOWS (BASELINE configs[3] as worded: every rank holds all points)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
     ap.add_argument("--no-secondary", action="store_true", help="skip the H2D-inclusive and whole-MSM measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")

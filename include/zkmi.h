@@ -143,6 +143,19 @@ int32_t zkmi_comm_destroy(zkmi_comm* comm);
 int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
                                       const zkmi_bases_g1* bases, uint64_t plan_n, uint8_t out_affine[96]);
 
+/* The WINDOW split (BASELINE configs[3] as worded: "windows split across 8 GPUs"): every rank holds ALL n scalars and
+ * bases and computes the sums of a contiguous range of the plan's windows; the ranks' windows are disjoint, so the
+ * exchange is a concatenation.  zkmi_msm_g1_window_range_dev: windows [w_first, w_first + w_count) of the plan of plan_n
+ * terms -> w_count x 96 B (the caller combines: zkmi_msm_g1_combine over n_ranks x nwin_total windows with all-zero =
+ * infinity entries where a rank owns nothing).  zkmi_msm_g1_window_split_allgather: the collective form over a zkmi_comm
+ * (rank k takes windows [k nwin / R, (k + 1) nwin / R)); the full result on every rank.  The POINT split above moves 1 / R
+ * of the scalars and bases per rank and is what bench.py measures by default. */
+int32_t zkmi_msm_g1_window_range_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                     uint64_t plan_n, uint32_t w_first, uint32_t w_count, uint8_t* out_windows_affine,
+                                     uint32_t* out_nwin_total, uint32_t* out_window_bits);
+int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
+                                           const zkmi_bases_g1* bases, uint8_t out_affine[96]);
+
 /* Same split driven from ONE process holding one ctx per GPU (SURVEY.md §8b
  * "zkmi_msm_g1_multi", BASELINE config 3): device d holds counts[d] scalars at
  * d_scalars[d] and the matching slice of the points in bases[d] (loaded on

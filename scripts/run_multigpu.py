@@ -145,7 +145,29 @@ def main():
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         okt = torch.tensor([1 if got_c == want and got_c == got else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        # BASELINE configs[3] as worded: the WINDOWS split over the ranks, every rank over ALL points (it needs every scalar
+        # and base resident: only run where that fits this script's budget), RCCL all-gather of the window partials
+        okw = None
+        if args.msm_log_n <= 22:
+            gall = [torch.Generator(device="cuda").manual_seed(1000 + k) for k in range(world)]
+            parts = []
+            for k in range(world):
+                ak, bk = par.shard_units(n, k, world)
+                t = torch.randint(0, 256, (bk - ak, 32), dtype=torch.uint8, device="cuda", generator=gall[k])
+                t[:, 31] &= 0x3F
+                parts.append(t)
+            raw_all = torch.cat(parts).contiguous()
+            bases_all = ctx.bases_g1_synthetic(n)
+            got_w = ctx.msm_g1_window_split_allgather(comm, raw_all.data_ptr(), n, bases_all)
+            okw = torch.tensor([1 if got_w == want else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okw, op=dist.ReduceOp.MIN)
+            bases_all.free()
+            del raw_all
         comm.free()
+        if rank == 0 and okw is not None:
+            print(json.dumps({"config": 3, "workload": "the same MSM with its WINDOWS split over the ranks (zkmi_msm_g1_window_split_allgather)",
+                              "matches_closed_form_on_every_rank": bool(okw.item()), "n_gpus": world}), flush=True)
+        assert okw is None or okw.item() == 1
         if rank == 0:
             print(json.dumps({"config": 3, "workload": "the same MSM through zkmi_msm_g1_allgather_combine (RCCL behind the C ABI)",
                               "matches_closed_form_and_python_path_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),

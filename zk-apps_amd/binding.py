@@ -757,6 +757,20 @@ class Context:
         self._chk(self.lib.zkmi_selftest_msm_g1_sum2_dev(self.h, C.c_void_p(dptr_a), C.c_void_p(dptr_b), C.c_uint64(n), bases.h, out))
         return bytes(out)
 
+    def msm_g1_window_range_dev(self, dptr, n, bases, plan_n, w_first, w_count):
+        """(w_count x 96 B window sums over ALL n points, total windows of the plan, window bits): a rank of a WINDOW split"""
+        out = (C.c_uint8 * (96 * max(1, w_count)))()
+        tot, cbits = C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.zkmi_msm_g1_window_range_dev(self.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, C.c_uint64(plan_n),
+                                                        C.c_uint32(w_first), C.c_uint32(w_count), out, C.byref(tot), C.byref(cbits)))
+        return bytes(out)[: 96 * w_count], tot.value, cbits.value
+
+    def msm_g1_window_split_allgather(self, comm, dptr, n, bases):
+        """BASELINE configs[3] as worded: windows split over the ranks of `comm`, RCCL all-gather, the full result (collective)"""
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_window_split_allgather(self.h, comm.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):
         out = (C.c_uint8 * (96 * 64))()
         nwin, cbits = C.c_uint32(), C.c_uint32()

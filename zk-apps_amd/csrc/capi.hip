@@ -497,6 +497,37 @@ int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n
   return ZKMI_OK;
 }
 
+// The WINDOW split of BASELINE configs[3] as worded: this rank takes windows [w_first, w_first + w_count) of the plan of
+// plan_n terms over ALL n points (it needs all scalars and all bases resident) and returns their sums; the ranks hold
+// disjoint windows, so the exchange is a concatenation and the combination a Horner walk (zkmi_msm_g1_combine with
+// infinity in the windows a rank does not own, or zkmi_msm_g1_window_split_allgather).
+int32_t zkmi_msm_g1_window_range_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                     uint64_t plan_n, uint32_t w_first, uint32_t w_count, uint8_t* out_windows_affine,
+                                     uint32_t* out_nwin_total, uint32_t* out_window_bits) {
+  ZK_ENTER(ctx);
+  if (!ctx || !bases || !out_windows_affine || n > bases->n || n > MSM_MAX_TERMS || plan_n > MSM_MAX_TERMS || (n && !d_scalars))
+    return ZKMI_ERR_BAD_ARG;
+  if (plan_n < n) plan_n = n;
+  const MsmPlan pl = msm_make_plan(plan_n);
+  if (w_count == 0 || w_first + w_count > (uint32_t)pl.nwin) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, ctx->sort.reserve(plan_n));
+  ZK_HIP(ctx, ctx->g1.reserve(plan_n));
+  ctx->sort.plan_override = pl.c;
+  ctx->sort.win_first = (int)w_first;
+  ctx->sort.win_count = (int)w_count;
+  const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+  ctx->sort.plan_override = 0;
+  ctx->sort.win_first = ctx->sort.win_count = 0;
+  if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  std::vector<G1XYZZ> win(w_count);
+  ZK_HIP(ctx, ctx->g1.finish_host_windows(win.data()));
+  for (uint32_t w = 0; w < w_count; w++) g1_to_wire(win[w].to_affine(), out_windows_affine + 96 * w);
+  if (out_nwin_total) *out_nwin_total = (uint32_t)pl.nwin;
+  if (out_window_bits) *out_window_bits = (uint32_t)pl.c;
+  return ZKMI_OK;
+}
+
 int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* const* d_scalars, const uint64_t* counts,
                           const zkmi_bases_g1* const* bases, uint8_t out_affine[96]) {
   if (!ctxs || !d_scalars || !counts || !bases || !out_affine || n_dev == 0 || n_dev > 64) return ZKMI_ERR_BAD_ARG;

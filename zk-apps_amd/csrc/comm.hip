@@ -12,6 +12,7 @@
 // called on it) or else from librccl.so.1.  A host without RCCL can load the library and use everything but this file.
 #include <dlfcn.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 #include "ctx.hpp"
@@ -191,6 +192,70 @@ int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void
     for (int w = 0; w < sp.nwin; w++) sum[w].add(win[w]);
   }
   const G1XYZZ res = msm_combine_windows<Fq>(sum.data(), sp.nwin, sp.c);
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+// The window split as a collective: every rank holds ALL n scalars and bases and takes a contiguous share of the plan's
+// windows (rank k: windows [k nwin / R, (k + 1) nwin / R) up to rounding; a rank beyond the window count takes none); the
+// per-(window, job) partial sums are all-gathered in equal-sized slots and every rank walks the windows once.
+int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
+                                           const zkmi_bases_g1* bases, uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
+  if (!comm || comm->ctx != ctx || !bases || !out_affine || n == 0 || n > bases->n || n > MSM_MAX_TERMS || !d_scalars) return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
+  const MsmPlan pl = msm_make_plan(n);
+  const uint32_t R = comm->n_ranks, nwin = (uint32_t)pl.nwin;
+  auto first_of = [&](uint32_t k) { return (uint32_t)(((uint64_t)k * nwin) / R); };
+  const uint32_t w0 = first_of(comm->rank), w1 = first_of(comm->rank + 1);
+  uint32_t max_w = 0;
+  for (uint32_t k = 0; k < R; k++) max_w = std::max(max_w, first_of(k + 1) - first_of(k));
+  ZK_HIP(ctx, ctx->sort.reserve(n));
+  ZK_HIP(ctx, ctx->g1.reserve(n));
+  // sub-plan of a rank: the plan with its window range (what the sort of that rank runs)
+  auto sub_plan = [&](uint32_t k) {
+    MsmPlan q = pl;
+    q.nwin_total = pl.nwin;
+    q.win_first = (int)first_of(k);
+    q.nwin = (int)(first_of(k + 1) - first_of(k));
+    return q;
+  };
+  const int per_window = MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin;
+  const uint64_t slot_bytes = sizeof(G1XYZZ) * (uint64_t)per_window * max_w;
+  if ((uint64_t)per_window * max_w > (uint64_t)MsmEngine<Fq28>::SLOT_PTS) return ZKMI_ERR_BAD_ARG;
+  if (w1 > w0) {
+    ctx->sort.win_first = (int)w0;
+    ctx->sort.win_count = (int)(w1 - w0);
+    const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+    ctx->sort.win_first = ctx->sort.win_count = 0;
+    if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+    ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  }
+  if (comm->gather_cap < slot_bytes * R) {
+    if (comm->d_gather) (void)hipFree(comm->d_gather);
+    comm->d_gather = nullptr;
+    comm->gather_cap = 0;
+    ZK_HIP(ctx, hipMalloc(&comm->d_gather, slot_bytes * R));
+    comm->gather_cap = slot_bytes * R;
+  }
+  // (a rank's slot is the head of its `partial` array: whatever lies behind its own windows is ignored by the readers)
+  const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)slot_bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
+  if (rc != 0) {
+    (void)ctx->drain();
+    return rccl_fail(ctx, rc, "ncclAllGather");
+  }
+  std::vector<uint8_t> all(slot_bytes * R);
+  ZK_HIP(ctx, hipMemcpyAsync(all.data(), comm->d_gather, slot_bytes * R, hipMemcpyDeviceToHost, ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<G1XYZZ> win(nwin, G1XYZZ::infinity());
+  for (uint32_t k = 0; k < R; k++) {
+    const MsmPlan q = sub_plan(k);
+    if (q.nwin > 0)
+      MsmEngine<Fq28>::windows_from_partials(q, reinterpret_cast<const G1XYZZ*>(all.data() + slot_bytes * k), win.data() + q.win_first);
+  }
+  const G1XYZZ res = msm_combine_windows<Fq>(win.data(), (int)nwin, pl.c);
   g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }

@@ -71,6 +71,10 @@ struct MsmPlan {
   // and the partition's share of that weight sits in the top top_spread_log bits of the SEGMENT index, whose bit sums
   // the host simply leaves out for this window (MsmEngine::finish_host_windows).
   int top_spread_log = 0;
+  // a sort restricted to the windows [win_first, win_first + nwin) of a windowed plan with nwin_total windows (a rank of a
+  // WINDOW-split MSM: BASELINE configs[3] as worded, MsmSort::win_first / win_count); nwin_total = 0: all windows
+  int win_first = 0, nwin_total = 0;
+  int total_windows() const { return nwin_total ? nwin_total : nwin; }
 };
 MsmPlan msm_make_plan(uint64_t n);
 MsmPlan msm_make_plan_c(uint64_t n, int c);
@@ -95,6 +99,7 @@ struct MsmSort {
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;
   int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
+  int win_first = 0, win_count = 0;  // run(): only these windows of the plan (win_count = 0: all); reset by the caller
   // events of kernels on OTHER streams that still read count/begin/heavy/sorted (the heavy-bucket
   // kernels of MsmEngine::run_device): the next sort waits for them before it overwrites the buffers
   mutable std::vector<hipEvent_t> readers;

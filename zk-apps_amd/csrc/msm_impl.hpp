@@ -1433,7 +1433,7 @@ void MsmEngine<F>::windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, X
     XYZZ<HF> u = XYZZ<HF>::infinity();
     // (top window of a partitioned big-window plan: the top bits of the segment index number the partition its entries
     // were spread to, not the digit -- MsmPlan::top_spread_log)
-    const int bits = (w == pl.nwin - 1 && pl.top_spread_log > 0) ? seg_bits - pl.top_spread_log : seg_bits;
+    const int bits = (pl.win_first + w == pl.total_windows() - 1 && pl.top_spread_log > 0) ? seg_bits - pl.top_spread_log : seg_bits;
     for (int j = bits - 1; j >= 0; j--) {
       u.dbl_inplace();
       u.add(h[(size_t)w * njobs + 1 + j]);

@@ -51,9 +51,9 @@ __device__ __forceinline__ uint32_t digit_of(const uint32_t* k, int w, int c, bo
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024)
 k_bucket_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, uint32_t nb, uint32_t chunk, RecodeConst rc,
-              uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted) {
+              uint32_t* __restrict__ blockhist, uint32_t* __restrict__ sorted, uint32_t w0) {
   extern __shared__ uint32_t hist[];
-  const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+  const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;  // w: window of this sort; w0 + w: digit position
   uint32_t* gh = blockhist + ((size_t)w * nch + ch) * nb;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = SCATTER ? gh[b] : 0u;
   __syncthreads();
@@ -63,7 +63,7 @@ k_bucket_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, uint32_t 
     uint32_t k[9];
     load_biased(scalars, i, rc, k);
     bool neg;
-    const uint32_t d = digit_of(k, (int)w, c, neg);
+    const uint32_t d = digit_of(k, (int)(w0 + w), c, neg);
     if (d) {
       if (SCATTER) {
         const uint32_t pos = atomicAdd(&hist[d - 1], 1u);
@@ -135,13 +135,14 @@ template <bool WRITE, bool WIN = false>
 __global__ void __launch_bounds__(1024)
 k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P,
             uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry,
-            uint32_t* __restrict__ rec_bkt) {
+            uint32_t* __restrict__ rec_bkt, int w0 = 0, int w_top_pos = -1) {
   __shared__ uint32_t cnt[PART_MAX];
   if (threadIdx.x < PART_MAX) cnt[threadIdx.x] = (WRITE && threadIdx.x < P) ? blkcnt[blockIdx.x * P + threadIdx.x] : 0u;
   __syncthreads();
   const uint32_t ppw = WIN ? ((1u << (c - 1)) >> nb_log) : 0u;
   // the top window's digits are < 2^nb_log: its entries go to partition (point mod ppw) instead of partition 0 (MsmPlan::top_spread_log)
-  const int w_top = WIN ? ndigits - 1 : -1;
+  // (WIN: digit positions [w0, w0 + ndigits) of the scalar; w_top_pos = position of the plan's top window)
+  const int w_top = WIN ? w_top_pos - w0 : -1;
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
   for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
@@ -149,7 +150,7 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
     load_biased(scalars, i, rc, k);
     for (int w = 0; w < ndigits; w++) {
       bool neg;
-      const uint32_t d = digit_of(k, w, c, neg);
+      const uint32_t d = digit_of(k, WIN ? w0 + w : w, c, neg);
       if (d == 0) continue;
       const uint32_t bkt = d - 1;
       const uint32_t q = WIN ? (uint32_t)w * ppw + (w == w_top ? (i & (ppw - 1u)) : (bkt >> nb_log)) : bkt >> nb_log;
@@ -964,6 +965,12 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
     if (er != hipSuccess) return er;
   }
   plan = plan_override ? msm_make_plan_c(n, plan_override) : msm_make_plan(n);
+  if (win_count > 0) {
+    if (win_first < 0 || win_first + win_count > plan.nwin) return hipErrorInvalidValue;
+    plan.nwin_total = plan.nwin;
+    plan.win_first = win_first;
+    plan.nwin = win_count;
+  }
   if (plan_is_big(plan)) return run_windowed_big(d_scalars, n, st, prof);
   const uint32_t nb = plan.nb, nwin = (uint32_t)plan.nwin;
   const uint32_t tot_b = nwin * nb;
@@ -973,7 +980,7 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   // M = sum_w (2^(c-1) - 1) 2^(c w), 9 limbs
   RecodeConst rc;
   for (int j = 0; j < 9; j++) rc.m[j] = 0;
-  for (uint32_t w = 0; w < nwin; w++) {
+  for (uint32_t w = 0; w < (uint32_t)plan.total_windows(); w++) {  // (the recoding bias covers ALL digit positions)
     const uint64_t v = (1ull << (plan.c - 1)) - 1;
     const int bit = (int)w * plan.c, limb = bit >> 5, sh = bit & 31;
     if (limb < 9) {
@@ -990,7 +997,7 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, nwin);
   hipLaunchKernelGGL(k_bucket_pass<false>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
-                     blockhist, sorted);
+                     blockhist, sorted, (uint32_t)plan.win_first);
   hipLaunchKernelGGL(k_bucket_totals, dim3((tot_b + 255) / 256), dim3(256), 0, st, blockhist, count, nb, nch, tot_b);
   hipLaunchKernelGGL(k_window_scan, dim3(nwin), dim3(1024), 0, st, count, begin, nb, (uint32_t)n,
                      (const uint32_t*)nullptr);
@@ -999,7 +1006,7 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
   hipError_t e0 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
   if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(k_bucket_pass<true>, grid, dim3(1024), lds, st, d_scalars, (uint32_t)n, plan.c, nb, chunk, rc,
-                     blockhist, sorted);
+                     blockhist, sorted, (uint32_t)plan.win_first);
   if (prof) prof->end(PH_MSM_SORT, st);
   return hipGetLastError();
 }
@@ -1020,7 +1027,7 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
     return hipErrorInvalidValue;
   RecodeConst rc;
   for (int j = 0; j < 9; j++) rc.m[j] = 0;
-  for (uint32_t w = 0; w < nwin; w++) {
+  for (uint32_t w = 0; w < (uint32_t)plan.total_windows(); w++) {  // (the recoding bias covers ALL digit positions)
     const uint64_t v = (1ull << (plan.c - 1)) - 1;
     const int bit = (int)w * plan.c, limb = bit >> 5, sh = bit & 31;
     if (limb < 9) {
@@ -1037,11 +1044,12 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
   if (nblk > 256) nblk = 256;
   if (!nblk) nblk = 1;
   const uint32_t chunk = (uint32_t)((n + nblk - 1) / nblk);
+  const int w_top_pos = plan.total_windows() - 1;
   hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
-                     chunk, rc, blkcnt, rec_entry, rec_bkt);
+                     chunk, rc, blkcnt, rec_entry, rec_bkt, plan.win_first, w_top_pos);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
   hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
-                     chunk, rc, blkcnt, rec_entry, rec_bkt);
+                     chunk, rc, blkcnt, rec_entry, rec_bkt, plan.win_first, w_top_pos);
   const size_t lds = sizeof(uint32_t) * nb;
   const dim3 grid(nch, P);
   hipLaunchKernelGGL(k_bucket_pass_rec<false>, grid, dim3(1024), lds, st, rec_entry, rec_bkt, part_total, nb, blockhist, sorted);
