@@ -202,6 +202,25 @@ def cpu_baseline(z, ctx, sample_log_n, full_log_n, relation):
     }
 
 
+class stdout_to_stderr:
+    """fd-level redirect of stdout to stderr for the duration of the block, C stdio buffers included"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # text a C library printed sits in ITS stdout buffer: flush while fd 1 is still stderr
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def _need_torch():
     global torch, dist
     if torch is None:
@@ -436,22 +455,12 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     # the exchange behind the C ABI: zkmi_comm (RCCL; torch.distributed only carries rank 0's 128-byte id), partial sums
     # all-gathered from HBM on the reduction stream, combined on every rank -- also at one rank (a world of 1)
     # (RCCL prints a version banner on STDOUT when its first communicator comes up: sent to stderr, stdout carries the one JSON line)
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with stdout_to_stderr():
         if use_dist:
             comm = par.rccl_comm(z, ctx)
         else:
             comm = ctx.comm_init(1, 0, z.comm_unique_id())
-        one_ = one()  # first collective (workspaces, RCCL channels)
-        del one_
-    finally:
-        import ctypes
-
-        ctypes.CDLL(None).fflush(None)  # the banner sits in the C library's stdout buffer: flush it while fd 1 is still stderr
-        os.dup2(saved, 1)
-        os.close(saved)
+        one()  # first collective (workspaces, RCCL channels)
 
     for _ in range(max(1, args.warmup)):  # the first call allocates the workspaces
         one()
@@ -531,6 +540,15 @@ def main():
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not launched and args.gpus > 1:
         return spawn_ranks(args.gpus)  # before anything touches the GPU
+    # From here on file descriptor 1 is stderr and the one JSON line goes to a private duplicate of the real stdout:
+    # libraries chat on stdout whenever they like (RCCL prints a version banner when a communicator comes up -- during the
+    # first collective, from C stdio, sometimes after the call that caused it has returned), and the contract is ONE line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -544,7 +562,13 @@ def main():
     # barriers around the timed region and the max-over-ranks of the elapsed time -- no data-path collective
     use_dist = launched and "MASTER_ADDR" in os.environ
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up (at the first collective): bring it
+        # up here with fd 1 pointed at stderr, so that stdout carries nothing but rank 0's one JSON line
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
 
     pkg = load_pkg()
     z = pkg.Zkmi()
@@ -552,7 +576,7 @@ def main():
     if args.workload == "msm26":
         out, rc = run_msm26(args, pkg, z, ctx, rank, world, use_dist)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         ctx.close()
         if use_dist:
             dist.destroy_process_group()
@@ -721,7 +745,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n, args.relation)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if pk is not None:
         pk.free()
     ctx.close()
