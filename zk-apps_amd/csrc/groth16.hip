@@ -863,7 +863,9 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // And only for one-proof groups (N >= 2^20): in a group of small proofs the relation's bit variables fill real heavy
   // buckets, the L query's cooperative kernel takes milliseconds, and the H accumulation would wait for it instead of
   // running beside it (2^14: 2 355 / 2 293 proofs/s apart, 2 220 / 2 200 merged: lh_merge_small_domain_ab.txt).
-  const bool lh_merge = lh_merge_on && sh && followed && G == 1 && same_bucket_set(sz.plan, msm_make_plan_shared(N));
+  // (A/B library: ZKMI_LH_MERGE_GROUPS=1 merges in groups as well)
+  const bool lh_merge = lh_merge_on && sh && followed && (G == 1 || ZK_TUNE("ZKMI_LH_MERGE_GROUPS", 0) == 1) &&
+                        same_bucket_set(sz.plan, G > 1 ? msm_make_plan_shared_batch(N, G) : msm_make_plan_shared(N));
   ctx->h_mode[par] = lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
