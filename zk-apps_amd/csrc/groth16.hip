@@ -119,7 +119,9 @@ k_check_sat(const Fr28* __restrict__ a, const Fr28* __restrict__ b, const Fr28* 
     const Fr28 d = (ld28(z) - Fr28::one()) * Fr28::one();
     bad = bad || !d.is_zero();
   }
-  if (bad) atomicOr(flag, 1u);
+  // (the flag word lives in pinned HOST memory: a rare system-scope atomic instead of a memset kernel in front of and a
+  // copy kernel behind every proof's checks -- both were 512-thread blits that waited ~0.2 ms each for SIMDs on the front stream)
+  if (bad) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // every witness element must be a canonical integer < r: the MSM digits are taken from the raw words while
@@ -138,7 +140,7 @@ k_check_canonical(const uint32_t* __restrict__ z, uint32_t n, uint32_t* __restri
       lt = w[k] < Fr28Params::MOD32[k];
       decided = true;
     }
-  if (!lt) atomicOr(flag, 2u);
+  if (!lt) __hip_atomic_fetch_or(flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void __launch_bounds__(256)
@@ -248,8 +250,9 @@ struct zkmi_pk {
   mutable const Fr* z_cur[zkmi_ctx::PROOF_RING] = {};
   uint32_t* d_h[zkmi_ctx::PROOF_RING] = {};
   Fr28 *d_zm = nullptr, *d_a = nullptr;  // limb form (field28.hpp), front stream only; d_a holds a, b, c of a group back to back
-  uint32_t* d_unsat = nullptr;  // per proof in flight: set by k_check_sat
-  uint32_t* h_unsat = nullptr;  // pinned host copy, valid once the proof's H MSM has landed
+  // per proof in flight, in pinned host memory: bit 0 set by k_check_sat, bit 1 by k_check_canonical (system-scope atomics);
+  // valid once the proof's H MSM has landed (it waits for the front stream), cleared by the host when it has read it
+  uint32_t* h_unsat = nullptr;
   ~zkmi_pk() {
     if (device >= 0) (void)hipSetDevice(device);  // the key's buffers live on its context's device (the ctx may be gone)
     (void)hipDeviceSynchronize();  // nothing queued by an earlier call may still read the key or write its pinned flags
@@ -263,7 +266,6 @@ struct zkmi_pk {
     static_assert(zkmi_ctx::PROOF_RING == 3, "ring size");
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
-    if (d_unsat) (void)hipFree(d_unsat);
     if (h_unsat) (void)hipHostFree(h_unsat);
   }
 };
@@ -329,8 +331,7 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   // one batched launch per pass (3 x G vectors)
   // (a group of g <= G proofs uses the first 3 g N elements: a[0..g), b[0..g), c[0..g))
   if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * 3 * N * G)) != hipSuccess) return e;
-  if ((e = hipMalloc(&pk->d_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t))) != hipSuccess) return e;
-  if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocCoherent)) != hipSuccess) return e;
   for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
@@ -681,9 +682,8 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_z[par], 0));
   if (st != ctx->stream) ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_z[par], 0));
   if (t) t->begin(PH_WITNESS, st);
-  ZK_HIP(ctx, hipMemsetAsync(pk->d_unsat + par, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_check_canonical, dim3((G * nv + 63) / 64), dim3(64), 0, st,
-                     reinterpret_cast<const uint32_t*>(pk->z_cur[par]), G * nv, pk->d_unsat + par);
+                     reinterpret_cast<const uint32_t*>(pk->z_cur[par]), G * nv, pk->h_unsat + par);
   ZK_HIP(ctx, ntt_from_canonical(reinterpret_cast<const uint32_t*>(pk->z_cur[par]), pk->d_zm, G * nv, st));
   MatSet ms;
   for (int m = 0; m < 3; m++) {
@@ -698,8 +698,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   Fr28* const d_b = pk->d_a + (size_t)N * G;  // the layout follows the size of THIS group, not the key's maximum
   Fr28* const d_c = pk->d_a + 2 * (size_t)N * G;
   hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 64) / 64, G), dim3(64), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
-                     pk->d_unsat + par, N, nv);
-  ZK_HIP(ctx, hipMemcpyAsync(pk->h_unsat + par, pk->d_unsat + par, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                     pk->h_unsat + par, N, nv);
   if (t) t->end(PH_WITNESS, st);
   hipError_t e;
   NttDomain* dom = ctx->domain((int)pk->log_n, &e);
@@ -741,7 +740,9 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
   std::vector<uint8_t> rev(32ull * N);
   ZK_HIP(ctx, hipMemcpyAsync(rev.data(), pk->d_h[0], 32ull * N, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (pk->h_unsat[0] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+  const uint32_t flags0 = pk->h_unsat[0];
+  pk->h_unsat[0] = 0;
+  if (flags0 & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
   for (uint32_t p = 0; p < N; p++) {
     uint32_t i = 0;
     for (uint32_t b = 0; b < pk->log_n; b++) i |= ((p >> b) & 1u) << (pk->log_n - 1 - b);
@@ -1025,8 +1026,10 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     mark(3);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3));
     mark(4);
-    if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
-    if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+    const uint32_t flags = pk->h_unsat[par];
+    pk->h_unsat[par] = 0;  // (the slot's next proof is queued after this function returns)
+    if (flags & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+    if (flags) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
     assemble_tail(head, acc_l[0], acc_h[0], out_proofs);
     mark(5);
     if (lat_debug)
@@ -1044,8 +1047,12 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_h.data(), s0 + 3));
   }
   // the flag copy precedes the h coefficients on the front stream, which the H MSM waited for
-  if (pk->h_unsat[par] & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
-  if (pk->h_unsat[par]) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+  {
+    const uint32_t flags = pk->h_unsat[par];
+    pk->h_unsat[par] = 0;
+    if (flags & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+    if (flags) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+  }
   auto one = [&](uint32_t b) {
     assemble_proof(pk, acc_a[b], acc_b1[b], acc_l[b], acc_h[b], acc_b2[b], r_bytes + 32ull * b, s_bytes + 32ull * b,
                    out_proofs + 192ull * b);
@@ -1092,6 +1099,7 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
     (void)ctx->drain();
     (void)ctx->g1.reset_transients();  // an MSM abandoned between its accumulation and its redo pass leaves a list behind
     (void)ctx->g2.reset_transients();
+    for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;  // flags of proofs that were queued and never finished
     ctx->err = msg;
   }
   return rc;
@@ -1199,6 +1207,7 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
     (void)ctx->drain();
     (void)ctx->g1.reset_transients();
     (void)ctx->g2.reset_transients();
+    for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
     ctx->err = msg;
     return code;
   };

@@ -757,7 +757,8 @@ k_segreduce_g2_split(const XYZZ<Fq2_28>* __restrict__ buckets, XYZZ<Fq2_28>* __r
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, uint32_t segs_per_win,
-          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial, int plain_job, XYZZ<F>* __restrict__ stage) {
+          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial, int plain_job, XYZZ<F>* __restrict__ stage,
+          XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial_host) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const int job = blockIdx.x;
@@ -796,7 +797,10 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
     if (nchunk == 1) {
       XYZZ<typename HostFieldOf<F>::type> o = {fq_from_fq28(acc.x), fq_from_fq28(acc.y), fq_from_fq28(acc.zz),
                                                fq_from_fq28(acc.zzz)};
+      // device copy (the RCCL exchange gathers it) and, directly, the pinned host slot the combining thread reads: no
+      // device-to-host copy behind the reduction (it ran as a blit kernel, 0.3 ms of waiting for SIMDs per MSM)
       store_vec(partial + (size_t)w * gridDim.x + job, o);
+      store_vec(partial_host + (size_t)w * gridDim.x + job, o);
     } else {
       store_vec(stage + ((size_t)w * gridDim.x + job) * nchunk + z, acc);
     }
@@ -806,7 +810,8 @@ k_treesum(const XYZZ<F>* __restrict__ segsum, const XYZZ<F>* __restrict__ segw, 
 // grid = (njobs, nwin), nchunk <= blockDim.x (a power of two) <= MSM_TREE_T: adds the slices of one (window, job)
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
-k_treesum_final(const XYZZ<F>* __restrict__ stage, uint32_t nchunk, XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial) {
+k_treesum_final(const XYZZ<F>* __restrict__ stage, uint32_t nchunk, XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial,
+                XYZZ<typename HostFieldOf<F>::type>* __restrict__ partial_host) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const size_t idx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -825,6 +830,7 @@ k_treesum_final(const XYZZ<F>* __restrict__ stage, uint32_t nchunk, XYZZ<typenam
     XYZZ<typename HostFieldOf<F>::type> o = {fq_from_fq28(acc.x), fq_from_fq28(acc.y), fq_from_fq28(acc.zz),
                                              fq_from_fq28(acc.zzz)};
     store_vec(partial + idx, o);
+    store_vec(partial_host + idx, o);
   }
 }
 
@@ -854,7 +860,7 @@ __device__ __forceinline__ XYZZ<Fq2P> pair_tree_sum(XYZZ<Fq2P> acc, XYZZ<Fq2_28>
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(2 * MSM_TREE_T, 2)
 k_treesum_g2_split(const XYZZ<Fq2_28>* __restrict__ segsum, const XYZZ<Fq2_28>* __restrict__ segw, uint32_t segs_per_win,
-                   XYZZ<Fq2>* __restrict__ partial, int plain_job, XYZZ<Fq2_28>* __restrict__ stage) {
+                   XYZZ<Fq2>* __restrict__ partial, int plain_job, XYZZ<Fq2_28>* __restrict__ stage, XYZZ<Fq2>* __restrict__ partial_host) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
   const int job = blockIdx.x;
@@ -876,14 +882,18 @@ k_treesum_g2_split(const XYZZ<Fq2_28>* __restrict__ segsum, const XYZZ<Fq2_28>* 
   acc = pair_tree_sum(acc, sh, pair, npair, comp);
   if (pair == 0) {
     if (nchunk == 1)
+    {
       st_host_split(partial + (size_t)w * gridDim.x + job, acc, comp);
+      st_host_split(partial_host + (size_t)w * gridDim.x + job, acc, comp);
+    }
     else
       st_xyzz_split(stage + ((size_t)w * gridDim.x + job) * nchunk + z, acc, comp);
   }
 }
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(2 * MSM_TREE_T, 2)
-k_treesum_final_g2_split(const XYZZ<Fq2_28>* __restrict__ stage, uint32_t nchunk, XYZZ<Fq2>* __restrict__ partial) {
+k_treesum_final_g2_split(const XYZZ<Fq2_28>* __restrict__ stage, uint32_t nchunk, XYZZ<Fq2>* __restrict__ partial,
+                         XYZZ<Fq2>* __restrict__ partial_host) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
   const size_t idx = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -891,7 +901,10 @@ k_treesum_final_g2_split(const XYZZ<Fq2_28>* __restrict__ stage, uint32_t nchunk
   XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
   if (pair < nchunk) acc = ld_xyzz_split(stage + idx * nchunk + pair, comp);
   acc = pair_tree_sum(acc, sh, pair, npair, comp);
-  if (pair == 0) st_host_split(partial + idx, acc, comp);
+  if (pair == 0) {
+    st_host_split(partial + idx, acc, comp);
+    st_host_split(partial_host + idx, acc, comp);
+  }
 }
 
 // Lane-pair forms of the heavy-bucket and redo kernels for G2: same logic as k_accum_heavy / k_accum_redo with a lane
@@ -1078,7 +1091,7 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMemset(heavy_ticket, 0, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots)) != hipSuccess) return e;  // every use leaves zeros behind
   if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // one list per slot
   if ((e = hipMemset(redo, 0, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // lengths and tickets start at zero
-  if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocDefault)) != hipSuccess) return e;
+  if ((e = hipHostMalloc(&h_partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS, hipHostMallocCoherent)) != hipSuccess) return e;
   for (int i = 0; i < SLOTS; i++) {
     hipEvent_t* evs[] = {&done[i], &acc_done[i], &pre[i], &heavy_done[i], &redo_done[i]};
     for (hipEvent_t* ev : evs)
@@ -1375,39 +1388,38 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg);
     }
     XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
+    XYZZ<HF>* const hp_out = h_partial + (size_t)slot * SLOT_PTS;  // pinned host slot, written by the tree-sum kernels themselves
     XYZZ<F>* const stg = tree_stage + (size_t)slot * MSM_STAGE_PTS;
     if constexpr (is_g2) {
       if (nchunk > 1) {
         hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, st_reduce,
-                           ssum, sw, segs_per_win, dp, plain_job, stg);
+                           ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
         uint32_t tf = 64;
         while (tf < 2 * nchunk) tf <<= 1;
-        hipLaunchKernelGGL(k_treesum_final_g2_split<0>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf / 2, st_reduce, stg, nchunk, dp);
+        hipLaunchKernelGGL(k_treesum_final_g2_split<0>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf / 2, st_reduce, stg, nchunk, dp, hp_out);
       } else {
         // big plans: the same lane-pair kernel, 128 pairs per job (the unsplit form's 330-register additions made this the
         // slowest link of a proof's tail: 16 + 7 dependent additions of 45-60 us); A/B library, ZKMI_G2_TREE_SPLIT=0: the unsplit kernel
 #ifdef ZKMI_EXPERIMENTS
         if (ZK_TUNE("ZKMI_G2_TREE_SPLIT", 1) == 0)
           hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, 1), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                             ssum, sw, segs_per_win, dp, plain_job, stg);
+                             ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
         else
 #endif
           hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                             ssum, sw, segs_per_win, dp, plain_job, stg);
+                             ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
       }
     } else {
       hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
-                         ssum, sw, segs_per_win, dp, plain_job, stg);
+                         ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
       if (nchunk > 1) {
         uint32_t tf = 64;
         while (tf < nchunk) tf <<= 1;
-        hipLaunchKernelGGL(k_treesum_final<F>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf, st_reduce, stg, nchunk, dp);
+        hipLaunchKernelGGL(k_treesum_final<F>, dim3(njobs, pl.nwin), dim3(tf), sizeof(XYZZ<F>) * tf, st_reduce, stg, nchunk, dp, hp_out);
       }
     }
     if (prof) prof->end(ph_reduce, st_reduce);
-    e = hipMemcpyAsync(h_partial + (size_t)slot * SLOT_PTS, dp, sizeof(XYZZ<HF>) * pl.nwin * njobs,
-                       hipMemcpyDeviceToHost, st_reduce);
-    if (e != hipSuccess) return e;
+    // (the partials are in the pinned host slot when the last tree-sum kernel has finished: the event is all that is left)
     if ((e = hipEventRecord(done[slot], st_reduce)) != hipSuccess) return e;
   }
   return hipGetLastError();
