@@ -665,12 +665,14 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // over PCIe) proceeds while the compute streams still work on proofs i-1 and i; the ring of witness
   // buffers makes that safe.  Canonicity (< r) is checked on the device, not in a host loop.
   pk->z_cur[par] = pk->d_z[par];
+  bool aligned = true;  // 16-byte aligned device pointers (the vector loads of the sort and of k_gather_z)
+  for (uint32_t b = 0; b < G; b++) aligned = aligned && (reinterpret_cast<uintptr_t>(src[b]) & 15u) == 0;
   if (host) {
     for (uint32_t b = 0; b < G; b++)
       ZK_HIP(ctx, hipMemcpyAsync(pk->d_z[par] + (size_t)b * nv, src[b], 32ull * nv, hipMemcpyHostToDevice, ctx->stream_copy));
-  } else if (G == 1 && (reinterpret_cast<uintptr_t>(src[0]) & 15u) == 0) {
+  } else if (G == 1 && aligned) {
     pk->z_cur[par] = static_cast<const Fr*>(src[0]);  // read in place: the caller's buffer outlives the call
-  } else if (G <= 64 && [&] { for (uint32_t b = 0; b < G; b++) if (reinterpret_cast<uintptr_t>(src[b]) & 15u) return false; return true; }()) {
+  } else if (G <= 64 && aligned) {
     ZPtrSet ps;
     for (uint32_t b = 0; b < 64; b++) ps.p[b] = static_cast<const uint4*>(src[b < G ? b : 0]);
     hipLaunchKernelGGL(k_gather_z, dim3((2 * nv + 63) / 64, G), dim3(64), 0, ctx->stream_copy, ps, reinterpret_cast<uint4*>(pk->d_z[par]), 2 * nv);
