@@ -507,6 +507,18 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
                      "algorithmic_bytes_per_launch": 128 * m,
                      "limiter": "VALU integer issue (384-bit Montgomery products), see DESIGN.md 4.1"},
     }
+    # HBM traffic and instruction count of the accumulation launch from the committed PMC summary of THIS workload
+    # (scripts/profile.sh: separate --pmc passes of `bench.py --workload msm26 --steps 1`), one rank only
+    if world == 1 and args.msm_pmc_summary != "none" and args.split == "points":
+        traffic, note = pmc_traffic(args.msm_pmc_summary, "k_accum_g1_nc")
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_note"] = note
+        out["roofline"]["traffic_source"] = pmc_traffic.source
+        if pmc_traffic.valu and avg_ms > 0:
+            rate = pmc_traffic.valu / (avg_ms * 1e-3)
+            out["roofline_valu"] = {"kernel": pmc_traffic.name, "bound": "valu", "achieved": rate / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
+                                    "unit": "G wave-instr/s", "frac": rate / VALU_ISSUE_PEAK, "wave_insts_per_launch": pmc_traffic.valu}
+    out["source_revision"] = source_revision()
     bases.free()
     if not ok:
         print("bench.py: MSM result differs from the closed form", file=sys.stderr)
@@ -530,6 +542,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
     ap.add_argument("--pmc-summary", default="profiles/r04/pmc_summary_bench_steps3.json")
+    ap.add_argument("--msm-pmc-summary", default="profiles/r04/pmc_summary_msm26_steps1.json")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20 if args.workload == "proofs" else 3

@@ -44,8 +44,15 @@ python3 scripts/pmc_summary.py "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" $
 grep -h '^{' "$OUT/trace.log" | tail -1 > "$DST/bench_line_under_trace.json"
 # the complete line again, now with traffic / instruction counts from the fresh PMC summary
 python3 bench.py --pmc-summary "$DST/pmc_summary_bench_steps${STEPS_PMC}.json" > "$DST/bench_line_full.json" 2> "$OUT/bench_full.err"
-# 4. BASELINE configs[3] behind the bench contract, and the torch-free twin of the headline run under the native HIP runtime
-python3 bench.py --workload msm26 > "$DST/bench_line_msm26_n1.json" 2> "$OUT/bench_msm26.err"
+# 4. BASELINE configs[3] behind the bench contract (with its own PMC passes: HBM traffic and instruction count of the 2^26-term
+#    accumulation launch), and the torch-free twin of the headline run under the native HIP runtime
+MSM="python3 bench.py --workload msm26 --steps 1 --warmup 1 --msm-pmc-summary none"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/msm_pmc_fetch" -- $MSM > "$OUT/msm_pmc_fetch.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/msm_pmc_write" -- $MSM > "$OUT/msm_pmc_write.log" 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv \
+  -d "$OUT/msm_pmc_sq" -- $MSM > "$OUT/msm_pmc_sq.log" 2>&1
+python3 scripts/pmc_summary.py "$DST/pmc_summary_msm26_steps1.json" 2 "$OUT/msm_pmc_fetch" "$OUT/msm_pmc_write" "$OUT/msm_pmc_sq"
+python3 bench.py --workload msm26 --msm-pmc-summary "$DST/pmc_summary_msm26_steps1.json" > "$DST/bench_line_msm26_n1.json" 2> "$OUT/bench_msm26.err"
 gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/bench_prove.c -Lzk-apps_amd -lzkmi -L/opt/rocm/lib -lamdhip64 \
   -Wl,-rpath,$PWD/zk-apps_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/bench_prove && \
   ZKMI_BACKTRACE=1 timeout 900 /tmp/bench_prove --log-n 20 --proofs 20 --warmup 2 --churn ${CHURN_OPS:-2000} > "$DST/c_bench_native_runtime.log" 2>&1
