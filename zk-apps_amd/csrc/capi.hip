@@ -464,7 +464,10 @@ int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, co
   // first MSM: slot 0, no reduction; second: slot 1, adds into slot 0's buckets and reduces both (same reduction stream)
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, pts, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 0, nullptr,
                                  -1, MSM_RUN_NO_REDUCE));
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, pts, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 1, nullptr, 0));
+  // (the product's mechanism: the second MSM's segment sums add both bucket arrays; A/B library with ZKMI_LH_MERGE=1: its
+  // kernels add into the first one's array)
+  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, pts, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 1, nullptr, 0,
+                                 ZK_TUNE("ZKMI_LH_MERGE", 2) == 1 ? 0 : MSM_RUN_ADD_AT_REDUCE));
   G1XYZZ res;
   ZK_HIP(ctx, ctx->g1.finish_host(&res, 1));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -28,7 +28,8 @@ struct zkmi_ctx {
   // How the H MSM of the proof (group) in ring slot `par` runs: decided ONCE by prove_enqueue_z, consumed by prove_enqueue_h
   // and prove_finish (groth16.hip).
   //   H_OWN    its own sort, bucket set and reduction, queued by the second half
-  //   H_INTO_L as H_OWN, but accumulated INTO the L MSM's buckets: L + H leave one reduction (slot of H), L has no result
+  //   H_INTO_L as H_OWN, but L + H share one reduction (slot of H; L has no result of its own): H's segment sums add L's bucket
+  //            array to its own (A/B library, ZKMI_LH_MERGE=1: H's kernels accumulate INTO L's buckets)
   //   H_SORTED one small proof: sorted by the first half behind the transforms, accumulated by the second half
   //   H_FUSED  one small proof: sorted and accumulated by the first half, in one launch with A, B1 and L
   enum HMode { H_OWN = 0, H_INTO_L = 1, H_SORTED = 2, H_FUSED = 3 };

@@ -852,23 +852,22 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     return ZKMI_OK;
   }
   // L and H only ever appear added together (C = s A + r B1 - rs delta + L + H): when the sorts of z and of h plan the same
-  // bucket set, the L accumulation stops after its redo pass and the H accumulation of the second half continues in L's
-  // bucket array -- one segment-sum / tree-sum pair and one host combine instead of two (0.14 of 8.1 x 10^9 instructions of
-  // a 2^20 proof, which is bound by the instruction issue rate: DESIGN.md 4.10).  A/B library: ZKMI_LH_MERGE=0 keeps
-  // separate bucket sets (and so do the retired accumulation kernels, which have no accumulate-into form).
-  const bool lh_merge_on = ZK_TUNE("ZKMI_LH_MERGE", 1) != 0 && (ZK_TUNE("ZKMI_ACCUM", 3) == 2 || ZK_TUNE("ZKMI_ACCUM", 3) == 3);
+  // bucket set, the L MSM stops after its redo pass and the H MSM's segment sums add L's bucket array to its own -- three
+  // additions per bucket for the pair instead of four, one tree sum and one host combine instead of two (0.085 of 8.1 x 10^9
+  // instructions of a 2^20 proof, which is bound by the instruction issue rate: DESIGN.md 4.1, 4.10).  The two
+  // accumulations know nothing of each other, so one proof, the last group of a batch and groups of small proofs merge
+  // like a pipelined 2^20 proof does.  A/B library, ZKMI_LH_MERGE: 0 = separate reductions; 1 = round 4's first form, the H
+  // accumulation continuing INSIDE L's bucket array (k_accum_g1_nc<.., INTO>: its main stream has to wait for L's
+  // heavy-bucket and redo kernels, so only one-proof groups that another group's first half follows take it).
+  const int lh_mode = ZK_TUNE("ZKMI_LH_MERGE", 2);
   const uint32_t N = 1u << pk->log_n;
-  // Only where another group's first half separates the two halves: the H accumulation must wait for L's heavy-bucket
-  // and redo kernels, which sit on the reduction stream and are not placed while accumulation waves fill the SIMDs
-  // (section 4.10).  Inside a batch they have long run by the time H is due; with H directly behind L -- one proof, the last
-  // group of a batch -- the main stream would stall until the chip has drained: one 2^20 proof 18.9 -> 20.4 ms
-  // (profiles/r04/experiments/lh_merge_single_proof_latency_ab.txt).
-  // And only for one-proof groups (N >= 2^20): in a group of small proofs the relation's bit variables fill real heavy
-  // buckets, the L query's cooperative kernel takes milliseconds, and the H accumulation would wait for it instead of
-  // running beside it (2^14: 2 355 / 2 293 proofs/s apart, 2 220 / 2 200 merged: lh_merge_small_domain_ab.txt).
-  // (A/B library: ZKMI_LH_MERGE_GROUPS=1 merges in groups as well)
-  const bool lh_merge = lh_merge_on && sh && followed && (G == 1 || ZK_TUNE("ZKMI_LH_MERGE_GROUPS", 0) == 1) &&
-                        same_bucket_set(sz.plan, G > 1 ? msm_make_plan_shared_batch(N, G) : msm_make_plan_shared(N));
+  const bool same_set = sh && same_bucket_set(sz.plan, G > 1 ? msm_make_plan_shared_batch(N, G) : msm_make_plan_shared(N));
+  const bool nocall_g1 = ZK_TUNE("ZKMI_ACCUM", 3) == 2 || ZK_TUNE("ZKMI_ACCUM", 3) == 3;
+  // Not for ONE proof by itself (zkmi_groth16_prove[_dev]): there the merged reduction is the tail of the proof -- three
+  // additions per bucket instead of two after the last accumulation, where L's own reduction used to run beside the H
+  // accumulation -- and its latency went from 18.9 to 20.1 ms at 2^20 for nothing (lh_merge_modes_ab.txt).
+  const bool lh_merge = same_set && ((lh_mode == 2 && !solo) ||
+                                     (lh_mode == 1 && nocall_g1 && followed && (G == 1 || ZK_TUNE("ZKMI_LH_MERGE_GROUPS", 0) == 1)));
   ctx->h_mode[par] = lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
@@ -919,9 +918,11 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   const bool into_l = mode == zkmi_ctx::H_INTO_L;
   if (into_l && !same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 2]))
     return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sorts of z and h planned different bucket sets");
-  // (into_l: the same reduction stream as the L accumulation's heavy-bucket and redo kernels)
+  // (into_l: L's bucket array joins this MSM's segment sums -- or, A/B library with ZKMI_LH_MERGE=1, this MSM's kernels add
+  // into L's array; the same reduction stream as the L accumulation's heavy-bucket and redo kernels)
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, aux_split ? ctx->stream_aux2 : ctx->stream_aux, t,
-                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth, into_l ? 4 * par + 2 : -1));
+                                 PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth, into_l ? 4 * par + 2 : -1,
+                                 into_l && ZK_TUNE("ZKMI_LH_MERGE", 2) == 2 ? MSM_RUN_ADD_AT_REDUCE : 0));
   return ZKMI_OK;
 }
 

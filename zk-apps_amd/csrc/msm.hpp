@@ -127,7 +127,7 @@ template <> struct HostFieldOf<Fq28> { using type = Fq; };
 template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
 template <> struct HostFieldOf<BnFq28> { using type = BnFq; };
 
-enum { MSM_RUN_NO_REDUCE = 1 };  // MsmEngine::run_device flags
+enum { MSM_RUN_NO_REDUCE = 1, MSM_RUN_ADD_AT_REDUCE = 2 };  // MsmEngine::run_device flags (msm_impl.hpp run_device_multi)
 
 template <class F>
 struct MsmEngine {

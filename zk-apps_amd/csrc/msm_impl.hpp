@@ -695,10 +695,14 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
 }
 
 // thread t handles buckets [t*SEG, (t+1)*SEG) of one window (global segment id)
+// buckets2 (optional): the bucket array of a SECOND MSM over the same bucket set whose result is only ever added to this
+// one's (the prover's L and H queries: C = ... + L + H).  Its buckets join the running sum here -- three additions per bucket
+// for the pair instead of two each, and one tree sum / host combine instead of two -- and nothing else of the two MSMs
+// knows about the other: both accumulate into their own arrays with the ordinary kernels.
 template <class F>
 __global__ void __launch_bounds__(256)
 k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, XYZZ<F>* __restrict__ segw,
-            uint32_t total_segs, int seg) {
+            uint32_t total_segs, int seg, const XYZZ<F>* __restrict__ buckets2) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_segs) return;
   XYZZ<F> run = XYZZ<F>::infinity();
@@ -706,6 +710,10 @@ k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, X
   for (int i = seg - 1; i >= 0; i--) {
     XYZZ<F> bk = load_vec(buckets + (size_t)t * seg + i);
     run.add(bk);
+    if (buckets2) {
+      bk = load_vec(buckets2 + (size_t)t * seg + i);
+      run.add(bk);
+    }
     acc.add(run);
   }
   store_vec(segsum + t, run);
@@ -1121,24 +1129,31 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
 // launch where the kernel has a fused form (the call-free G1 kernels), otherwise nm launches in line; each MSM keeps
 // its own slot and reduction stream.  All sorts must be complete on `st` (stream order or events) when this is called.
 //
-// Two MSMs whose results are only ever added (the prover's L and H queries: C = ... + L + H) can share ONE bucket set and one
-// reduction: the first runs with MSM_RUN_NO_REDUCE (accumulation, heavy buckets and redo list only; its slot's `done` event
-// is NOT recorded and it has no host result), the second names the first one's slot in bucket_slots[m] -- its kernels then
-// add INTO that bucket array (k_accum_g1_nc<.., INTO>, k_accum_heavy / k_accum_redo with into = 1) behind the first one's
-// redo_done event, and its reduction yields the sum of both.  Both sorts must plan the same bucket set (checked by the
-// caller: the bucket arrays are indexed by bucket id, and the ids mean the same digit values only under equal plans).
+// Two MSMs whose results are only ever added (the prover's L and H queries: C = ... + L + H) can share one reduction: the
+// first runs with MSM_RUN_NO_REDUCE (accumulation, heavy buckets and redo list only; its slot's `done` event is NOT recorded
+// and it has no host result), the second names the first one's slot in bucket_slots[m] and
+//   MSM_RUN_ADD_AT_REDUCE (the product): accumulates into its OWN array with the ordinary kernels; its k_segreduce adds both
+//     arrays behind the first one's redo_done event -- the accumulations stay independent of each other;
+//   without the flag (A/B library): its kernels add INTO the first one's array (k_accum_g1_nc<.., INTO>, k_accum_heavy /
+//     k_accum_redo with into = 1) behind that event.
+// Either way its reduction yields the sum of both.  Both sorts must plan the same bucket set (checked by the caller: the
+// arrays are indexed by bucket id, and the ids mean the same digit values only under equal plans).
 template <class F>
 hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
                                           const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce,
                                           const int* slots, hipStream_t st_heavy, const int* bucket_slots, int flags) {
   if (nm < 1 || nm > MSM_MULTI_MAX) return hipErrorInvalidValue;
   const bool no_reduce = (flags & MSM_RUN_NO_REDUCE) != 0;
+  // MSM_RUN_ADD_AT_REDUCE: bucket_slots[m] names a second SOURCE of this MSM's reduction (k_segreduce adds both arrays)
+  // instead of the array its kernels add INTO
+  const bool add_at_reduce = (flags & MSM_RUN_ADD_AT_REDUCE) != 0;
   bool any_into = false;
   for (int m = 0; m < nm; m++) {
     if (slots[m] < 0 || slots[m] >= nslots) return hipErrorInvalidValue;
     if (bucket_slots && (bucket_slots[m] < 0 || bucket_slots[m] >= nslots)) return hipErrorInvalidValue;
-    any_into = any_into || (bucket_slots && bucket_slots[m] != slots[m]);
+    any_into = any_into || (!add_at_reduce && bucket_slots && bucket_slots[m] != slots[m]);
   }
+  if (add_at_reduce && std::is_same<F, Fq2_28>::value) return hipErrorInvalidValue;  // (the lane-pair segment sums have no second source)
   // the accumulate-into forms exist for the call-free G1 kernels, one MSM per launch
   if (any_into && (nm != 1 || std::is_same<F, Fq2_28>::value)) return hipErrorInvalidValue;
   const MsmPlan& pl = sorts[0]->plan;  // bucket count, windows, segment length: common to all (checked); heavy_thr is per sort
@@ -1177,8 +1192,9 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
 #endif
   if (any_into && !nocall) return hipErrorInvalidValue;
   auto bslot_of = [&](int m) { return bucket_slots ? bucket_slots[m] : slots[m]; };
-  auto into_of = [&](int m) { return bslot_of(m) != slots[m]; };
-  auto bk_of = [&](int m) { return buckets + (size_t)bslot_of(m) * cap_buckets; };
+  auto into_of = [&](int m) { return !add_at_reduce && bslot_of(m) != slots[m]; };
+  auto second_of = [&](int m) { return add_at_reduce && bslot_of(m) != slots[m]; };
+  auto bk_of = [&](int m) { return buckets + (size_t)(into_of(m) ? bslot_of(m) : slots[m]) * cap_buckets; };
   // everything the reductions below would refuse is refused here, before the first launch: an early return between the
   // accumulation and k_accum_redo would leave a redo list behind that the slot's next MSM appends to
   {
@@ -1298,8 +1314,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       uint32_t* const redo = redo_of(m);
       const AccumArgs<F, false> one = {d_bases[m], bk, redo, view_of(m)};
       if (into_of(m)) {
+#ifdef ZKMI_EXPERIMENTS
         hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1, false, true>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
         continue;
+#else
+        return hipErrorInvalidValue;  // (the accumulate-into kernel is an A/B variant: the product adds at the reduction)
+#endif
       }
 #ifdef ZKMI_EXPERIMENTS
       if (accum_mode != 3) {
@@ -1385,7 +1405,13 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
                          tot_segs, seg);
     } else {
-      hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg);
+      const XYZZ<F>* bk2 = nullptr;
+      if (second_of(m)) {
+        // the other MSM's bucket array is complete behind its redo pass (which follows its accumulation and heavy-bucket kernels)
+        if ((e = hipStreamWaitEvent(st_reduce, redo_done[bslot_of(m)], 0)) != hipSuccess) return e;
+        bk2 = buckets + (size_t)bslot_of(m) * cap_buckets;
+      }
+      hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2);
     }
     XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
     XYZZ<HF>* const hp_out = h_partial + (size_t)slot * SLOT_PTS;  // pinned host slot, written by the tree-sum kernels themselves
