@@ -149,7 +149,8 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
     if (hipEventCreateWithFlags(&c->ev_sort[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_z[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_sorth[i], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_sorth[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_rz[i], hipEventDisableTiming) != hipSuccess) {
       delete c;
       return ZKMI_ERR_HIP;
     }
@@ -173,6 +174,7 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
   ctx->sort.release();
   ctx->sort_z2.release();
   ctx->sort_h.release();
+  ctx->sort_rz.release();
   ctx->g1.release();
   ctx->g2.release();
   ctx->g1_bn.release();
@@ -190,12 +192,14 @@ int32_t zkmi_ctx_destroy(zkmi_ctx* ctx) {
     if (ctx->ev_z[i]) (void)hipEventDestroy(ctx->ev_z[i]);
     if (ctx->ev_h[i]) (void)hipEventDestroy(ctx->ev_h[i]);
     if (ctx->ev_sorth[i]) (void)hipEventDestroy(ctx->ev_sorth[i]);
+    if (ctx->ev_rz[i]) (void)hipEventDestroy(ctx->ev_rz[i]);
   }
   if (ctx->stream_front) (void)hipStreamDestroy(ctx->stream_front);
   if (ctx->stream_heavy) (void)hipStreamDestroy(ctx->stream_heavy);
   if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
   if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
   if (ctx->stream_acc3) (void)hipStreamDestroy(ctx->stream_acc3);
+  if (ctx->stream_rz) (void)hipStreamDestroy(ctx->stream_rz);
   delete ctx;
   return ZKMI_OK;
 }

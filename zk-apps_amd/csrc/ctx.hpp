@@ -21,8 +21,10 @@ struct zkmi_ctx {
   hipStream_t stream_heavy = nullptr;  // ZKMI_HEAVY_ON=1 only: heavy-bucket kernels beside the accumulations; created at first use
   hipStream_t stream_sort = nullptr;   // the prover's digit sorts, beside the previous proof's accumulations
   hipStream_t stream_acc3 = nullptr;  // L accumulation of a single small proof (groth16.hip); created at first use
+  hipStream_t stream_rz = nullptr;    // A/B library, ZKMI_RB1_STREAM=1: scaling and digit sort of r z; created at first use
   enum { PROOF_RING = 3 };  // proofs in flight in the batch prover (groth16.hip)
   hipEvent_t ev_sort[PROOF_RING] = {}, ev_z[PROOF_RING] = {}, ev_h[PROOF_RING] = {}, ev_sorth[PROOF_RING] = {};
+  hipEvent_t ev_rz[PROOF_RING] = {};  // the digit sort of r z (B1 folded into the L + H reduction: groth16.hip)
   unsigned z_flip = 0;  // which of sort / sort_z2 the next z sort writes
   uint32_t group_override = 0;  // zkmi_ctx_set_group_size: proofs per group for keys created next (0 = automatic)
   // How the H MSM of the proof (group) in ring slot `par` runs: decided ONCE by prove_enqueue_z, consumed by prove_enqueue_h
@@ -32,7 +34,8 @@ struct zkmi_ctx {
   //            array to its own (A/B library, ZKMI_LH_MERGE=1: H's kernels accumulate INTO L's buckets)
   //   H_SORTED one small proof: sorted by the first half behind the transforms, accumulated by the second half
   //   H_FUSED  one small proof: sorted and accumulated by the first half, in one launch with A, B1 and L
-  enum HMode { H_OWN = 0, H_INTO_L = 1, H_SORTED = 2, H_FUSED = 3 };
+  //   H_INTO_LB as H_INTO_L, and the B1 MSM -- taken over r z instead of z -- is a third source of that reduction (no result of its own)
+  enum HMode { H_OWN = 0, H_INTO_L = 1, H_SORTED = 2, H_FUSED = 3, H_INTO_LB = 4 };
   int h_mode[PROOF_RING] = {H_OWN, H_OWN, H_OWN};
   std::string err;
   zkmi::PhaseTimer prof;
@@ -40,6 +43,7 @@ struct zkmi_ctx {
   zkmi::MsmSort sort;    // every MSM entry point; in the prover: the digit sort of z (A, B1, B2, L MSMs)
   zkmi::MsmSort sort_z2;  // second set of z-sort buffers: proof i+1 is sorted while proof i's accumulations read `sort`
   zkmi::MsmSort sort_h;  // the prover's digit sort of the h coefficients (own buffers: see prove_enqueue_h)
+  zkmi::MsmSort sort_rz;  // digit sort of r z: B1 of a one-proof group, folded into the L + H reduction (reserved by such a key's setup)
   zkmi::MsmEngine<zkmi::Fq28> g1;
   zkmi::MsmEngine<zkmi::Fq2_28> g2;
   zkmi::MsmEngine<zkmi::BnFq28> g1_bn;  // BN254 G1 (bn254.hip)
@@ -62,7 +66,7 @@ struct zkmi_ctx {
   std::vector<hipStream_t> all_streams() const {
     std::vector<hipStream_t> v;
     for (hipStream_t s : {stream, stream_aux, stream_aux2, stream_aux3, stream_g2, stream_front, stream_copy, stream_heavy,
-                          stream_sort, stream_acc3})
+                          stream_sort, stream_acc3, stream_rz})
       if (s) v.push_back(s);
     return v;
   }

@@ -163,6 +163,28 @@ k_gather_z(ZPtrSet src, uint4* __restrict__ dst, uint32_t vec16) {  // vec16 = 1
   dst[(size_t)blockIdx.y * vec16 + i] = src.p[blockIdx.y][i];
 }
 
+// out_i = r * z_i mod the scalar modulus, canonical words in and out: the scalars of the B1 MSM when it is folded into the
+// reduction C's other summands share (r * MSM(b1, z) = MSM(b1, r z)).  blockIdx.y = proof of the group: its own r, its
+// vector `stride` words further on.
+struct RSet {
+  Fr28 r[64];
+};
+__global__ void __launch_bounds__(64)
+k_scale_canonical(const uint32_t* __restrict__ in, RSet rs, uint32_t* __restrict__ out, uint32_t n, uint64_t stride) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const size_t at = (size_t)blockIdx.y * stride + (size_t)i * 8;
+  const uint4* q = reinterpret_cast<const uint4*>(in + at);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const Fr28 v = Fr28::from_canonical(w) * rs.r[blockIdx.y];
+  uint32_t o[8];
+  v.to_canonical(o);
+  uint4* d = reinterpret_cast<uint4*>(out + at);
+  d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // out[p] = in[rev(p)]: bases of the H MSM follow the bit-reversed coefficient order
 template <class A>
 __global__ void __launch_bounds__(256)
@@ -248,6 +270,7 @@ struct zkmi_pk {
   // where the assignment(s) of the proof (group) in flight in ring slot `par` actually lie: d_z[par], or -- one
   // device-resident assignment -- the caller's own buffer (no copy at all; it stays valid for the duration of the call)
   mutable const Fr* z_cur[zkmi_ctx::PROOF_RING] = {};
+  uint32_t* d_rz[zkmi_ctx::PROOF_RING] = {};  // r * z in canonical words, laid out like d_z: the scalars of the B1 MSM (prove_enqueue_z)
   uint32_t* d_h[zkmi_ctx::PROOF_RING] = {};
   Fr28 *d_zm = nullptr, *d_a = nullptr;  // limb form (field28.hpp), front stream only; d_a holds a, b, c of a group back to back
   // per proof in flight, in pinned host memory: bit 0 set by k_check_sat, bit 1 by k_check_canonical (system-scope atomics);
@@ -267,6 +290,8 @@ struct zkmi_pk {
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (h_unsat) (void)hipHostFree(h_unsat);
+    for (uint32_t* p : d_rz)
+      if (p) (void)hipFree(p);
   }
 };
 
@@ -378,6 +403,17 @@ static hipError_t pk_convert_queries(zkmi_pk* pk) {
   // and the host no longer walks a 255-doubling Horner chain.  (A/B library: ZKMI_MSM_SHARED=0 keeps the windowed schedule.)
   pk->shared = ZK_TUNE("ZKMI_MSM_SHARED", 1) != 0;
   if (!pk->shared) pk->gmax = 1;  // groups need the digit tables (their sort emits table indices)
+  // B1's MSM is taken over r * z (prove_enqueue_z, "r B1 fold"): r * z per ring slot + a digit sort of its own
+  // (A/B library: ZKMI_RB1_FOLD=0 none, 1 = one-proof groups only)
+  const int fold = ZK_TUNE("ZKMI_RB1_FOLD", 2);
+  if (pk->shared && (fold == 2 || (fold == 1 && pk->gmax == 1))) {
+    zkmi_ctx* ctx = pk->ctx;
+    const uint64_t cap = N > pk->n_vars ? N : pk->n_vars;
+    for (int i = 0; i < zkmi_ctx::PROOF_RING; i++)
+      if ((e = hipMalloc(&pk->d_rz[i], 32ull * pk->n_vars * pk->gmax)) != hipSuccess) return e;
+    if ((e = ctx->sort_rz.reserve(cap, true)) != hipSuccess) return e;
+    if (pk->gmax > 1 && (e = ctx->sort_rz.reserve_batch(cap, pk->gmax)) != hipSuccess) return e;
+  }
   if (pk->shared) {
     const uint64_t nz = pk->n_vars - 1;
     const MsmPlan pz = msm_make_plan_shared(nz), ph = msm_make_plan_shared(N);
@@ -766,7 +802,7 @@ int32_t zkmi_groth16_witness_map(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t
 // followed = the first half of ANOTHER group will be queued between this group's two halves (every group of a batch but
 // the last): only then do L and H share a bucket set (see below)
 static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* const* src, bool host, uint32_t G, int par, bool solo = false,
-                               bool followed = false) {
+                               bool followed = false, const uint8_t* r_bytes = nullptr) {
   const uint32_t nv = pk->n_vars;
   hipStream_t st = ctx->stream;
   // only the H MSM depends on the NTTs: the witness map runs on the front stream beside the MSMs over z
@@ -868,14 +904,48 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // accumulation -- and its latency went from 18.9 to 20.1 ms at 2^20 for nothing (lh_merge_modes_ab.txt).
   const bool lh_merge = same_set && ((lh_mode == 2 && !solo) ||
                                      (lh_mode == 1 && nocall_g1 && followed && (G == 1 || ZK_TUNE("ZKMI_LH_MERGE_GROUPS", 0) == 1)));
-  ctx->h_mode[par] = lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
+  // The r B1 fold: B1 only enters the proof as r * B1 inside C, and r * MSM(b1, z) = MSM(b1, r z).  With a digit sort of
+  // r z of its own (copy stream, beside the A and L accumulations) the B1 MSM becomes a third source of the L + H reduction:
+  // four additions per bucket for the three instead of six, one tree sum and one host combine instead of three.  What it
+  // costs: r z has full-width digits whatever z looked like (a witness of bits and small values sorts into the first
+  // window only; r times it fills all 13), so B1 costs what an MSM over random scalars costs -- the price of one of five
+  // MSMs at most, and nothing for a witness of hashes like the Shielder relations' (+2-3 % proofs/s at 2^20 and in the
+  // groups of 2^14..2^18: profiles/r04/experiments/rb1_fold_ab.txt).  A/B library: ZKMI_RB1_FOLD=0 off, 1 one-proof groups only.
+  const bool fold_b1 = lh_merge && lh_mode == 2 && r_bytes && pk->d_rz[par] != nullptr;
+  ctx->h_mode[par] = fold_b1 ? zkmi_ctx::H_INTO_LB : lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
+  if (fold_b1) {
+    RSet rs;
+    for (uint32_t g = 0; g < G; g++) {
+      uint32_t rw[8];
+      memcpy(rw, r_bytes + 32ull * g, 32);
+      rs.r[g] = Fr28::from_canonical(rw);
+    }
+    // on the copy stream, in order behind the upload / ev_z of this proof (A/B library, ZKMI_RB1_STREAM=1: a stream of its own)
+    const bool own = ZK_TUNE("ZKMI_RB1_STREAM", 0) == 1;
+    if (own) {
+      ZK_HIP(ctx, ctx->lazy_stream(&ctx->stream_rz, false));
+      ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_rz, ctx->ev_z[par], 0));
+    }
+    const hipStream_t sc = own ? ctx->stream_rz : ctx->stream_copy;
+    hipLaunchKernelGGL(k_scale_canonical, dim3((nv - 1 + 63) / 64, G), dim3(64), 0, sc, zs, rs, pk->d_rz[par], nv - 1, 8ull * nv);
+    if (G > 1)
+      ZK_HIP(ctx, ctx->sort_rz.run_shared_batch(pk->d_rz[par], nv - 1, 8ull * nv, G, sc, t));
+    else
+      ZK_HIP(ctx, ctx->sort_rz.run_shared(pk->d_rz[par], nv - 1, sc, t));
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_rz[par], sc));
+  }
   ZK_HIP(ctx, ctx->g2.run_device(sz, sh ? pk->b2_tab : pk->b2_28 + 1, ctx->stream_g2, rc2, t,
                                  PH_MSM_ACCUM_G2, PH_MSM_REDUCE_G2, g2s, sth));
   ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->a_tab : pk->a28 + 1, st, ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 0, sth));
   // reductions: A and B1 on one stream, L (+ H) on the second, B2 on the third (without the merge: A, L | B1, H | B2)
-  ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, sb1, lh_merge ? ra : rb, t, PH_MSM_ACCUM_G1,
-                                 PH_MSM_REDUCE_G1, s0 + 1, sth));
+  if (fold_b1) {
+    ZK_HIP(ctx, hipStreamWaitEvent(sb1, ctx->ev_rz[par], 0));
+    ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_rz, pk->b1_tab, sb1, rb, t, PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, s0 + 1, sth, -1, MSM_RUN_NO_REDUCE));
+  } else {
+    ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->b1_tab : pk->b1_28 + 1, sb1, lh_merge ? ra : rb, t, PH_MSM_ACCUM_G1,
+                                   PH_MSM_REDUCE_G1, s0 + 1, sth));
+  }
   ZK_HIP(ctx, ctx->g1.run_device(sz, sh ? pk->l_tab : pk->l28 + 1, sl, lh_merge ? rb : ra, t, PH_MSM_ACCUM_G1,
                                  PH_MSM_REDUCE_G1, s0 + 2, sth, -1, lh_merge ? MSM_RUN_NO_REDUCE : 0));
   return ZKMI_OK;
@@ -915,14 +985,15 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
     ZK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_sorth[par], 0));
   }
   const bool aux_split = prover_aux_split();
-  const bool into_l = mode == zkmi_ctx::H_INTO_L;
+  const bool into_l = mode == zkmi_ctx::H_INTO_L || mode == zkmi_ctx::H_INTO_LB;
   if (into_l && !same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 2]))
     return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sorts of z and h planned different bucket sets");
   // (into_l: L's bucket array joins this MSM's segment sums -- or, A/B library with ZKMI_LH_MERGE=1, this MSM's kernels add
   // into L's array; the same reduction stream as the L accumulation's heavy-bucket and redo kernels)
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, aux_split ? ctx->stream_aux2 : ctx->stream_aux, t,
                                  PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1, 4 * par + 3, sth, into_l ? 4 * par + 2 : -1,
-                                 into_l && ZK_TUNE("ZKMI_LH_MERGE", 2) == 2 ? MSM_RUN_ADD_AT_REDUCE : 0));
+                                 into_l && ZK_TUNE("ZKMI_LH_MERGE", 2) == 2 ? MSM_RUN_ADD_AT_REDUCE : 0,
+                                 mode == zkmi_ctx::H_INTO_LB ? 4 * par + 1 : -1));
   return ZKMI_OK;
 }
 
@@ -1004,7 +1075,8 @@ static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ&
 static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_bytes, const uint8_t* s_bytes, uint32_t G,
                             int par, uint8_t* out_proofs) {
   const int s0 = 4 * par, g2s = par;
-  const bool merged = ctx->h_mode[par] == zkmi_ctx::H_INTO_L;  // acc_h arrives as L + H
+  const bool merged_b1 = ctx->h_mode[par] == zkmi_ctx::H_INTO_LB;             // acc_h arrives as r * B1 + L + H
+  const bool merged = ctx->h_mode[par] == zkmi_ctx::H_INTO_L || merged_b1;  // acc_h arrives as L + H
   std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
   std::vector<G2XYZZ> acc_b2(G);
   if (G == 1) {
@@ -1017,7 +1089,8 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     AssemblyHead head;
     const AssemblyPre pre = assemble_pre(pk, r_bytes, s_bytes);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
-    ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
+    if (merged_b1) acc_b1[0] = G1XYZZ::infinity();  // r * MSM(b1, z) comes in through the H slot: assemble_g1 multiplies the fixed part of B1 only
+    else ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
     mark(0);
     assemble_g1(pk, pre, acc_a[0], acc_b1[0], head);
     mark(1);
@@ -1041,7 +1114,10 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     return ZKMI_OK;
   } else {
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
-    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
+    if (merged_b1)
+      for (auto& p : acc_b1) p = G1XYZZ::infinity();
+    else
+      ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
     if (merged)
       for (auto& p : acc_l) p = G1XYZZ::infinity();
     else
@@ -1090,7 +1166,7 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   const bool lat_debug = debug_level() >= 2;
   const auto t0 = std::chrono::steady_clock::now();
   auto us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
-  int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0, true);
+  int32_t rc = prove_enqueue_z(ctx, pk, src, z != nullptr, 1, 0, true, false, r_bytes);
   const long t_z = us();
   if (rc == ZKMI_OK) rc = prove_enqueue_h(ctx, pk, 1, 0, true);
   const long t_h = us();
@@ -1223,7 +1299,9 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
     return prove_finish(ctx, pk, r_bytes + 32ull * first(g), s_bytes + 32ull * first(g), count(g), (int)(g % RING),
                         out_proofs + 192ull * first(g));
   };
-  auto enqueue_z = [&](uint32_t g) { return prove_enqueue_z(ctx, pk, d_z + first(g), host, count(g), (int)(g % RING), false, g + 1 < n_groups); };
+  auto enqueue_z = [&](uint32_t g) {
+    return prove_enqueue_z(ctx, pk, d_z + first(g), host, count(g), (int)(g % RING), false, g + 1 < n_groups, r_bytes + 32ull * first(g));
+  };
   int32_t rc = enqueue_z(0);
   if (rc != ZKMI_OK) return bail(rc);
   for (uint32_t g = 0; g < n_groups; g++) {

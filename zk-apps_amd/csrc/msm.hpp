@@ -178,12 +178,12 @@ struct MsmEngine {
   // and reduce the sum of both MSMs; see run_device_multi in msm_impl.hpp
   hipError_t run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st, hipStream_t st_reduce,
                         PhaseTimer* prof, int ph_accum, int ph_reduce, int slot = 0, hipStream_t st_heavy = nullptr,
-                        int bucket_slot = -1, int flags = 0);
+                        int bucket_slot = -1, int flags = 0, int bucket_slot3 = -1);
   // nm <= 4 MSMs of one plan shape (sorts[m] may repeat: several tables over one sort), each with its own slot and
   // reduction stream; the G1 call-free kernels accumulate them in one launch (one small proof: A, B1, L and H side by side)
   hipError_t run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
                               const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce, const int* slots,
-                              hipStream_t st_heavy = nullptr, const int* bucket_slots = nullptr, int flags = 0);
+                              hipStream_t st_heavy = nullptr, const int* bucket_slots = nullptr, int flags = 0, int third_slot = -1);
   // host part: wait for the slot's event and combine (O(255) doublings on the CPU)
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points

@@ -702,7 +702,7 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
 template <class F>
 __global__ void __launch_bounds__(256)
 k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, XYZZ<F>* __restrict__ segw,
-            uint32_t total_segs, int seg, const XYZZ<F>* __restrict__ buckets2) {
+            uint32_t total_segs, int seg, const XYZZ<F>* __restrict__ buckets2, const XYZZ<F>* __restrict__ buckets3) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_segs) return;
   XYZZ<F> run = XYZZ<F>::infinity();
@@ -712,6 +712,10 @@ k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, X
     run.add(bk);
     if (buckets2) {
       bk = load_vec(buckets2 + (size_t)t * seg + i);
+      run.add(bk);
+    }
+    if (buckets3) {
+      bk = load_vec(buckets3 + (size_t)t * seg + i);
       run.add(bk);
     }
     acc.add(run);
@@ -1119,10 +1123,10 @@ static inline int msm_seg_bits(const MsmPlan& pl) {
 template <class F>
 hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_bases, hipStream_t st,
                                     hipStream_t st_reduce, PhaseTimer* prof, int ph_accum, int ph_reduce, int slot,
-                                    hipStream_t st_heavy, int bucket_slot, int flags) {
+                                    hipStream_t st_heavy, int bucket_slot, int flags, int bucket_slot3) {
   const MsmSort* sp = &sort;
   return run_device_multi(&sp, &d_bases, 1, st, &st_reduce, prof, ph_accum, ph_reduce, &slot, st_heavy,
-                          bucket_slot >= 0 ? &bucket_slot : nullptr, flags);
+                          bucket_slot >= 0 ? &bucket_slot : nullptr, flags, bucket_slot3);
 }
 
 // nm MSMs of the same plan shape (sorts[m] may repeat: different tables over one digit sort): one fused accumulation
@@ -1141,8 +1145,10 @@ hipError_t MsmEngine<F>::run_device(const MsmSort& sort, const Affine<F>* d_base
 template <class F>
 hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Affine<F>* const* d_bases, int nm, hipStream_t st,
                                           const hipStream_t* st_reduces, PhaseTimer* prof, int ph_accum, int ph_reduce,
-                                          const int* slots, hipStream_t st_heavy, const int* bucket_slots, int flags) {
+                                          const int* slots, hipStream_t st_heavy, const int* bucket_slots, int flags, int third_slot) {
   if (nm < 1 || nm > MSM_MULTI_MAX) return hipErrorInvalidValue;
+  // third_slot >= 0 (with MSM_RUN_ADD_AT_REDUCE, one MSM): a THIRD bucket array joins the segment sums
+  if (third_slot >= nslots || (third_slot >= 0 && (nm != 1 || !(flags & MSM_RUN_ADD_AT_REDUCE) || !bucket_slots))) return hipErrorInvalidValue;
   const bool no_reduce = (flags & MSM_RUN_NO_REDUCE) != 0;
   // MSM_RUN_ADD_AT_REDUCE: bucket_slots[m] names a second SOURCE of this MSM's reduction (k_segreduce adds both arrays)
   // instead of the array its kernels add INTO
@@ -1405,13 +1411,17 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
                          tot_segs, seg);
     } else {
-      const XYZZ<F>* bk2 = nullptr;
+      const XYZZ<F>*bk2 = nullptr, *bk3 = nullptr;
       if (second_of(m)) {
         // the other MSM's bucket array is complete behind its redo pass (which follows its accumulation and heavy-bucket kernels)
         if ((e = hipStreamWaitEvent(st_reduce, redo_done[bslot_of(m)], 0)) != hipSuccess) return e;
         bk2 = buckets + (size_t)bslot_of(m) * cap_buckets;
+        if (third_slot >= 0) {
+          if ((e = hipStreamWaitEvent(st_reduce, redo_done[third_slot], 0)) != hipSuccess) return e;
+          bk3 = buckets + (size_t)third_slot * cap_buckets;
+        }
       }
-      hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2);
+      hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
     }
     XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
     XYZZ<HF>* const hp_out = h_partial + (size_t)slot * SLOT_PTS;  // pinned host slot, written by the tree-sum kernels themselves
