@@ -1606,3 +1606,58 @@ def test_grouped_prover_partial_groups(ctx, zk, lg, count):
     assert ctx.groth16_prove_batch_host(pk, [hw[j].data_ptr() for j in idx], rs, ss) == proofs
     pk.free()
     r1.free()
+
+
+def test_groth16_witness_of_bits_and_edge_blinding_factors_vs_cpp_oracle(ctx, zk):
+    """The B1 MSM is taken over r z and enters the proof through the reduction L and H share (groth16.hip, "r B1 fold"):
+    proof bytes against the C++ oracle's prover for r in {0, 1, r_mod - 1, random} on a relation of bit constraints --
+    every 1 of the witness becomes the SAME full-width scalar r (one heavy bucket per digit position), every 0 stays 0,
+    r = 0 empties the B1 MSM altogether -- through the single-proof call (no fold), the grouped batch and the batch of
+    one-proof groups (what a 2^20 key runs)."""
+    import random
+
+    import torch
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    one = (1).to_bytes(32, "little")
+    nbits, n_pub = 3000, 2
+    n_vars = n_pub + nbits + 40  # 1, the public count of ones, the bits, a tail of full-width values
+    rnd = random.Random(77)
+    bits = [1 if rnd.random() < 0.6 else 0 for _ in range(nbits)]
+    tail = [rnd.randrange(R) for _ in range(40)]
+    zv = [1, sum(bits) % R] + bits + tail
+    # rows: b_i * b_i = b_i;  (sum b_i) * 1 = z[1];  t_k * 1 = t_k
+    a_rp, a_c, b_rp, b_c, c_rp, c_c = [0], [], [0], [], [0], []
+    for i in range(nbits):
+        a_c.append(n_pub + i), b_c.append(n_pub + i), c_c.append(n_pub + i)
+        a_rp.append(len(a_c)), b_rp.append(len(b_c)), c_rp.append(len(c_c))
+    a_c += [n_pub + i for i in range(nbits)]
+    b_c.append(0), c_c.append(1)
+    a_rp.append(len(a_c)), b_rp.append(len(b_c)), c_rp.append(len(c_c))
+    for k in range(40):
+        a_c.append(n_pub + nbits + k), b_c.append(0), c_c.append(n_pub + nbits + k)
+        a_rp.append(len(a_c)), b_rp.append(len(b_c)), c_rp.append(len(c_c))
+    mats = [(rp, cl, one * len(cl)) for rp, cl in ((a_rp, a_c), (b_rp, b_c), (c_rp, c_c))]
+    wit = frs(zv)
+    rng = ec.SplitMix64(0xB175)
+    toxic = frs([rng.fr() for _ in range(5)])
+    blind = [0, 1, R - 1, rng.fr(), 0, rng.fr(), 1]
+    rs = [ec.fr_to_bytes(v) for v in blind]
+    ss = [ec.fr_to_bytes(v) for v in (rng.fr(), 0, rng.fr(), R - 1, 0, 1, rng.fr())]
+    r1 = zk.r1cs_create(n_vars, n_pub, mats)
+    assert r1.is_satisfied(wit)
+    ovk, okey = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, toxic)
+    want = [ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, okey, wit, r_, s_) for r_, s_ in zip(rs, ss)]
+    d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    for group in (0, 1):
+        ctx.set_group_size(group)
+        pk, vk = ctx.groth16_setup(r1, toxic)
+        ctx.set_group_size(0)
+        assert vk == ovk
+        assert [ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) for r_, s_ in zip(rs, ss)] == want
+        assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * len(rs), rs, ss) == want
+        pk.free()
+    assert all(zk.groth16_verify(ovk, wit[32: 32 * n_pub], p) for p in want)
+    r1.free()
