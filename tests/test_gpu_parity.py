@@ -1613,7 +1613,7 @@ def test_groth16_witness_of_bits_and_edge_blinding_factors_vs_cpp_oracle(ctx, zk
     proof bytes against the C++ oracle's prover for r in {0, 1, r_mod - 1, random} on a relation of bit constraints --
     every 1 of the witness becomes the SAME full-width scalar r (one heavy bucket per digit position), every 0 stays 0,
     r = 0 empties the B1 MSM altogether -- through the single-proof call (no fold), the grouped batch and the batch of
-    one-proof groups (what a 2^20 key runs)."""
+    one-proof groups (what a 2^20 key runs).  Such a witness is also the one the prover stops folding for."""
     import random
 
     import torch
@@ -1656,8 +1656,11 @@ def test_groth16_witness_of_bits_and_edge_blinding_factors_vs_cpp_oracle(ctx, zk
         pk, vk = ctx.groth16_setup(r1, toxic)
         ctx.set_group_size(0)
         assert vk == ovk
-        assert [ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) for r_, s_ in zip(rs, ss)] == want
+        # the batch FIRST: a fresh key folds until the first finished proof has reported how few of its digits this witness
+        # fills (groth16.hip fold_dense) -- the proofs in flight by then are the ones with r = 0, 1, r_mod - 1
         assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * len(rs), rs, ss) == want
+        assert [ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) for r_, s_ in zip(rs, ss)] == want
+        assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * len(rs), rs, ss) == want  # and without the fold
         pk.free()
     assert all(zk.groth16_verify(ovk, wit[32: 32 * n_pub], p) for p in want)
     r1.free()

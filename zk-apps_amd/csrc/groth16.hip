@@ -185,6 +185,17 @@ k_scale_canonical(const uint32_t* __restrict__ in, RSet rs, uint32_t* __restrict
   d[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// The digit sort of z knows how many NON-ZERO digits the assignment has (entries per partition); their sum goes to a pinned
+// host word, from which the prover decides whether the next proofs of this key fold B1 (prove_enqueue_z): r z has all its
+// digits whatever z looked like.
+__global__ void __launch_bounds__(64)
+k_entries_to_host(const uint32_t* __restrict__ part_total, uint32_t np, uint32_t* __restrict__ host_word) {
+  uint32_t s = 0;
+  for (uint32_t i = threadIdx.x; i < np; i += 64) s += part_total[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x == 0) __hip_atomic_store(host_word, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // out[p] = in[rev(p)]: bases of the H MSM follow the bit-reversed coefficient order
 template <class A>
 __global__ void __launch_bounds__(256)
@@ -276,6 +287,13 @@ struct zkmi_pk {
   // per proof in flight, in pinned host memory: bit 0 set by k_check_sat, bit 1 by k_check_canonical (system-scope atomics);
   // valid once the proof's H MSM has landed (it waits for the front stream), cleared by the host when it has read it
   uint32_t* h_unsat = nullptr;
+  // non-zero digits of the assignment(s) of the proof (group) in ring slot i, written by k_entries_to_host behind the digit
+  // sort of z (same pinned allocation, words RING..2 RING); and what prove_finish made of the last one it read: B1 is only
+  // folded into the L + H reduction (its MSM taken over r z, all of whose digits are non-zero) while the assignments of this
+  // key fill at least 9 in 10 of their digits -- a witness of bits is cheaper through the sort of z itself (106.8 against 68.4
+  // proofs/s for 2^20 bit constraints: profiles/r04/experiments/rb1_fold_ab.txt).  The proof bytes do not depend on it.
+  uint32_t* h_zent = nullptr;
+  mutable bool fold_dense = true;
   ~zkmi_pk() {
     if (device >= 0) (void)hipSetDevice(device);  // the key's buffers live on its context's device (the ctx may be gone)
     (void)hipDeviceSynchronize();  // nothing queued by an earlier call may still read the key or write its pinned flags
@@ -356,8 +374,9 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   // one batched launch per pass (3 x G vectors)
   // (a group of g <= G proofs uses the first 3 g N elements: a[0..g), b[0..g), c[0..g))
   if ((e = hipMalloc(&pk->d_a, sizeof(Fr28) * 3 * N * G)) != hipSuccess) return e;
-  if ((e = hipHostMalloc(&pk->h_unsat, zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocCoherent)) != hipSuccess) return e;
-  for (int i = 0; i < zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
+  if ((e = hipHostMalloc(&pk->h_unsat, 2 * zkmi_ctx::PROOF_RING * sizeof(uint32_t), hipHostMallocCoherent)) != hipSuccess) return e;
+  for (int i = 0; i < 2 * zkmi_ctx::PROOF_RING; i++) pk->h_unsat[i] = 0;
+  pk->h_zent = pk->h_unsat + zkmi_ctx::PROOF_RING;
   const uint64_t cap = N > r->n_vars ? N : r->n_vars;
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
   if (prover_sort_side() && (e = ctx->sort_z2.reserve(cap, true)) != hipSuccess) return e;
@@ -839,6 +858,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     ZK_HIP(ctx, sz.run_shared(zs, nv - 1, ss, t));
   else
     ZK_HIP(ctx, sz.run(zs, nv - 1, ss, t));
+  if (sh && pk->d_rz[par]) hipLaunchKernelGGL(k_entries_to_host, dim3(1), dim3(64), 0, ss, sz.part_total, (uint32_t)sz.plan.nwin, pk->h_zent + par);
   // the G2 accumulation runs on its own stream beside the three G1 ones (same sort, disjoint
   // outputs): the kernels' drain tails overlap instead of adding up
   ZK_HIP(ctx, hipEventRecord(ctx->ev_sort[par], ss));
@@ -911,7 +931,7 @@ static int32_t prove_enqueue_z(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
   // window only; r times it fills all 13), so B1 costs what an MSM over random scalars costs -- the price of one of five
   // MSMs at most, and nothing for a witness of hashes like the Shielder relations' (+2-3 % proofs/s at 2^20 and in the
   // groups of 2^14..2^18: profiles/r04/experiments/rb1_fold_ab.txt).  A/B library: ZKMI_RB1_FOLD=0 off, 1 one-proof groups only.
-  const bool fold_b1 = lh_merge && lh_mode == 2 && r_bytes && pk->d_rz[par] != nullptr;
+  const bool fold_b1 = lh_merge && lh_mode == 2 && r_bytes && pk->d_rz[par] != nullptr && (pk->fold_dense || ZK_TUNE("ZKMI_RB1_FOLD_ALWAYS", 0) == 1);
   ctx->h_mode[par] = fold_b1 ? zkmi_ctx::H_INTO_LB : lh_merge ? zkmi_ctx::H_INTO_L : zkmi_ctx::H_OWN;
   if (fold_b1) {
     RSet rs;
@@ -986,8 +1006,9 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   }
   const bool aux_split = prover_aux_split();
   const bool into_l = mode == zkmi_ctx::H_INTO_L || mode == zkmi_ctx::H_INTO_LB;
-  if (into_l && !same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 2]))
-    return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sorts of z and h planned different bucket sets");
+  if (into_l && (!same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 2]) ||
+                 (mode == zkmi_ctx::H_INTO_LB && !same_bucket_set(ctx->sort_h.plan, ctx->g1.slot_plan[4 * par + 1]))))
+    return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sorts of z, r z and h planned different bucket sets");
   // (into_l: L's bucket array joins this MSM's segment sums -- or, A/B library with ZKMI_LH_MERGE=1, this MSM's kernels add
   // into L's array; the same reduction stream as the L accumulation's heavy-bucket and redo kernels)
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort_h, sh ? pk->h_tab : pk->h28_rev, st, aux_split ? ctx->stream_aux2 : ctx->stream_aux, t,
@@ -1075,6 +1096,12 @@ static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ&
 static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_bytes, const uint8_t* s_bytes, uint32_t G,
                             int par, uint8_t* out_proofs) {
   const int s0 = 4 * par, g2s = par;
+  // called once the A MSM of this slot is in (its accumulation ran behind the digit sort of z and k_entries_to_host)
+  auto note_density = [&]() {
+    if (!pk->d_rz[par]) return;
+    const uint64_t full = (uint64_t)(pk->n_vars - 1) * G * (uint64_t)ctx->g1.slot_plan[s0].ndigits;
+    pk->fold_dense = 10ull * pk->h_zent[par] >= 9ull * full;
+  };
   const bool merged_b1 = ctx->h_mode[par] == zkmi_ctx::H_INTO_LB;             // acc_h arrives as r * B1 + L + H
   const bool merged = ctx->h_mode[par] == zkmi_ctx::H_INTO_L || merged_b1;  // acc_h arrives as L + H
   std::vector<G1XYZZ> acc_a(G), acc_b1(G), acc_l(G), acc_h(G);
@@ -1089,6 +1116,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     AssemblyHead head;
     const AssemblyPre pre = assemble_pre(pk, r_bytes, s_bytes);
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
+    note_density();
     if (merged_b1) acc_b1[0] = G1XYZZ::infinity();  // r * MSM(b1, z) comes in through the H slot: assemble_g1 multiplies the fixed part of B1 only
     else ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
     mark(0);
@@ -1114,6 +1142,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     return ZKMI_OK;
   } else {
     ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
+    note_density();
     if (merged_b1)
       for (auto& p : acc_b1) p = G1XYZZ::infinity();
     else
