@@ -2,7 +2,8 @@
 """What the r B1 fold costs a witness of BITS: a relation of b_i * b_i = b_i rows, 60 % ones -- the digits of z
 fill one digit position, the digits of r z all thirteen, and every 1 becomes the same scalar r (one heavy bucket per
 position).  Proof rate of a pipelined batch through zkmi_groth16_prove_batch_dev; run once per setting of the A/B library:
-    ZKMI_LIB=zk-apps_amd/libzkmi_exp.so ZKMI_RB1_FOLD=0|2 python scripts/bits_relation_ab.py [log_n = 18] [proofs = 24]"""
+    ZKMI_LIB=zk-apps_amd/libzkmi_exp.so ZKMI_RB1_FOLD=0|2 python scripts/bits_relation_ab.py [log_n = 18] [proofs = 24] [sum]
+("sum" adds one row that sums all the bits: a linear combination of 2^log_n terms.)"""
 import os
 import random
 import sys
@@ -32,6 +33,11 @@ def main():
     a = (rp, cols + [n_pub], one * (nbits + 1))  # rows b_i * b_i = b_i, last row b_0 * 1 = z[1] (the public input)
     b = (rp, cols + [0], one * (nbits + 1))
     c = (rp, cols + [1], one * (nbits + 1))
+    if len(sys.argv) > 3 and sys.argv[3] == "sum":
+        # the public input becomes the NUMBER of ones: its row sums all the bits, (b_0 + b_1 + ...) * 1 = z[1] -- a linear
+        # combination of nbits terms, a row one lane cannot take (k_matvec_long's)
+        zv[1] = sum(bits)
+        a = (rp[:-1] + [2 * nbits], cols + cols, one * (2 * nbits))
     r1 = z.r1cs_create(n_vars, n_pub, [a, b, c])
     wit = b"".join(v.to_bytes(32, "little") for v in zv)
     assert r1.is_satisfied(wit), "relation"

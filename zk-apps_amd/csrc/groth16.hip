@@ -62,6 +62,30 @@ struct MatSet {
 // S lanes per row (adjacent lanes, partial sums added over __shfl_xor): 1 for throughput; 8 for one small proof, whose
 // mat-vec lasts as long as its longest row on one lane (the Poseidon relation has rows of ~100 terms: 0.12 ms at the head of
 // the latency chain, section 4.11)
+// A row with more terms than this is not one lane's work (a linear combination over a whole vector -- a sum of 2^20 bits --
+// would keep one lane busy for a second while the chip waits: the rows of a relation are as long as its author made them).
+// The key lists such rows at setup (normally none, and then nothing is launched); k_matvec leaves them to k_matvec_long:
+// one 256-thread workgroup per (listed row, proof of the group), terms dealt round-robin, partial sums added through LDS.
+constexpr uint32_t MATVEC_LONG_ROW = 1024;
+__global__ void __launch_bounds__(256)
+k_matvec_long(MatSet ms, const uint32_t* __restrict__ rows, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uint32_t n, uint32_t n_vars) {
+  __shared__ Fr28 part[256];
+  const uint32_t m = rows[2 * blockIdx.x], i = rows[2 * blockIdx.x + 1];
+  const uint32_t* __restrict__ col = ms.col[m];
+  const Fr28* __restrict__ val = ms.val[m];
+  z += (size_t)blockIdx.y * n_vars;
+  Fr28 acc = Fr28::zero();
+  const uint32_t b = ms.rowptr[m][i], e = ms.rowptr[m][i + 1];
+  for (uint32_t k = b + threadIdx.x; k < e; k += 256) acc = acc + ld28(val + k) * ld28(z + col[k]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st28(out_base + (size_t)m * gridDim.y * n + (size_t)blockIdx.y * n + i, part[0]);
+}
+
 template <int S>
 __global__ void __launch_bounds__(256)
 k_matvec(MatSet ms, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uint32_t nc, uint32_t n, uint32_t n_pub,
@@ -81,6 +105,7 @@ k_matvec(MatSet ms, const Fr28* __restrict__ z, Fr28* __restrict__ out_base, uin
   Fr28 acc = Fr28::zero();
   if (i < nc) {
     const uint32_t b = rowptr[i], e = rowptr[i + 1];
+    if (e - b > MATVEC_LONG_ROW) return;  // k_matvec_long's (all S lanes of the row see the same bounds)
     for (uint32_t k = b + lane; k < e; k += S) acc = acc + ld28(val + k) * ld28(z + col[k]);
   } else if (is_a && i < nc + n_pub && lane == 0) {
     acc = ld28(z + (i - nc));
@@ -259,6 +284,8 @@ struct zkmi_pk {
   // per query, batched NTT passes); every per-proof buffer below holds gmax vectors back to back
   uint32_t gmax = 1;
   uint32_t* d_rowptr[3] = {nullptr, nullptr, nullptr};
+  uint32_t* d_long_rows = nullptr;  // (matrix, row) of every row with more than MATVEC_LONG_ROW terms (k_matvec_long)
+  uint32_t n_long_rows = 0;
   uint32_t* d_col[3] = {nullptr, nullptr, nullptr};
   Fr28* d_val[3] = {nullptr, nullptr, nullptr};
   G1Affine *a_query = nullptr, *b_g1_query = nullptr, *h_query = nullptr, *l_query = nullptr;  // l padded to n_vars
@@ -302,6 +329,7 @@ struct zkmi_pk {
       if (d_col[m]) (void)hipFree(d_col[m]);
       if (d_val[m]) (void)hipFree(d_val[m]);
     }
+    if (d_long_rows) (void)hipFree(d_long_rows);
     void* ptrs[] = {a_query, b_g1_query, h_query, l_query, b_g2_query, d_zm, d_a, a28, b1_28, h28, h28_rev, l28, b2_28,
                     a_tab, b1_tab, l_tab, h_tab, b2_tab, d_z[0], d_z[1], d_z[2], d_h[0], d_h[1], d_h[2]};
     static_assert(zkmi_ctx::PROOF_RING == 3, "ring size");
@@ -323,6 +351,20 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   pk->tree_height = r->tree_height;
   const uint64_t N = 1ull << r->log_n;
   hipError_t e;
+  {
+    std::vector<uint32_t> longs;
+    for (uint32_t m = 0; m < 3; m++)
+      for (uint32_t i = 0; i + 1 < r->m[m].rowptr.size(); i++)
+        if (r->m[m].rowptr[i + 1] - r->m[m].rowptr[i] > MATVEC_LONG_ROW) {
+          longs.push_back(m);
+          longs.push_back(i);
+        }
+    pk->n_long_rows = (uint32_t)(longs.size() / 2);
+    if (pk->n_long_rows) {
+      if ((e = hipMalloc(&pk->d_long_rows, sizeof(uint32_t) * longs.size())) != hipSuccess) return e;
+      if ((e = hipMemcpy(pk->d_long_rows, longs.data(), sizeof(uint32_t) * longs.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
+  }
   for (int m = 0; m < 3; m++) {
     const auto& c = r->m[m];
     const size_t nnz = c.col.size();
@@ -752,6 +794,7 @@ static int32_t witness_map_dev(zkmi_ctx* ctx, const zkmi_pk* pk, const void* con
     hipLaunchKernelGGL(k_matvec<8>, dim3((8 * N + 63) / 64, 1, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
   else
     hipLaunchKernelGGL(k_matvec<1>, dim3((N + 63) / 64, G, 3), dim3(64), 0, st, ms, pk->d_zm, pk->d_a, pk->nc, N, pk->n_pub, nv);
+  if (pk->n_long_rows) hipLaunchKernelGGL(k_matvec_long, dim3(pk->n_long_rows, G), dim3(256), 0, st, ms, pk->d_long_rows, pk->d_zm, pk->d_a, N, nv);
   Fr28* const d_b = pk->d_a + (size_t)N * G;  // the layout follows the size of THIS group, not the key's maximum
   Fr28* const d_c = pk->d_a + 2 * (size_t)N * G;
   hipLaunchKernelGGL(k_check_sat, dim3((pk->nc + 64) / 64, G), dim3(64), 0, st, pk->d_a, d_b, d_c, pk->d_zm, pk->nc,
