@@ -266,6 +266,13 @@ int32_t zkmi_bn254_ntt_fr_dev(zkmi_ctx* ctx, void* d_data, uint32_t log_n, int32
  * commitment = MSM(srs, coefficients); srs holds at least 2^log_n points [tau^i] G. */
 int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, const zkmi_bn_bases* srs,
                                   uint8_t out_commitment[64]);
+/* KZG opening of one polynomial at one point -- halo2_proofs::arithmetic::eval_polynomial + kate_division and the
+ * commitment to the quotient (poly::kzg::multiopen's inner step; halo2_proofs is a git dependency of the reference,
+ * shielder/Cargo.toml:26, not in the tree): d_coeffs = n coefficients in HBM (32-byte LE canonical, constant term first),
+ * *out_eval = p(zeta), out_proof = commit(q) for q(X) = (p(X) - p(zeta)) / (X - zeta).  srs holds at least n - 1 points
+ * [tau^i] G (a prepared SRS is used through its table).  d_quotient: NULL, or n - 1 x 32 B in HBM that receive q. */
+int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
+                                void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]);
 
 /* ---- the contract's SHA-256 Merkle tree, batched ------------ *
  * compute_hash / combine_merkle_hash = SHA-256(first.bytes || second.bytes)

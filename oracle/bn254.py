@@ -135,3 +135,30 @@ def ntt(a, inverse=False, coset=False):
             ginv = pow(FR_GENERATOR, -1, R)
             a = [v * pow(ginv, i, R) % R for i, v in enumerate(a)]
     return a
+
+
+def eval_polynomial(coeffs, point):
+    """halo2_proofs::arithmetic::eval_polynomial: Horner from the top coefficient down (coefficients: constant term first)."""
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * point + c) % R
+    return acc
+
+
+def kate_division(coeffs, b):
+    """halo2_proofs::arithmetic::kate_division(a, b): the quotient of a(X) by (X - b), len(a) - 1 coefficients; the remainder
+    a(b) is dropped.  Synthetic division from the top: q_{n-2} = a_{n-1}, q_{i-1} = a_i + b q_i."""
+    q = [0] * (len(coeffs) - 1)
+    tmp = 0
+    for i in range(len(coeffs) - 1, 0, -1):
+        tmp = (coeffs[i] + b * tmp) % R
+        q[i - 1] = tmp
+    return q
+
+
+def kzg_open(coeffs, point, srs):
+    """(p(point), commit(q)) for q = kate_division(p, point) against the monomial SRS [tau^i] G: the opening a KZG prover
+    sends for one polynomial at one point (halo2's poly::kzg::multiopen reduces to this per rotation set)."""
+    q = kate_division(coeffs, point)
+    return eval_polynomial(coeffs, point), msm_naive(q, srs[: len(q)])
+

@@ -36,3 +36,9 @@ for it in range(2):
     ctx.prof_reset()
     t = time.time(); ctx.bn254_kzg_commit_dev(x.data_ptr(), lg, b); dt = time.time() - t
     print(f"bn254 kzg commit from 2^{lg} evaluations: wall {dt*1e3:.2f} ms")
+zeta = (0x2B1C5E9F00D1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234 % 21888242871839275222246405745257275088548364400416034343698204186575808495617).to_bytes(32, "little")
+for it in range(3):
+    ctx.prof_reset()
+    t = time.time(); ctx.bn254_kzg_open_dev(raw.data_ptr(), n, zeta, b); dt = time.time() - t
+    print(f"bn254 kzg open of 2^{lg} coefficients (prepared SRS): wall {dt*1e3:.2f} ms, evaluation + quotient scan {ctx.prof_get('misc')[0]:.3f} ms,",
+          {k: round(ctx.prof_get(k)[0], 3) for k in ("msm_sort", "msm_accum_g1", "msm_reduce_g1")})

@@ -271,3 +271,36 @@ def test_poseidon_and_bn254_golden_fixtures_reproduce():
     assert bn.g1_to_bytes(bn.msm_naive(sc, bn.synthetic_bases(64))).hex() == b["msm"]["expected"]
     a = [int.from_bytes(H(b["ntt"]["input"])[i : i + 32], "little") for i in range(0, 32 * 32, 32)]
     assert b"".join(v.to_bytes(32, "little") for v in bn.ntt(a)).hex() == b["ntt"]["forward"]
+
+
+def test_bn254_kzg_opening_oracle_identities():
+    """eval_polynomial / kate_division / kzg_open restate halo2's arithmetic: p(X) = (X - z) q(X) + p(z) coefficient by
+    coefficient, and against an SRS with a KNOWN tau the opening is [q(tau)] G with (tau - z) q(tau) = p(tau) - p(z) -- the
+    relation a verifier checks through the pairing."""
+    import random
+
+    from oracle import bn254 as bn
+
+    rnd = random.Random(254)
+    for n in (1, 2, 3, 17, 64):
+        p = [rnd.randrange(bn.R) for _ in range(n)]
+        z = rnd.randrange(bn.R)
+        y, q = bn.eval_polynomial(p, z), bn.kate_division(p, z)
+        assert len(q) == n - 1
+        assert y == sum(c * pow(z, i, bn.R) for i, c in enumerate(p)) % bn.R
+        back = [0] * n  # (X - z) q + y
+        for i, c in enumerate(q):
+            back[i + 1] = (back[i + 1] + c) % bn.R
+            back[i] = (back[i] - z * c) % bn.R
+        back[0] = (back[0] + y) % bn.R
+        assert back == p
+    tau = 0x1234567DEADBEEF % bn.R
+    n = 12
+    srs = [bn.pt_mul(bn.G1, pow(tau, i, bn.R)) for i in range(n)]
+    p = [rnd.randrange(bn.R) for _ in range(n)]
+    z = rnd.randrange(bn.R)
+    y, proof = bn.kzg_open(p, z, srs)
+    q_tau = bn.eval_polynomial(bn.kate_division(p, z), tau)
+    assert proof == bn.pt_mul(bn.G1, q_tau)
+    assert (tau - z) * q_tau % bn.R == (bn.eval_polynomial(p, tau) - y) % bn.R
+

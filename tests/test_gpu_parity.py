@@ -947,6 +947,79 @@ def test_bn254_kzg_commit(ctx):
     b.free()
 
 
+def test_bn254_kzg_open_matches_oracle(ctx):
+    """zkmi_bn254_kzg_open_dev = eval_polynomial + kate_division + commit: evaluation, every quotient coefficient and the
+    opening proof against the oracle for lengths around the block sizes of the scan (1, 2, 1023..1025 coefficients), at
+    zeta in {0, 1, r - 1, random}; against an SRS with a known tau the proof is [q(tau)] G, through the plain and the
+    prepared SRS."""
+    import torch
+    from oracle import bn254 as bn
+
+    rng = ec.SplitMix64(2540)
+    fr = lambda: rng.next() * rng.next() * rng.next() * rng.next() % bn.R
+    nmax = 1030
+    pts = bn.synthetic_bases(300)
+    b = ctx.bn254_bases_synthetic(nmax)
+    for n in (1, 2, 5, 300, 1023, 1024, 1025, 1030):
+        p = [fr() for _ in range(n)]
+        d = torch.frombuffer(bytearray(_bn_frs(p)), dtype=torch.uint8).cuda()
+        dq = torch.zeros(32 * max(n - 1, 1), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for z in (fr(), 0, 1, bn.R - 1):
+            ev, pf = ctx.bn254_kzg_open_dev(d.data_ptr(), n, _bn_frs([z]), b, dq.data_ptr())
+            q = bn.kate_division(p, z)
+            assert ev == _bn_frs([bn.eval_polynomial(p, z)]), (n, z)
+            assert bytes(dq.cpu().numpy().tobytes())[: 32 * (n - 1)] == _bn_frs(q), (n, z)
+            if n <= 300:
+                assert pf == bn.g1_to_bytes(bn.msm_naive(q, pts[: n - 1])), (n, z)
+            else:  # the synthetic bases' closed form: sum q_i [1 + i c] G
+                k = (sum(q) + 0xC0FFEE * sum(i * v for i, v in enumerate(q))) % bn.R
+                assert pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, k)), (n, z)
+    b.free()
+    tau, n = 0xDEADBEEFCAFEF00D1234567 % bn.R, 256
+    srs_pts = [bn.pt_mul(bn.G1, pow(tau, i, bn.R)) for i in range(n)]
+    p = [fr() for _ in range(n)]
+    z = fr()
+    d = torch.frombuffer(bytearray(_bn_frs(p)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    srs = ctx.bn254_bases(b"".join(bn.g1_to_bytes(x) for x in srs_pts))
+    want = bn.g1_to_bytes(bn.pt_mul(bn.G1, bn.eval_polynomial(bn.kate_division(p, z), tau)))
+    ev, pf = ctx.bn254_kzg_open_dev(d.data_ptr(), n, _bn_frs([z]), srs)
+    assert pf == want and ev == _bn_frs([bn.eval_polynomial(p, z)])
+    srs.prepare()
+    assert ctx.bn254_kzg_open_dev(d.data_ptr(), n, _bn_frs([z]), srs) == (ev, pf)
+    assert ctx.bn254_kzg_open_dev(d.data_ptr(), n - 7, _bn_frs([z]), srs)[1] == bn.g1_to_bytes(
+        bn.pt_mul(bn.G1, bn.eval_polynomial(bn.kate_division(p[: n - 7], z), tau)))
+    with pytest.raises(Exception):
+        ctx.bn254_kzg_open_dev(d.data_ptr(), n, _bn_frs([z])[:31] + b"\xff", srs)  # zeta >= r
+    srs.free()
+
+
+def test_bn254_kzg_open_full_size(ctx):
+    """2^20 + 3 coefficients (1 025 blocks of the first level: all three levels of the scan run): evaluation and every
+    quotient coefficient equal the oracle's Horner chain; the proof equals the synthetic bases' closed form."""
+    import torch
+    from oracle import bn254 as bn
+
+    n = (1 << 20) + 3
+    g = torch.Generator(device="cuda").manual_seed(2541)
+    raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    raw[:, 31] &= 0x1F
+    host = raw.cpu().numpy().tobytes()
+    p = [int.from_bytes(host[32 * i: 32 * i + 32], "little") for i in range(n)]
+    z = 0x2B1C5E9F00D1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234 % bn.R
+    b = ctx.bn254_bases_synthetic(n - 1)
+    dq = torch.zeros(32 * (n - 1), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ev, pf = ctx.bn254_kzg_open_dev(raw.data_ptr(), n, _bn_frs([z]), b, dq.data_ptr())
+    q = bn.kate_division(p, z)
+    assert ev == _bn_frs([bn.eval_polynomial(p, z)])
+    assert dq.cpu().numpy().tobytes() == _bn_frs(q)
+    k = (sum(q) + 0xC0FFEE * sum(i * v for i, v in enumerate(q))) % bn.R
+    assert pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, k))
+    b.free()
+
+
 def test_poseidon_and_bn254_golden_fixtures_on_gpu(ctx, zk):
     """HIP path vs the committed fixtures (tests/golden/poseidon.json, bn254.json)."""
     g = golden("poseidon.json")

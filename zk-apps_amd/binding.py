@@ -702,6 +702,13 @@ class Context:
         self._chk(self.lib.zkmi_bn254_kzg_commit_dev(self.h, C.c_void_p(d_evals), C.c_uint32(log_n), srs.h, out))
         return bytes(out)
 
+    def bn254_kzg_open_dev(self, d_coeffs, n, zeta, srs, d_quotient=None):
+        """(p(zeta) as 32 bytes, commit(q) as 64 bytes); d_quotient: device pointer that receives the n - 1 quotient coefficients."""
+        ev, pf = (C.c_uint8 * 32)(), (C.c_uint8 * 64)()
+        self._chk(self.lib.zkmi_bn254_kzg_open_dev(self.h, C.c_void_p(d_coeffs), C.c_uint64(n), _buf(zeta), srs.h,
+                                                   C.c_void_p(d_quotient) if d_quotient else None, ev, pf))
+        return bytes(ev), bytes(pf)
+
     def sha256_pairs(self, inputs, n_hashes):
         assert len(inputs) == 64 * n_hashes
         out = (C.c_uint8 * (32 * max(1, n_hashes)))()

@@ -10,6 +10,9 @@
 //   halo2_proofs::arithmetic::best_multiexp   -> G1 MSM (y^2 = x^3 + 3, generator (1, 2))
 //   ParamsKZG::commit_lagrange                -> commitment = MSM(SRS in Lagrange basis, evaluations);
 //                                                commit(coefficients) = MSM(SRS, iNTT(evaluations))
+//   halo2_proofs::arithmetic::eval_polynomial -> p(zeta) (Horner)
+//   halo2_proofs::arithmetic::kate_division   -> q(X) = (p(X) - p(zeta)) / (X - zeta) by synthetic division; the KZG
+//                                                opening proof is commit(q) (poly::kzg::multiopen, one polynomial, one point)
 // The kernels are the same templates as the BLS12-381 ones (msm_impl.hpp over Fp28<BnFq28Params>,
 // ntt.hip over Fp28<BnFr28Params>): 10 limbs instead of 14, and the bucket accumulation fits
 // 166 VGPRs = 3 waves per SIMD instead of 2.
@@ -82,6 +85,107 @@ __global__ void __launch_bounds__(64) k_bn_synth(Affine<BnFq28>* __restrict__ ou
   const uint4* sgm = reinterpret_cast<const uint4*>(&a);
 #pragma unroll
   for (unsigned q = 0; q < sizeof(a) / 16; q++) d[q] = sgm[q];
+}
+
+// ---- KZG opening: eval_polynomial + kate_division as ONE suffix scan ----------------------------------------------
+// With y = zeta, the synthetic division by (X - y) is q_i = sum_{j > i} p_j y^(j-i-1), and p(y) = sum_j p_j y^j: both are
+// values of the inclusive suffix scan  S_i = sum_{j >= i} p_j y^(j-i)  (q_i = S_{i+1}, p(y) = S_0) -- a linear recurrence
+// S_i = p_i + y S_{i+1} walked from the top coefficient down, which CPUs run as one dependent chain of n products.  Here:
+//   level 1: 256-thread blocks own 1024 consecutive coefficients; a thread runs the recurrence over its four, the 256
+//            thread values are combined by a log-step suffix scan in LDS (multipliers y^(4 2^s));
+//   level 2: the block values V_k = S restricted to block k are the coefficients of the same problem in Y = y^1024
+//            (1024 blocks per 2^20 coefficients), level 3 the same again in y^(2^20) (at most 64 values for 2^26);
+//   then the levels are walked back down: a block repeats its scan with the suffix value at the start of the NEXT block
+//   as an extra, 257th entry, and writes S for all of its elements.
+// Every multiplier is a power zeta^(2^j): one table of 30 entries (k_kzg_pow_table) serves all levels.
+constexpr int KZG_T = 256, KZG_E = 4, KZG_L = KZG_T * KZG_E;  // threads per block, elements per thread, elements per block
+constexpr int KZG_POWS = 32;
+
+__global__ void k_kzg_pow_table(BnFr28 zeta, BnFr28* __restrict__ pows) {
+  if (threadIdx.x || blockIdx.x) return;
+  BnFr28 v = zeta;
+  for (int j = 0; j < KZG_POWS; j++) {
+    pows[j] = v;  // zeta^(2^j)
+    v = v.sqr();
+  }
+}
+
+// in: m elements -- canonical words (CANON_IN, level 1) or limb form (the block values of the level below).
+// FINAL = false: vals[blockIdx.x] = the block's own suffix value at its first element (no carry).
+// FINAL = true:  carry[blockIdx.x + 1] (0 behind the last block) joins as the 257th entry and S_i is written for every element:
+//                level 1 (CANON_OUT): q[i - 1] = S_i for i >= 1 in canonical words and *eval = S_0; otherwise out[i] = S_i in limb form.
+// lg = log2 of the exponent of zeta this level's variable is (0, 10, 20).
+template <bool CANON_IN, bool FINAL, bool CANON_OUT>
+__global__ void __launch_bounds__(KZG_T)
+k_kzg_scan(const void* __restrict__ in, uint64_t m, const BnFr28* __restrict__ pows, int lg, const BnFr28* __restrict__ carry, uint32_t n_carry,
+           BnFr28* __restrict__ vals, void* __restrict__ out, uint32_t* __restrict__ eval_out) {
+  __shared__ BnFr28 sh[KZG_T + 1];
+  const int t = threadIdx.x;
+  const uint64_t first = (uint64_t)blockIdx.x * KZG_L + (uint64_t)t * KZG_E;
+  BnFr28 c[KZG_E];
+#pragma unroll
+  for (int e = 0; e < KZG_E; e++) {
+    const uint64_t i = first + e;
+    if (i >= m) {
+      c[e] = BnFr28::zero();
+    } else if constexpr (CANON_IN) {
+      const uint4* w4 = reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(in) + 8 * i);
+      const uint4 a = w4[0], b = w4[1];
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      c[e] = BnFr28::from_canonical(w);
+    } else {
+      c[e] = static_cast<const BnFr28*>(in)[i];
+    }
+  }
+  const BnFr28 y = pows[lg];
+  BnFr28 v = c[KZG_E - 1];
+#pragma unroll
+  for (int e = KZG_E - 2; e >= 0; e--) v = c[e] + y * v;  // the thread's own suffix value at its first element
+  sh[t] = v;
+  if (t == 0) {
+    BnFr28 cin = BnFr28::zero();
+    if (FINAL && carry && blockIdx.x + 1 < n_carry) cin = carry[blockIdx.x + 1];
+    sh[KZG_T] = cin;
+  }
+  __syncthreads();
+  // suffix scan over the 257 entries: entry t covers [t, t + 2^s) after step s; the multiplier is y^(E 2^s)
+  for (int s = 0; (1 << s) <= KZG_T; s++) {
+    const int src = t + (1 << s);
+    BnFr28 add = BnFr28::zero();
+    const bool on = src <= KZG_T;
+    if (on) add = pows[lg + 2 + s] * sh[src];
+    __syncthreads();
+    if (on) sh[t] = sh[t] + add;
+    __syncthreads();
+  }
+  if constexpr (!FINAL) {
+    if (t == 0) vals[blockIdx.x] = sh[0];
+    return;
+  } else {
+    // S at the first element of the NEXT thread (entry 256 = the carry), then the recurrence over this thread's four
+    BnFr28 nxt = sh[t + 1];
+    // (sh[t + 1] after the scan covers [t + 1, 257): everything behind this thread, the carry included)
+#pragma unroll
+    for (int e = KZG_E - 1; e >= 0; e--) {
+      const uint64_t i = first + e;
+      nxt = c[e] + y * nxt;  // S_i
+      if (i >= m) continue;
+      if constexpr (CANON_OUT) {
+        uint32_t w[8];
+        nxt.to_canonical(w);
+        if (i == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) eval_out[k] = w[k];
+        } else {
+          uint4* d = reinterpret_cast<uint4*>(static_cast<uint32_t*>(out) + 8 * (i - 1));
+          d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+          d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+      } else {
+        static_cast<BnFr28*>(out)[i] = nxt;
+      }
+    }
+  }
 }
 
 bool scalars_canonical(const uint8_t* s, uint64_t n) {
@@ -270,6 +374,58 @@ int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, 
   const int32_t rc = zkmi_bn254_ntt_fr_dev(ctx, d_evals, log_n, 1, 0);
   if (rc != ZKMI_OK) return rc;
   return msm_dev(ctx, d_evals, 1ull << log_n, srs, out_commitment);
+}
+
+// KZG opening at zeta of the polynomial with n coefficients (canonical words in HBM, constant term first):
+// *out_eval = p(zeta), out_proof = commit(q), q(X) = (p(X) - p(zeta)) / (X - zeta) -- n - 1 coefficients, also written to
+// d_quotient (canonical) when that is not null.  srs holds at least n - 1 points [tau^i] G; a prepared SRS is used through
+// its table (the quotient is zero-padded to the SRS's length).
+int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
+                                void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]) {
+  ZK_ENTER(ctx);
+  if (!d_coeffs || !zeta || !srs || !out_eval || !out_proof || n == 0 || n > MSM_MAX_TERMS || srs->n + 1 < n) return ZKMI_ERR_BAD_ARG;
+  if (!scalars_canonical(zeta, 1)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 zeta >= r");
+  uint32_t zw[8];
+  memcpy(zw, zeta, 32);
+  const uint64_t nb1 = (n + KZG_L - 1) / KZG_L, nb2 = (nb1 + KZG_L - 1) / KZG_L;  // nb2 <= 64 for n < 2^28
+  // the quotient as MSM scalars: n - 1 of them, zero-padded to the length of a prepared SRS
+  const bool padded = srs->tab != nullptr && srs->n >= n - 1;
+  const uint64_t qn = padded ? srs->n : n - 1;
+  ZK_HIP(ctx, ctx->staging((qn ? qn : 1) * 32 + 32));
+  uint32_t* d_q = static_cast<uint32_t*>(ctx->d_tmp);
+  uint32_t* d_eval = d_q + 8 * (qn ? qn : 1);
+  // work: pows | V1[nb1] | E1[nb1] | V2[nb2] | E2[nb2]
+  ZK_HIP(ctx, work_buffer(ctx, sizeof(BnFr28) * (KZG_POWS + 2 * nb1 + 2 * nb2 + 4)));
+  BnFr28* pows = static_cast<BnFr28*>(ctx->d_work);
+  BnFr28 *v1 = pows + KZG_POWS, *e1 = v1 + nb1, *v2 = e1 + nb1, *e2 = v2 + nb2;
+  const hipStream_t st = ctx->stream;
+  PhaseTimer* t = ctx->timer();
+  if (t) t->begin(PH_MISC, st);
+  if (padded && qn > n - 1) ZK_HIP(ctx, hipMemsetAsync(d_q + 8 * (n - 1), 0, 32 * (qn - (n - 1)), st));
+  hipLaunchKernelGGL(k_kzg_pow_table, dim3(1), dim3(64), 0, st, BnFr28::from_canonical(zw), pows);
+  const BnFr28* carry1 = nullptr;
+  if (nb1 > 1) {
+    hipLaunchKernelGGL((k_kzg_scan<true, false, false>), dim3((unsigned)nb1), dim3(KZG_T), 0, st, d_coeffs, n, pows, 0, nullptr, 0u, v1, nullptr, nullptr);
+    const BnFr28* carry2 = nullptr;
+    if (nb2 > 1) {
+      hipLaunchKernelGGL((k_kzg_scan<false, false, false>), dim3((unsigned)nb2), dim3(KZG_T), 0, st, v1, nb1, pows, 10, nullptr, 0u, v2, nullptr, nullptr);
+      hipLaunchKernelGGL((k_kzg_scan<false, true, false>), dim3(1), dim3(KZG_T), 0, st, v2, nb2, pows, 20, nullptr, 0u, nullptr, e2, nullptr);
+      carry2 = e2;
+    }
+    hipLaunchKernelGGL((k_kzg_scan<false, true, false>), dim3((unsigned)nb2), dim3(KZG_T), 0, st, v1, nb1, pows, 10, carry2, (uint32_t)nb2, nullptr, e1, nullptr);
+    carry1 = e1;
+  }
+  hipLaunchKernelGGL((k_kzg_scan<true, true, true>), dim3((unsigned)nb1), dim3(KZG_T), 0, st, d_coeffs, n, pows, 0, carry1, (uint32_t)nb1, nullptr, d_q, d_eval);
+  ZK_HIP(ctx, hipGetLastError());
+  if (t) t->end(PH_MISC, st);
+  ZK_HIP(ctx, hipMemcpyAsync(out_eval, d_eval, 32, hipMemcpyDeviceToHost, st));
+  if (d_quotient && n > 1) ZK_HIP(ctx, hipMemcpyAsync(d_quotient, d_q, 32 * (n - 1), hipMemcpyDeviceToDevice, st));
+  ZK_HIP(ctx, hipStreamSynchronize(st));
+  if (n == 1) {  // a constant: the quotient is the zero polynomial, its commitment the point at infinity
+    memset(out_proof, 0, 64);
+    return ZKMI_OK;
+  }
+  return msm_dev(ctx, d_q, qn, srs, out_proof);
 }
 
 }  // extern "C"
