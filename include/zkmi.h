@@ -274,6 +274,13 @@ int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, 
 int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
                                 void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]);
 
+/* Grand product of a permutation argument (halo2_proofs::plonk::permutation::prover::commit: batch_invert of the
+ * denominators + running product; PLONK's z(X)): d_out[0] = 1, d_out[i] = prod_{j < i} d_num[j] / d_den[j] for i < n,
+ * out_total = the product over all n terms.  All arrays: n x 32-byte LE canonical Fr in HBM.  ZKMI_ERR_BAD_ARG on a zero
+ * denominator (d_out is then unspecified). */
+int32_t zkmi_bn254_grand_product_dev(zkmi_ctx* ctx, const void* d_num, const void* d_den, uint64_t n, void* d_out,
+                                     uint8_t out_total[32]);
+
 /* ---- the contract's SHA-256 Merkle tree, batched ------------ *
  * compute_hash / combine_merkle_hash = SHA-256(first.bytes || second.bytes)
  * (shielder/contract/merkle.rs:24-28, shielder/mocked_zk/src/lib.rs:24-28).

@@ -162,3 +162,12 @@ def kzg_open(coeffs, point, srs):
     q = kate_division(coeffs, point)
     return eval_polynomial(coeffs, point), msm_naive(q, srs[: len(q)])
 
+
+def grand_product(num, den):
+    """halo2_proofs::plonk::permutation::prover::commit's running product (PLONK's z): z_0 = 1, z_{i+1} = z_i num_i / den_i.
+    Returns ([z_0 .. z_{n-1}], z_n)."""
+    z, acc = [], 1
+    for a, b in zip(num, den):
+        z.append(acc)
+        acc = acc * a % R * pow(b, -1, R) % R
+    return z, acc

@@ -42,3 +42,10 @@ for it in range(3):
     t = time.time(); ctx.bn254_kzg_open_dev(raw.data_ptr(), n, zeta, b); dt = time.time() - t
     print(f"bn254 kzg open of 2^{lg} coefficients (prepared SRS): wall {dt*1e3:.2f} ms, evaluation + quotient scan {ctx.prof_get('misc')[0]:.3f} ms,",
           {k: round(ctx.prof_get(k)[0], 3) for k in ("msm_sort", "msm_accum_g1", "msm_reduce_g1")})
+out = torch.empty_like(raw)
+den = raw.clone(); den[:, 0] |= 1
+torch.cuda.synchronize()
+for it in range(3):
+    ctx.prof_reset()
+    t = time.time(); ctx.bn254_grand_product_dev(raw.data_ptr(), den.data_ptr(), n, out.data_ptr()); dt = time.time() - t
+    print(f"bn254 grand product of 2^{lg} terms: wall {dt*1e3:.2f} ms, kernels {ctx.prof_get('misc')[0]:.3f} ms")

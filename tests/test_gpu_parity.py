@@ -1737,3 +1737,42 @@ def test_groth16_witness_of_bits_and_edge_blinding_factors_vs_cpp_oracle(ctx, zk
         pk.free()
     assert all(zk.groth16_verify(ovk, wit[32: 32 * n_pub], p) for p in want)
     r1.free()
+
+
+def test_bn254_grand_product_matches_oracle(ctx, pkg):
+    """zkmi_bn254_grand_product_dev (PLONK's z: batch inversion of the denominators + running product) against the oracle's
+    chain for lengths around the block sizes (1 .. 1 030 terms; 8 per thread in the inversion kernel, 1 024 per block in the
+    scan) and for 2^20 + 3 terms (all three levels); a permutation's product telescopes to 1; a zero denominator is refused."""
+    import random
+
+    import torch
+    from oracle import bn254 as bn
+
+    rnd = random.Random(2542)
+    up = lambda v: torch.frombuffer(bytearray(_bn_frs(v)), dtype=torch.uint8).cuda()
+    for n in (1, 2, 7, 8, 9, 513, 1023, 1024, 1025, 1030, (1 << 20) + 3):
+        num = [rnd.randrange(bn.R) for _ in range(n)]
+        den = [rnd.randrange(1, bn.R) for _ in range(n)]
+        if n > 4:
+            num[3], den[2] = 0 if n < 100 else 1, 1  # a zero numerator zeroes everything behind it
+        dn, dd = up(num), up(den)
+        out = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        tot = ctx.bn254_grand_product_dev(dn.data_ptr(), dd.data_ptr(), n, out.data_ptr())
+        z, last = bn.grand_product(num, den)
+        assert out.cpu().numpy().tobytes() == _bn_frs(z), n
+        assert tot == _bn_frs([last]), n
+    # the permutation argument's shape: num_i = f(i), den_i = f(sigma(i)) -> the product over the whole domain is 1
+    n = 4096
+    vals = [rnd.randrange(1, bn.R) for _ in range(n)]
+    sigma = list(range(n))
+    rnd.shuffle(sigma)
+    dn, dd = up(vals), up([vals[j] for j in sigma])
+    out = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert ctx.bn254_grand_product_dev(dn.data_ptr(), dd.data_ptr(), n, out.data_ptr()) == _bn_frs([1])
+    dd = up([vals[j] if k != 77 else 0 for k, j in enumerate(sigma)])
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.ZkmiError) as e:
+        ctx.bn254_grand_product_dev(dn.data_ptr(), dd.data_ptr(), n, out.data_ptr())
+    assert e.value.code == -1

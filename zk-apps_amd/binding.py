@@ -709,6 +709,12 @@ class Context:
                                                    C.c_void_p(d_quotient) if d_quotient else None, ev, pf))
         return bytes(ev), bytes(pf)
 
+    def bn254_grand_product_dev(self, d_num, d_den, n, d_out):
+        """d_out[i] = prod_{j < i} num_j / den_j; returns the product over all n terms (32 bytes)."""
+        tot = (C.c_uint8 * 32)()
+        self._chk(self.lib.zkmi_bn254_grand_product_dev(self.h, C.c_void_p(d_num), C.c_void_p(d_den), C.c_uint64(n), C.c_void_p(d_out), tot))
+        return bytes(tot)
+
     def sha256_pairs(self, inputs, n_hashes):
         assert len(inputs) == 64 * n_hashes
         out = (C.c_uint8 * (32 * max(1, n_hashes)))()

@@ -188,6 +188,108 @@ k_kzg_scan(const void* __restrict__ in, uint64_t m, const BnFr28* __restrict__ p
   }
 }
 
+// ---- permutation-argument grand product: z_0 = 1, z_(i+1) = z_i num_i / den_i ---------------------------------------
+// (halo2_proofs::plonk::permutation::prover::commit: batch_invert of the denominators, then a running product -- one
+// dependent chain of n products on a CPU.)  k_gp_ratio: a thread inverts its eight denominators with Montgomery's trick and
+// one Fermat inversion of its own (47 products per element; the MSMs of a prover cost thousands per element), ratio_i =
+// num_i / den_i in limb form.  k_gp_scan: the EXCLUSIVE prefix products of the ratios with the three-level shape of
+// k_kzg_scan (1024 elements per block, block totals one level up, carries on the way back down).
+constexpr int GP_E = 8;
+__device__ __forceinline__ BnFr28 ld_canon_fr(const void* base, uint64_t i) {
+  const uint4* w4 = reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(base) + 8 * i);
+  const uint4 a = w4[0], b = w4[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return BnFr28::from_canonical(w);
+}
+__global__ void __launch_bounds__(64)
+k_gp_ratio(const void* __restrict__ num, const void* __restrict__ den, uint64_t n, BnFr28* __restrict__ ratio, uint32_t* __restrict__ zero_flag) {
+  const uint64_t first = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * GP_E;
+  if (first >= n) return;
+  BnFr28 pre[GP_E];  // pre[e] = den_0 ... den_e (entries beyond n count as 1)
+  BnFr28 acc = BnFr28::one();
+  bool zero = false;
+#pragma unroll
+  for (int e = 0; e < GP_E; e++) {
+    if (first + e < n) {
+      const uint4* w4 = reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(den) + 8 * (first + e));
+      const uint4 a = w4[0], b = w4[1];
+      zero |= (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0;  // canonical input: zero is all-zero words
+      acc = acc * ld_canon_fr(den, first + e);
+    }
+    pre[e] = acc;
+  }
+  if (zero) {
+    atomicOr(zero_flag, 1u);
+    return;
+  }
+  BnFr28 inv = acc.inv();  // 1 / (den_0 ... den_last)
+  for (int e = GP_E - 1; e >= 0; e--) {
+    if (first + e < n) {
+      const BnFr28 inv_e = e ? inv * pre[e ? e - 1 : 0] : inv;  // 1 / den_e
+      if (e) inv = inv * ld_canon_fr(den, first + e);
+      ratio[first + e] = ld_canon_fr(num, first + e) * inv_e;
+    }
+  }
+}
+
+// FINAL = false: vals[blockIdx.x] = product of the block's elements.
+// FINAL = true:  carry[blockIdx.x] (1 when carry is null) = product of everything in front of the block; the exclusive prefix
+//                products are written for every element -- canonical words (CANON_OUT, level 1; the product of ALL elements also
+//                goes to total_out) or limb form.
+template <bool FINAL, bool CANON_OUT>
+__global__ void __launch_bounds__(KZG_T)
+k_gp_scan(const BnFr28* __restrict__ in, uint64_t m, const BnFr28* __restrict__ carry, BnFr28* __restrict__ vals, void* __restrict__ out,
+          uint32_t* __restrict__ total_out) {
+  __shared__ BnFr28 sh[KZG_T];
+  const int t = threadIdx.x;
+  const uint64_t first = (uint64_t)blockIdx.x * KZG_L + (uint64_t)t * KZG_E;
+  BnFr28 c[KZG_E];
+  BnFr28 v = BnFr28::one();
+#pragma unroll
+  for (int e = 0; e < KZG_E; e++) {
+    c[e] = first + e < m ? in[first + e] : BnFr28::one();
+    v = v * c[e];
+  }
+  sh[t] = v;
+  __syncthreads();
+  for (int s = 1; s < KZG_T; s <<= 1) {  // inclusive prefix products over the thread values
+    BnFr28 left = BnFr28::one();
+    const bool on = t >= s;
+    if (on) left = sh[t - s];
+    __syncthreads();
+    if (on) sh[t] = sh[t] * left;
+    __syncthreads();
+  }
+  if constexpr (!FINAL) {
+    if (t == KZG_T - 1) vals[blockIdx.x] = sh[t];
+    return;
+  } else {
+    BnFr28 run = carry ? carry[blockIdx.x] : BnFr28::one();
+    if (t > 0) run = run * sh[t - 1];  // everything in front of this thread's first element
+#pragma unroll
+    for (int e = 0; e < KZG_E; e++) {
+      const uint64_t i = first + e;
+      if (i >= m) break;
+      if constexpr (CANON_OUT) {
+        uint32_t w[8];
+        run.to_canonical(w);
+        uint4* d = reinterpret_cast<uint4*>(static_cast<uint32_t*>(out) + 8 * i);
+        d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      } else {
+        static_cast<BnFr28*>(out)[i] = run;
+      }
+      run = run * c[e];
+      if (CANON_OUT && i == m - 1) {
+        uint32_t w[8];
+        run.to_canonical(w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) total_out[k] = w[k];
+      }
+    }
+  }
+}
+
 bool scalars_canonical(const uint8_t* s, uint64_t n) {
   for (uint64_t i = 0; i < n; i++) {
     uint32_t w[8];
@@ -426,6 +528,47 @@ int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n,
     return ZKMI_OK;
   }
   return msm_dev(ctx, d_q, qn, srs, out_proof);
+}
+
+// Grand product of a permutation argument: d_out[0] = 1, d_out[i] = prod_{j < i} num_j / den_j (i < n), out_total = the
+// product over all n (1 for a satisfied permutation).  Inputs and outputs: canonical words in HBM.  A zero denominator is an
+// argument error (halo2's batch_invert would leave it zero and the argument would not verify).
+int32_t zkmi_bn254_grand_product_dev(zkmi_ctx* ctx, const void* d_num, const void* d_den, uint64_t n, void* d_out, uint8_t out_total[32]) {
+  ZK_ENTER(ctx);
+  if (!d_num || !d_den || !d_out || !out_total || n == 0 || n > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
+  const uint64_t nb1 = (n + KZG_L - 1) / KZG_L, nb2 = (nb1 + KZG_L - 1) / KZG_L;
+  // work: ratio[n] | V1[nb1] | E1[nb1] | V2[nb2] | E2[nb2] | total (8 words) | flag
+  ZK_HIP(ctx, work_buffer(ctx, sizeof(BnFr28) * (n + 2 * nb1 + 2 * nb2 + 4)));
+  BnFr28* ratio = static_cast<BnFr28*>(ctx->d_work);
+  BnFr28 *v1 = ratio + n, *e1 = v1 + nb1, *v2 = e1 + nb1, *e2 = v2 + nb2;
+  uint32_t* d_total = reinterpret_cast<uint32_t*>(e2 + nb2);
+  uint32_t* d_flag = d_total + 8;
+  const hipStream_t st = ctx->stream;
+  PhaseTimer* t = ctx->timer();
+  if (t) t->begin(PH_MISC, st);
+  ZK_HIP(ctx, hipMemsetAsync(d_flag, 0, 4, st));
+  hipLaunchKernelGGL(k_gp_ratio, dim3((unsigned)((n + 64 * GP_E - 1) / (64 * GP_E))), dim3(64), 0, st, d_num, d_den, n, ratio, d_flag);
+  const BnFr28* carry1 = nullptr;
+  if (nb1 > 1) {
+    hipLaunchKernelGGL((k_gp_scan<false, false>), dim3((unsigned)nb1), dim3(KZG_T), 0, st, ratio, n, nullptr, v1, nullptr, nullptr);
+    const BnFr28* carry2 = nullptr;
+    if (nb2 > 1) {
+      hipLaunchKernelGGL((k_gp_scan<false, false>), dim3((unsigned)nb2), dim3(KZG_T), 0, st, v1, nb1, nullptr, v2, nullptr, nullptr);
+      hipLaunchKernelGGL((k_gp_scan<true, false>), dim3(1), dim3(KZG_T), 0, st, v2, nb2, nullptr, nullptr, e2, nullptr);
+      carry2 = e2;
+    }
+    hipLaunchKernelGGL((k_gp_scan<true, false>), dim3((unsigned)nb2), dim3(KZG_T), 0, st, v1, nb1, carry2, nullptr, e1, nullptr);
+    carry1 = e1;
+  }
+  hipLaunchKernelGGL((k_gp_scan<true, true>), dim3((unsigned)nb1), dim3(KZG_T), 0, st, ratio, n, carry1, nullptr, d_out, d_total);
+  ZK_HIP(ctx, hipGetLastError());
+  if (t) t->end(PH_MISC, st);
+  uint32_t host[9];
+  ZK_HIP(ctx, hipMemcpyAsync(host, d_total, 36, hipMemcpyDeviceToHost, st));
+  ZK_HIP(ctx, hipStreamSynchronize(st));
+  if (host[8]) return ctx->fail(ZKMI_ERR_BAD_ARG, "grand product: zero denominator");
+  memcpy(out_total, host, 32);
+  return ZKMI_OK;
 }
 
 }  // extern "C"
