@@ -273,6 +273,11 @@ def bn254_vectors():
     frs = lambda v: b"".join(int(x).to_bytes(32, "little") for x in v).hex()
     tau = 0xDEADBEEFCAFEF00D1234567 % bn.R
     coeffs = [rnd() for _ in range(16)]
+    zeta = rnd()  # (drawn after everything the earlier vectors use)
+    gp_num, gp_den = [rnd() for _ in range(12)], [rnd() or 1 for _ in range(12)]
+    srs_pts = [bn.pt_mul(bn.G1, pow(tau, i, bn.R)) for i in range(16)]
+    open_eval, open_proof = bn.kzg_open(coeffs, zeta, srs_pts)
+    gp_z, gp_total = bn.grand_product(gp_num, gp_den)
     dump("bn254.json", {
         "p": hex(bn.P), "r": hex(bn.R), "root_2_28": hex(bn.FR_ROOT_2_28),
         "synthetic_first4": [bn.g1_to_bytes(p).hex() for p in pts[:4]],
@@ -284,6 +289,10 @@ def bn254_vectors():
                 "srs": b"".join(bn.g1_to_bytes(bn.pt_mul(bn.G1, pow(tau, i, bn.R))) for i in range(16)).hex(),
                 "evaluations": frs(bn.ntt(coeffs)), "coefficients": frs(coeffs),
                 "commitment": bn.g1_to_bytes(bn.pt_mul(bn.G1, sum(c * pow(tau, i, bn.R) for i, c in enumerate(coeffs)) % bn.R)).hex()},
+        # opening of the same polynomial against the same SRS (eval_polynomial, kate_division, commit(q))
+        "kzg_open": {"zeta": frs([zeta]), "eval": frs([open_eval]), "quotient": frs(bn.kate_division(coeffs, zeta)),
+                     "proof": bn.g1_to_bytes(open_proof).hex()},
+        "grand_product": {"num": frs(gp_num), "den": frs(gp_den), "z": frs(gp_z), "total": frs([gp_total])},
     })
 
 

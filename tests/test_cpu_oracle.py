@@ -271,6 +271,16 @@ def test_poseidon_and_bn254_golden_fixtures_reproduce():
     assert bn.g1_to_bytes(bn.msm_naive(sc, bn.synthetic_bases(64))).hex() == b["msm"]["expected"]
     a = [int.from_bytes(H(b["ntt"]["input"])[i : i + 32], "little") for i in range(0, 32 * 32, 32)]
     assert b"".join(v.to_bytes(32, "little") for v in bn.ntt(a)).hex() == b["ntt"]["forward"]
+    ints = lambda h: [int.from_bytes(H(h)[i : i + 32], "little") for i in range(0, len(h) // 2, 32)]
+    frs = lambda v: b"".join(x.to_bytes(32, "little") for x in v).hex()
+    co, o = ints(b["kzg"]["coefficients"]), b["kzg_open"]
+    z = ints(o["zeta"])[0]
+    assert (frs([bn.eval_polynomial(co, z)]), frs(bn.kate_division(co, z))) == (o["eval"], o["quotient"])
+    tau = int(b["kzg"]["tau"], 16)  # the proof is [q(tau)] G
+    assert bn.g1_to_bytes(bn.pt_mul(bn.G1, bn.eval_polynomial(ints(o["quotient"]), tau))).hex() == o["proof"]
+    gp = b["grand_product"]
+    zs, tot = bn.grand_product(ints(gp["num"]), ints(gp["den"]))
+    assert (frs(zs), frs([tot])) == (gp["z"], gp["total"])
 
 
 def test_bn254_kzg_opening_oracle_identities():

@@ -1047,7 +1047,19 @@ def test_poseidon_and_bn254_golden_fixtures_on_gpu(ctx, zk):
     torch.cuda.synchronize()
     assert ctx.bn254_kzg_commit_dev(d.data_ptr(), k["log_n"], srs).hex() == k["commitment"]
     assert bytes(d.cpu().numpy().tobytes()).hex() == k["coefficients"]
+    o = b["kzg_open"]  # d now holds the coefficients
+    dq = torch.zeros(32 * 15, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ev, pf = ctx.bn254_kzg_open_dev(d.data_ptr(), 16, H(o["zeta"]), srs, dq.data_ptr())
+    assert (ev.hex(), pf.hex(), dq.cpu().numpy().tobytes().hex()) == (o["eval"], o["proof"], o["quotient"])
     srs.free()
+    gp = b["grand_product"]
+    dn = torch.frombuffer(bytearray(H(gp["num"])), dtype=torch.uint8).cuda()
+    dd = torch.frombuffer(bytearray(H(gp["den"])), dtype=torch.uint8).cuda()
+    out = torch.zeros(32 * 12, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert ctx.bn254_grand_product_dev(dn.data_ptr(), dd.data_ptr(), 12, out.data_ptr()).hex() == gp["total"]
+    assert out.cpu().numpy().tobytes().hex() == gp["z"]
 
 
 def test_bn254_prepared_srs_matches_plain_msm(ctx):
