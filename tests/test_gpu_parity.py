@@ -1788,3 +1788,76 @@ def test_bn254_grand_product_matches_oracle(ctx, pkg):
     with pytest.raises(pkg.ZkmiError) as e:
         ctx.bn254_grand_product_dev(dn.data_ptr(), dd.data_ptr(), n, out.data_ptr())
     assert e.value.code == -1
+
+
+def test_random_relations_vs_cpp_oracle(ctx, zk):
+    """Differential test on relations nobody designed: random sparse A and B rows (empty rows, rows that are one constant,
+    rows of hundreds of terms and one of 1 500, variables no row mentions, zero and one and r - 1 among the values), C_i one
+    product variable per row.  Setup (verifying key) and proof bytes against the C++ oracle's setup and prover from the same
+    toxic waste, witness, r and s -- single proofs, grouped batches and one-proof groups."""
+    import random
+
+    import torch
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    one = (1).to_bytes(32, "little")
+    for seed, n_free, n_rows, n_pub in ((1, 40, 200, 3), (2, 300, 900, 1), (3, 1700, 2300, 5)):
+        rnd = random.Random(9000 + seed)
+        special = [0, 1, R - 1, 2, R - 2]
+        vals = [1] + [rnd.choice(special) if rnd.random() < 0.2 else rnd.randrange(R) for _ in range(n_pub - 1 + n_free)]
+        n_in = len(vals)
+        rows = []
+
+        def lc(max_len):
+            k = rnd.choice([0, 1, 1, 2, 3, 5, 8, max_len])
+            cols = sorted(rnd.sample(range(n_in), min(k, n_in)))
+            return cols, [rnd.choice([1, R - 1, 2]) if rnd.random() < 0.5 else rnd.randrange(1, R) for _ in cols]
+
+        for i in range(n_rows):
+            big = 1500 if (seed == 3 and i == 7) else (200 if i % 97 == 0 else 12)
+            (ac, av), (bc, bv) = lc(big), lc(12)
+            a = sum(v * vals[c] for c, v in zip(ac, av)) % R
+            b = sum(v * vals[c] for c, v in zip(bc, bv)) % R
+            rows.append((ac, av, bc, bv))
+            vals.append(a * b % R)  # the product variable of row i: column n_in + i
+        n_vars = len(vals)
+        mats = []
+        for which in range(3):
+            rp, cl, vl = [0], [], b""
+            for i, (ac, av, bc, bv) in enumerate(rows):
+                cols, cv = ((ac, av), (bc, bv), ([n_in + i], [1]))[which]
+                cl += cols
+                vl += b"".join(v.to_bytes(32, "little") for v in cv)
+                rp.append(len(cl))
+            mats.append((rp, cl, vl))
+        r1 = zk.r1cs_create(n_vars, n_pub, mats)
+        wit = frs(vals)
+        assert r1.is_satisfied(wit)
+        rng = ec.SplitMix64(0xABCD00 + seed)
+        toxic = frs([rng.fr() for _ in range(5)])
+        ovk, okey = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, toxic)
+        rs = [ec.fr_to_bytes(rng.fr()) for _ in range(5)]
+        ss = [ec.fr_to_bytes(rng.fr()) for _ in range(5)]
+        want = [ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, okey, wit, r_, s_) for r_, s_ in zip(rs, ss)]
+        d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        for group in (0, 1):
+            ctx.set_group_size(group)
+            pk, vk = ctx.groth16_setup(r1, toxic)
+            ctx.set_group_size(0)
+            assert vk == ovk, (seed, group)
+            assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * 5, rs, ss) == want, (seed, group)
+            assert ctx.groth16_prove_dev(pk, d.data_ptr(), rs[0], ss[0]) == want[0], (seed, group)
+            assert ctx.groth16_prove(pk, wit, rs[1], ss[1]) == want[1], (seed, group)
+            pk.free()
+        assert zk.groth16_verify(ovk, wit[32: 32 * n_pub], want[0])
+        bad = bytearray(wit)
+        bad[32 * (n_in + 3)] ^= 1  # a wrong product variable: refused, not proved
+        with pytest.raises(Exception):
+            ctx2_pk, _ = ctx.groth16_setup(r1, toxic)
+            try:
+                ctx.groth16_prove(ctx2_pk, bytes(bad), rs[0], ss[0])
+            finally:
+                ctx2_pk.free()
+        r1.free()
