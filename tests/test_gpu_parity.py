@@ -1861,3 +1861,47 @@ def test_random_relations_vs_cpp_oracle(ctx, zk):
             finally:
                 ctx2_pk.free()
         r1.free()
+
+
+def test_bn254_polynomial_entry_points_refuse_bad_arguments(ctx, pkg):
+    """The ABI promises an error code, not a crash: no coefficients, an SRS shorter than the quotient, null buffers."""
+    import torch
+    from oracle import bn254 as bn
+
+    n = 40
+    d = torch.frombuffer(bytearray(_bn_frs(list(range(1, n + 1)))), dtype=torch.uint8).cuda()
+    out = torch.zeros(32 * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    z = _bn_frs([5])
+    short = ctx.bn254_bases_synthetic(n - 2)  # the quotient has n - 1 coefficients
+    exact = ctx.bn254_bases_synthetic(n - 1)
+    for call in (lambda: ctx.bn254_kzg_open_dev(d.data_ptr(), 0, z, exact),
+                 lambda: ctx.bn254_kzg_open_dev(d.data_ptr(), n, z, short),
+                 lambda: ctx.bn254_kzg_open_dev(0, n, z, exact),
+                 lambda: ctx.bn254_grand_product_dev(d.data_ptr(), d.data_ptr(), 0, out.data_ptr()),
+                 lambda: ctx.bn254_grand_product_dev(d.data_ptr(), 0, n, out.data_ptr()),
+                 lambda: ctx.bn254_grand_product_dev(d.data_ptr(), d.data_ptr(), n, 0)):
+        with pytest.raises(pkg.ZkmiError) as e:
+            call()
+        assert e.value.code == -1
+    ev, pf = ctx.bn254_kzg_open_dev(d.data_ptr(), n, z, exact)  # the context is still usable, and n - 1 points suffice
+    p = list(range(1, n + 1))
+    assert ev == _bn_frs([bn.eval_polynomial(p, 5)])
+    assert pf == bn.g1_to_bytes(bn.msm_naive(bn.kate_division(p, 5), bn.synthetic_bases(n - 1)))
+    assert ctx.bn254_grand_product_dev(d.data_ptr(), d.data_ptr(), n, out.data_ptr()) == _bn_frs([1])
+    short.free()
+    exact.free()
+
+
+def test_bits_relation_script_short():
+    """scripts/bits_relation_ab.py (a witness of bits with a row that sums them all: the long-row mat-vec kernel, the heavy
+    buckets of a one-value witness and the density switch of the B1 fold) proves and verifies at 2^12."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bits_relation_ab.py"), "12", "12", "sum"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "verified True" in p.stdout, p.stdout[-500:]
