@@ -274,6 +274,11 @@ int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, 
 int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
                                 void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]);
 
+/* k polynomials of n coefficients each opened at ONE point (a rotation set of poly::kzg::multiopen): d_polys = k device
+ * pointers (a host array), out_evals = k x 32 B, out_evals[j] = p_j(zeta); out_proof = commit((f - f(zeta)) / (X - zeta)) for
+ * f = sum_j v^j p_j (the verifier folds commitments and evaluations with the same powers of v). */
+int32_t zkmi_bn254_kzg_open_many_dev(zkmi_ctx* ctx, const void* const* d_polys, uint32_t k, uint64_t n, const uint8_t zeta[32],
+                                     const uint8_t v[32], const zkmi_bn_bases* srs, uint8_t* out_evals, uint8_t out_proof[64]);
 /* Grand product of a permutation argument (halo2_proofs::plonk::permutation::prover::commit: batch_invert of the
  * denominators + running product; PLONK's z(X)): d_out[0] = 1, d_out[i] = prod_{j < i} d_num[j] / d_den[j] for i < n,
  * out_total = the product over all n terms.  All arrays: n x 32-byte LE canonical Fr in HBM.  ZKMI_ERR_BAD_ARG on a zero

@@ -163,6 +163,16 @@ def kzg_open(coeffs, point, srs):
     return eval_polynomial(coeffs, point), msm_naive(q, srs[: len(q)])
 
 
+def kzg_open_many(polys, point, v, srs):
+    """k polynomials at one point (a rotation set of halo2's multiopen): ([p_j(point)], commit(q)) with q = kate_division of
+    f = sum_j v^j p_j -- the verifier checks the one proof against sum_j v^j C_j and sum_j v^j p_j(point)."""
+    n = len(polys[0])
+    f = [0] * n
+    for p in reversed(polys):
+        f = [(a * v + b) % R for a, b in zip(f, p)]
+    return [eval_polynomial(p, point) for p in polys], kzg_open(f, point, srs)[1]
+
+
 def grand_product(num, den):
     """halo2_proofs::plonk::permutation::prover::commit's running product (PLONK's z): z_0 = 1, z_{i+1} = z_i num_i / den_i.
     Returns ([z_0 .. z_{n-1}], z_n)."""

@@ -49,3 +49,8 @@ for it in range(3):
     ctx.prof_reset()
     t = time.time(); ctx.bn254_grand_product_dev(raw.data_ptr(), den.data_ptr(), n, out.data_ptr()); dt = time.time() - t
     print(f"bn254 grand product of 2^{lg} terms: wall {dt*1e3:.2f} ms, kernels {ctx.prof_get('misc')[0]:.3f} ms")
+polys = [raw] + [torch.roll(raw, shifts=7 * (j + 1), dims=0) for j in range(7)]
+torch.cuda.synchronize()
+for it in range(3):
+    t = time.time(); ctx.bn254_kzg_open_many_dev([p.data_ptr() for p in polys], n, zeta, zeta, b); dt = time.time() - t
+    print(f"bn254 kzg open of 8 polynomials of 2^{lg} coefficients at one point (prepared SRS): wall {dt*1e3:.2f} ms")

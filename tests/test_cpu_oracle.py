@@ -313,4 +313,12 @@ def test_bn254_kzg_opening_oracle_identities():
     q_tau = bn.eval_polynomial(bn.kate_division(p, z), tau)
     assert proof == bn.pt_mul(bn.G1, q_tau)
     assert (tau - z) * q_tau % bn.R == (bn.eval_polynomial(p, tau) - y) % bn.R
+    # several polynomials at one point: one proof for f = sum_j v^j p_j, checked against the folded evaluations
+    polys, v = [[rnd.randrange(bn.R) for _ in range(n)] for _ in range(4)], rnd.randrange(bn.R)
+    ys, proof = bn.kzg_open_many(polys, z, v, srs)
+    assert ys == [bn.eval_polynomial(p, z) for p in polys]
+    f = [sum(pow(v, j, bn.R) * p[i] for j, p in enumerate(polys)) % bn.R for i in range(n)]
+    q_tau = bn.eval_polynomial(bn.kate_division(f, z), tau)
+    assert proof == bn.pt_mul(bn.G1, q_tau)
+    assert (tau - z) * q_tau % bn.R == sum(pow(v, j, bn.R) * (bn.eval_polynomial(p, tau) - y) for j, (p, y) in enumerate(zip(polys, ys))) % bn.R
 

@@ -1905,3 +1905,73 @@ def test_bits_relation_script_short():
                        timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "verified True" in p.stdout, p.stdout[-500:]
+
+
+def test_bn254_kzg_open_many_matches_oracle(ctx, pkg):
+    """zkmi_bn254_kzg_open_many_dev (k polynomials at one point: all evaluations + ONE proof for f = sum_j v^j p_j) against
+    the oracle: k in {1, 3, 8} x lengths around the block size, v in {0, 1, random}; against an SRS with a known tau the proof
+    is [q_f(tau)] G and satisfies the folded check (tau - z) q_f(tau) = sum_j v^j (p_j(tau) - p_j(z)); and three polynomials of
+    2^20 + 3 coefficients (every level of the scan, one launch per level for all three)."""
+    import torch
+    from oracle import bn254 as bn
+
+    rng = ec.SplitMix64(2543)
+    fr = lambda: rng.next() * rng.next() * rng.next() * rng.next() % bn.R
+    up = lambda vals: torch.frombuffer(bytearray(_bn_frs(vals)), dtype=torch.uint8).cuda()
+    b = ctx.bn254_bases_synthetic(1030)
+    for k in (1, 3, 8):
+        for n in (1, 2, 300, 1024, 1027):
+            polys = [[fr() for _ in range(n)] for _ in range(k)]
+            d = [up(p) for p in polys]
+            torch.cuda.synchronize()
+            for z, v in ((fr(), fr()), (fr(), 0), (0, 1), (bn.R - 1, fr())):
+                evs, pf = ctx.bn254_kzg_open_many_dev([t.data_ptr() for t in d], n, _bn_frs([z]), _bn_frs([v]), b)
+                f = [0] * n
+                for p in reversed(polys):
+                    f = [(a * v + c) % bn.R for a, c in zip(f, p)]
+                q = bn.kate_division(f, z)
+                assert evs == [_bn_frs([bn.eval_polynomial(p, z)]) for p in polys], (k, n)
+                kk = (sum(q) + 0xC0FFEE * sum(i * x for i, x in enumerate(q))) % bn.R
+                assert pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, kk)), (k, n)
+                if k == 1:
+                    assert (evs[0], pf) == ctx.bn254_kzg_open_dev(d[0].data_ptr(), n, _bn_frs([z]), b)
+    b.free()
+    tau, n, k = 0xDEADBEEFCAFEF00D1234567 % bn.R, 64, 5
+    srs_pts = [bn.pt_mul(bn.G1, pow(tau, i, bn.R)) for i in range(n)]
+    srs = ctx.bn254_bases(b"".join(bn.g1_to_bytes(x) for x in srs_pts))
+    polys = [[fr() for _ in range(n)] for _ in range(k)]
+    d = [up(p) for p in polys]
+    z, v = fr(), fr()
+    torch.cuda.synchronize()
+    evs, pf = ctx.bn254_kzg_open_many_dev([t.data_ptr() for t in d], n, _bn_frs([z]), _bn_frs([v]), srs)
+    want_evs, want_pf = bn.kzg_open_many(polys, z, v, srs_pts)
+    assert evs == [_bn_frs([y]) for y in want_evs] and pf == bn.g1_to_bytes(want_pf)
+    folded = sum(pow(v, j, bn.R) * (bn.eval_polynomial(p, tau) - y) for j, (p, y) in enumerate(zip(polys, want_evs))) % bn.R
+    f = [sum(pow(v, j, bn.R) * p[i] for j, p in enumerate(polys)) % bn.R for i in range(n)]
+    q_tau = bn.eval_polynomial(bn.kate_division(f, z), tau)
+    assert (tau - z) * q_tau % bn.R == folded and pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, q_tau))
+    with pytest.raises(pkg.ZkmiError) as e:
+        ctx.bn254_kzg_open_many_dev([], n, _bn_frs([z]), _bn_frs([v]), srs)
+    assert e.value.code == -1
+    srs.free()
+    # full size
+    n, k = (1 << 20) + 3, 3
+    g = torch.Generator(device="cuda").manual_seed(2544)
+    raws = []
+    for _ in range(k):
+        raw = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        raw[:, 31] &= 0x1F
+        raws.append(raw)
+    hosts = [r.cpu().numpy().tobytes() for r in raws]
+    polys = [[int.from_bytes(h[32 * i: 32 * i + 32], "little") for i in range(n)] for h in hosts]
+    b = ctx.bn254_bases_synthetic(n - 1)
+    torch.cuda.synchronize()
+    evs, pf = ctx.bn254_kzg_open_many_dev([r.data_ptr() for r in raws], n, _bn_frs([z]), _bn_frs([v]), b)
+    assert evs == [_bn_frs([bn.eval_polynomial(p, z)]) for p in polys]
+    f = [0] * n
+    for p in reversed(polys):
+        f = [(a * v + c) % bn.R for a, c in zip(f, p)]
+    q = bn.kate_division(f, z)
+    kk = (sum(q) + 0xC0FFEE * sum(i * x for i, x in enumerate(q))) % bn.R
+    assert pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, kk))
+    b.free()

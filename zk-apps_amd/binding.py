@@ -709,6 +709,15 @@ class Context:
                                                    C.c_void_p(d_quotient) if d_quotient else None, ev, pf))
         return bytes(ev), bytes(pf)
 
+    def bn254_kzg_open_many_dev(self, d_polys, n, zeta, v, srs):
+        """([p_j(zeta) as 32 bytes], commit(q of sum_j v^j p_j) as 64 bytes) for a list of device pointers."""
+        k = len(d_polys)
+        tab = (C.c_void_p * max(k, 1))(*d_polys)
+        ev, pf = (C.c_uint8 * (32 * max(k, 1)))(), (C.c_uint8 * 64)()
+        self._chk(self.lib.zkmi_bn254_kzg_open_many_dev(self.h, tab, C.c_uint32(k), C.c_uint64(n), _buf(zeta), _buf(v), srs.h, ev, pf))
+        raw = bytes(ev)
+        return [raw[32 * j: 32 * j + 32] for j in range(k)], bytes(pf)
+
     def bn254_grand_product_dev(self, d_num, d_den, n, d_out):
         """d_out[i] = prod_{j < i} num_j / den_j; returns the product over all n terms (32 bytes)."""
         tot = (C.c_uint8 * 32)()

@@ -118,9 +118,15 @@ __global__ void k_kzg_pow_table(BnFr28 zeta, BnFr28* __restrict__ pows) {
 template <bool CANON_IN, bool FINAL, bool CANON_OUT>
 __global__ void __launch_bounds__(KZG_T)
 k_kzg_scan(const void* __restrict__ in, uint64_t m, const BnFr28* __restrict__ pows, int lg, const BnFr28* __restrict__ carry, uint32_t n_carry,
-           BnFr28* __restrict__ vals, void* __restrict__ out, uint32_t* __restrict__ eval_out) {
+           BnFr28* __restrict__ vals, void* __restrict__ out, uint32_t* __restrict__ eval_out, const void* const* __restrict__ in_table = nullptr,
+           uint64_t in_stride = 0, uint64_t vals_stride = 0) {
   __shared__ BnFr28 sh[KZG_T + 1];
   const int t = threadIdx.x;
+  // blockIdx.y = polynomial of a set (block values only: zkmi_bn254_kzg_open_many_dev evaluates k polynomials per launch):
+  // level 1 reads polynomial y through a table of pointers, the levels above read row y of the level below
+  if (in_table) in = in_table[blockIdx.y];
+  else if (in_stride) in = static_cast<const BnFr28*>(in) + (size_t)blockIdx.y * in_stride;
+  if (vals) vals += (size_t)blockIdx.y * vals_stride;
   const uint64_t first = (uint64_t)blockIdx.x * KZG_L + (uint64_t)t * KZG_E;
   BnFr28 c[KZG_E];
 #pragma unroll
@@ -186,6 +192,35 @@ k_kzg_scan(const void* __restrict__ in, uint64_t m, const BnFr28* __restrict__ p
       }
     }
   }
+}
+
+// f_i = sum_j v^j p_j[i] (Horner in v from the last polynomial down), canonical words in and out: the polynomial whose
+// quotient opens all k at once
+__global__ void __launch_bounds__(256)
+k_kzg_lincomb(const void* const* __restrict__ polys, uint32_t k, uint64_t n, BnFr28 v, uint32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  BnFr28 acc = BnFr28::zero();
+  for (int j = (int)k - 1; j >= 0; j--) {
+    const uint4* w4 = reinterpret_cast<const uint4*>(static_cast<const uint32_t*>(polys[j]) + 8 * i);
+    const uint4 a = w4[0], b = w4[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    acc = acc * v + BnFr28::from_canonical(w);
+  }
+  uint32_t w[8];
+  acc.to_canonical(w);
+  uint4* d = reinterpret_cast<uint4*>(out + 8 * i);
+  d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// tops[j * stride] (limb form) -> out[8 j ..] canonical
+__global__ void k_kzg_evals_out(const BnFr28* __restrict__ tops, uint64_t stride, uint32_t k, uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  uint32_t w[8];
+  tops[(size_t)j * stride].to_canonical(w);
+#pragma unroll
+  for (int q = 0; q < 8; q++) out[8 * j + q] = w[q];
 }
 
 // ---- permutation-argument grand product: z_0 = 1, z_(i+1) = z_i num_i / den_i ---------------------------------------
@@ -482,13 +517,8 @@ int32_t zkmi_bn254_kzg_commit_dev(zkmi_ctx* ctx, void* d_evals, uint32_t log_n, 
 // *out_eval = p(zeta), out_proof = commit(q), q(X) = (p(X) - p(zeta)) / (X - zeta) -- n - 1 coefficients, also written to
 // d_quotient (canonical) when that is not null.  srs holds at least n - 1 points [tau^i] G; a prepared SRS is used through
 // its table (the quotient is zero-padded to the SRS's length).
-int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
-                                void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]) {
-  ZK_ENTER(ctx);
-  if (!d_coeffs || !zeta || !srs || !out_eval || !out_proof || n == 0 || n > MSM_MAX_TERMS || srs->n + 1 < n) return ZKMI_ERR_BAD_ARG;
-  if (!scalars_canonical(zeta, 1)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 zeta >= r");
-  uint32_t zw[8];
-  memcpy(zw, zeta, 32);
+static int32_t kzg_open_core(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint32_t zw[8], const zkmi_bn_bases* srs, void* d_quotient,
+                             uint8_t out_eval[32], uint8_t out_proof[64]) {
   const uint64_t nb1 = (n + KZG_L - 1) / KZG_L, nb2 = (nb1 + KZG_L - 1) / KZG_L;  // nb2 <= 64 for n < 2^28
   // the quotient as MSM scalars: n - 1 of them, zero-padded to the length of a prepared SRS
   const bool padded = srs->tab != nullptr && srs->n >= n - 1;
@@ -528,6 +558,75 @@ int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n,
     return ZKMI_OK;
   }
   return msm_dev(ctx, d_q, qn, srs, out_proof);
+}
+
+int32_t zkmi_bn254_kzg_open_dev(zkmi_ctx* ctx, const void* d_coeffs, uint64_t n, const uint8_t zeta[32], const zkmi_bn_bases* srs,
+                                void* d_quotient, uint8_t out_eval[32], uint8_t out_proof[64]) {
+  ZK_ENTER(ctx);
+  if (!d_coeffs || !zeta || !srs || !out_eval || !out_proof || n == 0 || n > MSM_MAX_TERMS || srs->n + 1 < n) return ZKMI_ERR_BAD_ARG;
+  if (!scalars_canonical(zeta, 1)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 zeta >= r");
+  uint32_t zw[8];
+  memcpy(zw, zeta, 32);
+  return kzg_open_core(ctx, d_coeffs, n, zw, srs, d_quotient, out_eval, out_proof);
+}
+
+// k polynomials of n coefficients opened at ONE point (a rotation set of halo2's multiopen; GWC's per-point step):
+// out_evals[j] = p_j(zeta), out_proof = commit((f - f(zeta)) / (X - zeta)) for f = sum_j v^j p_j -- the verifier folds the k
+// commitments and evaluations with the same powers of v.  All k evaluations come out of one launch per level of the scan
+// (block values only), f out of one pass over the k inputs; the opening of f is zkmi_bn254_kzg_open_dev's.
+int32_t zkmi_bn254_kzg_open_many_dev(zkmi_ctx* ctx, const void* const* d_polys, uint32_t k, uint64_t n, const uint8_t zeta[32], const uint8_t v[32],
+                                     const zkmi_bn_bases* srs, uint8_t* out_evals, uint8_t out_proof[64]) {
+  ZK_ENTER(ctx);
+  if (!d_polys || !zeta || !v || !srs || !out_evals || !out_proof || k == 0 || k > 4096 || n == 0 || n > MSM_MAX_TERMS || srs->n + 1 < n)
+    return ZKMI_ERR_BAD_ARG;
+  for (uint32_t j = 0; j < k; j++)
+    if (!d_polys[j]) return ZKMI_ERR_BAD_ARG;
+  if (!scalars_canonical(zeta, 1) || !scalars_canonical(v, 1)) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "bn254 zeta / v >= r");
+  uint32_t zw[8], vw[8];
+  memcpy(zw, zeta, 32);
+  memcpy(vw, v, 32);
+  const uint64_t nb1 = (n + KZG_L - 1) / KZG_L, nb2 = (nb1 + KZG_L - 1) / KZG_L;
+  // own allocation (the opening of f below re-sizes the context's staging and work buffers):
+  // f[n] canonical | pointer table | pows | V1[k][nb1] | V2[k][nb2] | V3[k] | evals (k x 8 words)
+  const size_t off_tab = 32 * n, off_pows = off_tab + 8 * (size_t)k, off_v1 = off_pows + sizeof(BnFr28) * KZG_POWS,
+               off_v2 = off_v1 + sizeof(BnFr28) * k * nb1, off_v3 = off_v2 + sizeof(BnFr28) * k * nb2, off_ev = off_v3 + sizeof(BnFr28) * k;
+  uint8_t* buf = nullptr;
+  ZK_HIP(ctx, hipMalloc(&buf, off_ev + 32 * (size_t)k));
+  uint32_t* d_f = reinterpret_cast<uint32_t*>(buf);
+  const void** d_tab = reinterpret_cast<const void**>(buf + off_tab);
+  BnFr28* pows = reinterpret_cast<BnFr28*>(buf + off_pows);
+  BnFr28 *v1 = reinterpret_cast<BnFr28*>(buf + off_v1), *v2 = reinterpret_cast<BnFr28*>(buf + off_v2), *v3 = reinterpret_cast<BnFr28*>(buf + off_v3);
+  uint32_t* d_ev = reinterpret_cast<uint32_t*>(buf + off_ev);
+  const hipStream_t st = ctx->stream;
+  hipError_t e = hipMemcpyAsync(d_tab, d_polys, 8 * (size_t)k, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_kzg_pow_table, dim3(1), dim3(64), 0, st, BnFr28::from_canonical(zw), pows);
+    hipLaunchKernelGGL((k_kzg_scan<true, false, false>), dim3((unsigned)nb1, k), dim3(KZG_T), 0, st, nullptr, n, pows, 0, nullptr, 0u, v1, nullptr, nullptr,
+                       reinterpret_cast<const void* const*>(d_tab), (uint64_t)0, nb1);
+    const BnFr28* tops = v1;
+    uint64_t top_stride = nb1;
+    if (nb1 > 1) {
+      hipLaunchKernelGGL((k_kzg_scan<false, false, false>), dim3((unsigned)nb2, k), dim3(KZG_T), 0, st, v1, nb1, pows, 10, nullptr, 0u, v2, nullptr, nullptr,
+                         nullptr, nb1, nb2);
+      tops = v2, top_stride = nb2;
+      if (nb2 > 1) {
+        hipLaunchKernelGGL((k_kzg_scan<false, false, false>), dim3(1, k), dim3(KZG_T), 0, st, v2, nb2, pows, 20, nullptr, 0u, v3, nullptr, nullptr, nullptr,
+                           nb2, (uint64_t)1);
+        tops = v3, top_stride = 1;
+      }
+    }
+    hipLaunchKernelGGL(k_kzg_evals_out, dim3((k + 63) / 64), dim3(64), 0, st, tops, top_stride, k, d_ev);
+    hipLaunchKernelGGL(k_kzg_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const void* const*>(d_tab), k, n,
+                       BnFr28::from_canonical(vw), d_f);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_evals, d_ev, 32 * (size_t)k, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  int32_t rc = e == hipSuccess ? ZKMI_OK : ctx->hip_fail(e, "bn254 kzg open (many)");
+  uint8_t f_eval[32];
+  if (rc == ZKMI_OK) rc = kzg_open_core(ctx, d_f, n, zw, srs, nullptr, f_eval, out_proof);
+  (void)hipFree(buf);
+  return rc;
 }
 
 // Grand product of a permutation argument: d_out[0] = 1, d_out[i] = prod_{j < i} num_j / den_j (i < n), out_total = the
