@@ -699,6 +699,9 @@ def main():
             "distinct_witnesses_per_rank": min(args.steps, n_distinct),
             "fresh_r_s_per_proof": True,
             "proofs_in_flight_per_gpu": 3,
+            # nothing is skipped: all five MSMs run in full; what is shared is the REDUCTION of the three queries that only
+            # ever appear summed in C -- the proof bytes equal the oracle's prover's
+            "msm_schedule": "A | B1 (over r*z) + L + H reduced together | B2 (G2)",
         },
         "verified_by_pairing": bool(verified),
         "setup_seconds": setup_s,
