@@ -56,6 +56,12 @@ python3 bench.py --workload msm26 --msm-pmc-summary "$DST/pmc_summary_msm26_step
 gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/bench_prove.c -Lzk-apps_amd -lzkmi -L/opt/rocm/lib -lamdhip64 \
   -Wl,-rpath,$PWD/zk-apps_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/bench_prove && \
   ZKMI_BACKTRACE=1 timeout 900 /tmp/bench_prove --log-n 20 --proofs 20 --warmup 2 --churn ${CHURN_OPS:-2000} > "$DST/c_bench_native_runtime.log" 2>&1
+# 5. the next-row kernels on the same library: BN254 MSM / NTT / KZG commitment, opening, grand product;
+#    Poseidon-5; SHA-256; assignment generation (DESIGN.md 4.5-4.8 quote this file)
+mkdir -p "$DST/experiments"
+for S in "bn254_timing.py 20" poseidon_timing.py sha_timing.py witness_timing.py; do
+  echo "== python3 scripts/$S"; timeout 300 python3 scripts/$S 2>&1 | grep -v amdgpu.ids; echo
+done > "$DST/experiments/next_rows_timing.txt"
 # gpurun only brings gpurun_out/ back: leave a copy of the summaries there
 mkdir -p "gpurun_out/profiles_$ROUND" && cp -r "$DST/." "gpurun_out/profiles_$ROUND/"
 ls -la "$DST"
