@@ -134,7 +134,14 @@ int32_t zkmi_msm_g1_combine(const uint8_t* windows_affine, uint32_t n_ranks, uin
  *   zkmi_comm_from_nccl   wrap an ncclComm_t the host created itself (same RCCL instance; not destroyed with the handle)
  *   zkmi_msm_g1_allgather_combine  this rank's n terms (plan from plan_n = the GLOBAL number of terms, equal on all ranks),
  *                         all-gather, combination: the FULL result on every rank.  Collective: all ranks call it.
- * ZKMI_ERR_RCCL: RCCL not found, or a call failed (zkmi_last_error). */
+ * ZKMI_ERR_RCCL: RCCL not found, or a call failed (zkmi_last_error).
+ * Failure semantics of the two collectives: arguments, the plan and every allocation are checked before anything is
+ * launched, so ZKMI_ERR_BAD_ARG never leaves the other ranks waiting PROVIDED all ranks pass consistent arguments (the same
+ * plan_n, n <= their bases).  After ZKMI_ERR_HIP / ZKMI_ERR_RCCL from a collective the communicator is unusable and the
+ * peers may be blocked inside ncclAllGather: abort all ranks (as after any failed NCCL collective).
+ * Lifetime: zkmi_comm_destroy may run before or after zkmi_ctx_destroy of the context the handle was made on.
+ * Environment: ZKMI_RCCL_LIB=<file> makes that file the only RCCL candidate (deployments with RCCL outside the loader's
+ * search path; a missing file yields ZKMI_ERR_RCCL). */
 typedef struct zkmi_comm zkmi_comm;
 int32_t zkmi_comm_unique_id(uint8_t out_id[128]);
 int32_t zkmi_comm_init(zkmi_ctx* ctx, uint32_t n_ranks, uint32_t rank, const uint8_t id[128], zkmi_comm** out);
@@ -155,6 +162,17 @@ int32_t zkmi_msm_g1_window_range_dev(zkmi_ctx* ctx, const void* d_scalars, uint6
                                      uint32_t* out_nwin_total, uint32_t* out_window_bits);
 int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
                                            const zkmi_bases_g1* bases, uint8_t out_affine[96]);
+
+/* What every rank computes AFTER the all-gather, on caller-supplied slots (host arithmetic; no GPU, no RCCL): partials =
+ * n_ranks slots of XYZZ points in the form the reductions leave in HBM (4 x 48-byte LE Montgomery coordinates x, y, zz, zzz;
+ * all-zero zz = infinity).  window_split = 0: rank k's slot holds the partial sums of ALL windows over its points (the
+ * point split); 1: the partial sums of its windows [k nwin / R, (k + 1) nwin / R).  zkmi_msm_exchange_layout reports the
+ * slot geometry for a plan of plan_n terms: out[0] windows, [1] partial sums per window, [2] points per slot (point
+ * split), [3] points per slot (window split over n_ranks), [4] bytes per point, [5] window bits, [6] log2 of the
+ * reduction's segment length, [7] log2 of the partitions the partial top window is spread over. */
+int32_t zkmi_msm_g1_combine_partials(const uint8_t* partials, uint32_t n_ranks, uint64_t plan_n, int32_t window_split,
+                                     uint8_t out_affine[96]);
+int32_t zkmi_msm_exchange_layout(uint64_t plan_n, uint32_t n_ranks, uint32_t out[8]);
 
 /* Same split driven from ONE process holding one ctx per GPU (SURVEY.md §8b
  * "zkmi_msm_g1_multi", BASELINE config 3): device d holds counts[d] scalars at
@@ -400,6 +418,12 @@ int32_t zkmi_pk_load(zkmi_ctx* ctx, const zkmi_r1cs* r1cs, const uint8_t alpha_g
 int32_t zkmi_pk_free(zkmi_pk* pk);
 int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint32_t* log_n);
 int32_t zkmi_pk_export_g1_elems(const zkmi_pk* pk, uint8_t out_beta_g1[96], uint8_t out_delta_g1[96]);
+/* What the prover learned from the last finished proof (group) of this key, and what it decided from it: out[0] = 1 while
+ * the B1 MSM is folded into the reduction L and H share (taken over r z; only while the assignments fill at least 9 in 10
+ * of their digits -- a witness of bits is cheaper through the sort of z), out[1] = non-zero digits the digit sort of that
+ * proof's (group's) assignment(s) placed, out[2] = digits a completely dense assignment would have placed.  Diagnostic:
+ * the proof bytes do not depend on it. */
+int32_t zkmi_pk_schedule_state(const zkmi_pk* pk, uint64_t out[3]);
 /* export one query of a resident key (0=a,1=b_g1,2=b_g2,3=h,4=l) in wire format */
 int32_t zkmi_pk_export_query(zkmi_ctx* ctx, const zkmi_pk* pk, int32_t which, uint64_t first, uint64_t count, uint8_t* out);
 /* witness -> proof.  z = full assignment (n_vars x 32 B, z[0] = 1); r, s =

@@ -85,6 +85,7 @@ extern "C" {
                             out_pk: *mut *mut zkmi_pk, out_vk: *mut u8, vk_cap: u64) -> i32;
     pub fn zkmi_ark_vk_read(buf: *const u8, len: u64, compressed: i32, out_vk: *mut u8, vk_cap: u64, out_n_pub: *mut u32, out_consumed: *mut u64) -> i32;
     pub fn zkmi_pk_shape(pk: *const zkmi_pk, n_vars: *mut u32, n_pub: *mut u32, log_n: *mut u32) -> i32;
+    pub fn zkmi_pk_schedule_state(pk: *const zkmi_pk, out: *mut u64) -> i32;
     pub fn zkmi_pk_free(pk: *mut zkmi_pk) -> i32;
 
     // witness -> proof (rows a6-a10), proof check (row a11)
@@ -160,4 +161,7 @@ extern "C" {
     pub fn zkmi_comm_destroy(comm: *mut zkmi_comm) -> i32;
     pub fn zkmi_msm_g1_allgather_combine(ctx: *mut zkmi_ctx, comm: *mut zkmi_comm, d_scalars: *const core::ffi::c_void, n: u64,
                                          bases: *const zkmi_bases_g1, plan_n: u64, out_affine: *mut u8) -> i32;
+    // what every rank computes behind the all-gather, on caller-supplied slots (host arithmetic), and the slot geometry
+    pub fn zkmi_msm_g1_combine_partials(partials: *const u8, n_ranks: u32, plan_n: u64, window_split: i32, out_affine: *mut u8) -> i32;
+    pub fn zkmi_msm_exchange_layout(plan_n: u64, n_ranks: u32, out: *mut u32) -> i32;
 }

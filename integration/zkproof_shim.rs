@@ -51,7 +51,7 @@ const FR_MODULUS_LE: [u8; 32] = [
     0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
     0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73,
 ];
-/// one element UNIFORM on [0, r): rejection sampling of 255-bit strings (acceptance 0.45), as Fr::rand does --
+/// one element UNIFORM on [0, r): rejection sampling of 255-bit strings (acceptance r / 2^255, about 0.905), as Fr::rand does --
 /// Groth16's zero-knowledge argument needs the blinding scalars uniform on the whole field, and clearing the top two
 /// bits would only ever reach the lower 55 % of it
 fn fresh_fr() -> [u8; 32] {

@@ -287,6 +287,85 @@ def test_msm_window_combine_host(zk):
     assert zk.msm_g1_combine(wins, 2, nwin, c) == ec.g1_to_bytes(ec.g1_mul(exp))
 
 
+def _xyzz_host_bytes(pt, lam):
+    """An affine oracle point as the XYZZ value (x lam^2, y lam^3, lam^2, lam^3) in the library's host form: four 48-byte
+    little-endian Montgomery residues (R = 2^384); None = infinity = zeros."""
+    if pt is None:
+        return bytes(192)
+    x, y = pt
+    mont = lambda v: ((v % ec.P) * pow(2, 384, ec.P) % ec.P).to_bytes(48, "little")
+    l2, l3 = lam * lam % ec.P, lam * lam * lam % ec.P
+    return mont(x * l2) + mont(y * l3) + mont(l2) + mont(l3)
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 8])
+def test_exchange_combine_at_the_real_slot_layout(zk, n_ranks):
+    """What every rank computes behind ncclAllGather (csrc/comm.hip), at the slot geometry of BASELINE config 3 -- the plan of
+    2^26 terms: 13 windows of 20 bits, 16 partial sums per window, the partial top window spread over 16 partitions --
+    with up to 8 synthetic ranks, in both partitions (points / windows).  The slots hold known multiples of the
+    generator in non-trivial XYZZ form (and some points at infinity); the expected scalar follows from the reduction's
+    definition: window = job_0 + 2^seg_log * sum_j 2^j job_(1+j), the top window without its top_spread_log top bits."""
+    plan_n = 1 << 26
+    lay = zk.msm_exchange_layout(plan_n, n_ranks)
+    assert (lay["nwin"], lay["per_window"], lay["c"], lay["seg_log"], lay["top_spread_log"]) == (13, 16, 20, 4, 4)
+    assert lay["slot_pts_points"] == 13 * 16 and lay["point_bytes"] == 192
+    nwin, per, c, seg_log = lay["nwin"], lay["per_window"], lay["c"], lay["seg_log"]
+    rng = ec.SplitMix64(0x5A4B0003 + n_ranks)
+    small = lambda: rng.fr() & ((1 << 48) - 1)
+
+    def window_value(w, jobs):
+        bits = per - 1 - (lay["top_spread_log"] if w == nwin - 1 else 0)
+        return jobs[0] + (1 << seg_log) * sum(jobs[1 + j] << j for j in range(bits))
+
+    # --- point split: every rank holds all windows
+    total, slots = 0, []
+    for k in range(n_ranks):
+        for w in range(nwin):
+            jobs = [small() if (k + w + j) % 7 else 0 for j in range(per)]
+            total += window_value(w, jobs) << (c * w)
+            slots += [_xyzz_host_bytes(ec.g1_mul(v) if v else None, 2 + rng.fr() % ec.P) for v in jobs]
+    got = zk.msm_g1_combine_partials(b"".join(slots), n_ranks, plan_n, window_split=False)
+    assert got == ec.g1_to_bytes(ec.g1_mul(total % ec.R))
+    # --- window split: rank k holds windows [k nwin / R, (k + 1) nwin / R) at the head of an equal-sized slot
+    first = lambda k: k * nwin // n_ranks
+    max_w = max(first(k + 1) - first(k) for k in range(n_ranks))
+    assert lay["slot_pts_windows"] == per * max_w
+    total, slots = 0, []
+    for k in range(n_ranks):
+        mine = []
+        for w in range(first(k), first(k + 1)):
+            jobs = [small() if (k + w + j) % 5 else 0 for j in range(per)]
+            total += window_value(w, jobs) << (c * w)
+            mine += [_xyzz_host_bytes(ec.g1_mul(v) if v else None, 2 + rng.fr() % ec.P) for v in jobs]
+        # whatever lies behind a rank's own windows is ignored by the readers: fill it with a valid but wrong point
+        mine += [_xyzz_host_bytes(ec.g1_mul(12345), 1)] * (per * max_w - len(mine))
+        slots += mine
+    got = zk.msm_g1_combine_partials(b"".join(slots), n_ranks, plan_n, window_split=True)
+    assert got == ec.g1_to_bytes(ec.g1_mul(total % ec.R))
+
+
+def test_rccl_not_found_is_an_error_code_not_a_crash(tmp_path):
+    """include/zkmi.h: a host without RCCL loads the library and gets ZKMI_ERR_RCCL from the zkmi_comm_* calls only
+    (round 4 dereferenced a null dlerror() here).  Fresh process: the lookup is cached."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from zkmi_loader import load_pkg\n"
+        "pkg = load_pkg(); zk = pkg.Zkmi()\n"
+        "try:\n"
+        "    zk.comm_unique_id()\n"
+        "except pkg.ZkmiError as e:\n"
+        "    print('code', e.code)\n"
+        "print('plan', zk.msm_plan_query(1 << 20)[0])\n" % ROOT
+    )
+    env = dict(os.environ, ZKMI_RCCL_LIB=str(tmp_path / "no_such_librccl.so"), ZKMI_SHARE_TORCH_HIP="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "code -9" in out.stdout and "plan 16" in out.stdout, out.stdout
+
+
 # ------------------------------------------------ mocked_zk mirror (row a12)
 def _tokens():
     return [bytes([228] * 32), bytes(32)]  # MOCKED_TOKEN, shielder/mocked_zk/src/lib.rs:18

@@ -18,6 +18,7 @@ ERR = {
     -6: "AccountUpdateError",
     -7: "OperationCombineError",
     -8: "UNSATISFIED",
+    -9: "RCCL",
 }
 PHASES = {
     "msm_sort": 0,
@@ -252,6 +253,20 @@ class Zkmi:
     def msm_g1_combine(self, windows, n_ranks, nwin, window_bits):
         out = (C.c_uint8 * 96)()
         self._chk(self.lib.zkmi_msm_g1_combine(_buf(windows), C.c_uint32(n_ranks), C.c_uint32(nwin), C.c_uint32(window_bits), out))
+        return bytes(out)
+
+    def msm_exchange_layout(self, plan_n, n_ranks=1):
+        """zkmi_msm_exchange_layout: dict of the slot geometry of the two RCCL exchanges for a plan of plan_n terms."""
+        out = (C.c_uint32 * 8)()
+        self._chk(self.lib.zkmi_msm_exchange_layout(C.c_uint64(plan_n), C.c_uint32(n_ranks), out))
+        keys = ("nwin", "per_window", "slot_pts_points", "slot_pts_windows", "point_bytes", "c", "seg_log", "top_spread_log")
+        return dict(zip(keys, out))
+
+    def msm_g1_combine_partials(self, partials, n_ranks, plan_n, window_split=False):
+        """zkmi_msm_g1_combine_partials: the host combination behind the all-gather, on caller-supplied slots."""
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_combine_partials(_buf(partials), C.c_uint32(n_ranks), C.c_uint64(plan_n),
+                                                        C.c_int32(1 if window_split else 0), out))
         return bytes(out)
 
     def msm_g1_multi(self, ctxs, dptrs, counts, bases):
@@ -948,6 +963,13 @@ class ProvingKey:
         out = (C.c_uint8 * (w * count))()
         self.ctx._chk(self.ctx.lib.zkmi_pk_export_query(self.ctx.h, self.h, C.c_int32(which), C.c_uint64(first), C.c_uint64(count), out))
         return bytes(out)
+
+    def schedule_state(self):
+        """zkmi_pk_schedule_state: (B1 folded into the L + H reduction?, non-zero digits of the last finished proof's
+        assignment(s), digits a dense assignment would have placed)."""
+        out = (C.c_uint64 * 3)()
+        self.ctx._chk(self.ctx.lib.zkmi_pk_schedule_state(self.h, out))
+        return bool(out[0]), int(out[1]), int(out[2])
 
     def free(self):
         if self.h:

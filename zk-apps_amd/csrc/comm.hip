@@ -11,6 +11,7 @@
 // process (the host's own: a communicator handed to zkmi_comm_from_nccl must belong to the library whose ncclAllGather is
 // called on it) or else from librccl.so.1.  A host without RCCL can load the library and use everything but this file.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <new>
@@ -46,12 +47,22 @@ const Rccl& rccl() {
     Rccl x;
     // an RCCL that is already mapped wins (dlopen by SONAME returns the loaded object; RTLD_NOLOAD first so that a process
     // that brought its own copy under another path is honoured through the global scope as well)
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // ZKMI_RCCL_LIB names the library file to use and nothing else is tried (a deployment whose RCCL lives outside the
+    // loader's search path; the test-suite points it at a missing file -- ZKMI_ERR_RCCL -- and at an in-process all-gather
+    // double that lets several ranks share one GPU, which RCCL itself refuses)
+    void* h = nullptr;
+    const char* forced = getenv("ZKMI_RCCL_LIB");
+    if (forced && *forced) {
+      h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+      if (!h && dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!h) {
-      x.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "librccl.so.1");
+      const char* de = dlerror();  // (one call: dlerror() clears the message it returns)
+      x.why = std::string("RCCL not found: ") + (de ? de : (forced && *forced) ? forced : "librccl.so.1");
       return x;
     }
     x.get_unique_id = reinterpret_cast<fn_get_unique_id>(dlsym(h, "ncclGetUniqueId"));
@@ -69,7 +80,8 @@ const Rccl& rccl() {
 }  // namespace
 
 struct zkmi_comm {
-  zkmi_ctx* ctx = nullptr;
+  zkmi_ctx* ctx = nullptr;   // identity check only after creation (the context may be destroyed first: `device` is what destroy uses)
+  int device = 0;
   nccl_comm_t comm = nullptr;
   uint32_t n_ranks = 0, rank = 0;
   bool owned = false;         // created by zkmi_comm_init (destroyed with the handle) / borrowed from the host
@@ -78,6 +90,55 @@ struct zkmi_comm {
 };
 
 using namespace zkmi;
+
+// room for the gathered slots (grows, never shrinks)
+static hipError_t comm_reserve(zkmi_comm* comm, uint64_t bytes) {
+  if (comm->gather_cap >= bytes) return hipSuccess;
+  if (comm->d_gather) (void)hipFree(comm->d_gather);
+  comm->d_gather = nullptr;
+  comm->gather_cap = 0;
+  const hipError_t e = hipMalloc(&comm->d_gather, bytes);
+  if (e == hipSuccess) comm->gather_cap = bytes;
+  return e;
+}
+
+// The combination every rank of a POINT split performs on the gathered array: rank k's slot holds the
+// partials_per_msm(plan) sums its reduction wrote (window-major, jobs inside a window); per rank they become one sum per
+// window, the ranks' windows are added, Horner over the windows.  Pure host arithmetic (also behind zkmi_msm_g1_combine_partials,
+// which the CPU suite drives with many synthetic ranks).
+static G1XYZZ combine_rank_partials(const MsmPlan& sp, const G1XYZZ* all, uint32_t n_ranks) {
+  const int pts = MsmEngine<Fq28>::partials_per_msm(sp);
+  std::vector<G1XYZZ> sum(sp.nwin, G1XYZZ::infinity()), win(sp.nwin);
+  for (uint32_t k = 0; k < n_ranks; k++) {
+    MsmEngine<Fq28>::windows_from_partials(sp, all + (size_t)k * pts, win.data());
+    for (int w = 0; w < sp.nwin; w++) sum[w].add(win[w]);
+  }
+  return msm_combine_windows<Fq>(sum.data(), sp.nwin, sp.c);
+}
+
+// The combination of a WINDOW split: rank k's slot (slot_pts points) holds the partials of its windows
+// [k nwin / R, (k + 1) nwin / R), whatever lies behind them in the slot is ignored.
+static uint32_t split_first_window(uint32_t k, uint32_t nwin, uint32_t R) { return (uint32_t)(((uint64_t)k * nwin) / R); }
+static MsmPlan split_sub_plan(const MsmPlan& pl, uint32_t k, uint32_t R) {
+  MsmPlan q = pl;
+  q.nwin_total = pl.nwin;
+  q.win_first = (int)split_first_window(k, (uint32_t)pl.nwin, R);
+  q.nwin = (int)(split_first_window(k + 1, (uint32_t)pl.nwin, R) - split_first_window(k, (uint32_t)pl.nwin, R));
+  return q;
+}
+static uint32_t split_max_windows(const MsmPlan& pl, uint32_t R) {
+  uint32_t max_w = 0;
+  for (uint32_t k = 0; k < R; k++) max_w = std::max(max_w, (uint32_t)split_sub_plan(pl, k, R).nwin);
+  return max_w;
+}
+static G1XYZZ combine_window_slots(const MsmPlan& pl, const G1XYZZ* all, uint64_t slot_pts, uint32_t R) {
+  std::vector<G1XYZZ> win((size_t)pl.nwin, G1XYZZ::infinity());
+  for (uint32_t k = 0; k < R; k++) {
+    const MsmPlan q = split_sub_plan(pl, k, R);
+    if (q.nwin > 0) MsmEngine<Fq28>::windows_from_partials(q, all + slot_pts * k, win.data() + q.win_first);
+  }
+  return msm_combine_windows<Fq>(win.data(), pl.nwin, pl.c);
+}
 
 static int32_t rccl_fail(zkmi_ctx* ctx, int code, const char* where) {
   const Rccl& r = rccl();
@@ -114,6 +175,7 @@ int32_t zkmi_comm_init(zkmi_ctx* ctx, uint32_t n_ranks, uint32_t rank, const uin
     return ZKMI_ERR_BAD_ARG;
   }
   k->ctx = ctx;
+  k->device = ctx->device;
   k->comm = c;
   k->n_ranks = n_ranks;
   k->rank = rank;
@@ -130,6 +192,7 @@ int32_t zkmi_comm_from_nccl(zkmi_ctx* ctx, void* nccl_comm, uint32_t n_ranks, ui
   zkmi_comm* k = new (std::nothrow) zkmi_comm();
   if (!k) return ZKMI_ERR_BAD_ARG;
   k->ctx = ctx;
+  k->device = ctx->device;
   k->comm = nccl_comm;
   k->n_ranks = n_ranks;
   k->rank = rank;
@@ -140,7 +203,7 @@ int32_t zkmi_comm_from_nccl(zkmi_ctx* ctx, void* nccl_comm, uint32_t n_ranks, ui
 
 int32_t zkmi_comm_destroy(zkmi_comm* comm) {
   if (!comm) return ZKMI_ERR_BAD_ARG;
-  if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+  (void)hipSetDevice(comm->device);  // (not through comm->ctx: the context may already be gone)
   if (comm->d_gather) (void)hipFree(comm->d_gather);
   if (comm->owned && comm->comm && rccl().ok) (void)rccl().comm_destroy(comm->comm);
   delete comm;
@@ -158,9 +221,17 @@ int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void
   const Rccl& r = rccl();
   if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
   if (plan_n < n) plan_n = n;
+  // Everything that can fail on THIS rank alone -- arguments, the plan's fit, every allocation -- is settled before the
+  // first launch: a rank that returned between its sort and the collective would leave its peers blocked in ncclAllGather.
+  // (What can still fail below is a HIP or RCCL error: the communicator is unusable after one, see zkmi.h.)
+  const MsmPlan pl = msm_make_plan(plan_n);  // one window width on every rank
+  const int pts = MsmEngine<Fq28>::partials_per_msm(pl);
+  if (pts > (int)MsmEngine<Fq28>::SLOT_PTS) return ctx->fail(ZKMI_ERR_BAD_ARG, "plan has more partial sums than a slot holds");
+  const uint64_t bytes = sizeof(G1XYZZ) * (uint64_t)pts;
   ZK_HIP(ctx, ctx->sort.reserve(plan_n));
   ZK_HIP(ctx, ctx->g1.reserve(plan_n));
-  const MsmPlan pl = msm_make_plan(plan_n);  // one window width on every rank
+  ZK_HIP(ctx, comm_reserve(comm, bytes * comm->n_ranks));
+  std::vector<G1XYZZ> all((size_t)pts * comm->n_ranks);
   ctx->sort.plan_override = pl.c;
   const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
   ctx->sort.plan_override = 0;
@@ -168,30 +239,16 @@ int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void
   ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   // the reduction (slot 0, on stream_aux) has left partials_per_msm points in the device array `partial`
   const MsmPlan& sp = ctx->g1.slot_plan[0];
-  const int pts = MsmEngine<Fq28>::partials_per_msm(sp);
-  const uint64_t bytes = sizeof(G1XYZZ) * (uint64_t)pts;
-  if (comm->gather_cap < bytes * comm->n_ranks) {
-    if (comm->d_gather) (void)hipFree(comm->d_gather);
-    comm->d_gather = nullptr;
-    comm->gather_cap = 0;
-    ZK_HIP(ctx, hipMalloc(&comm->d_gather, bytes * comm->n_ranks));
-    comm->gather_cap = bytes * comm->n_ranks;
-  }
+  if (MsmEngine<Fq28>::partials_per_msm(sp) != pts) return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sort planned another window set");
   const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
   if (rc != 0) {
     (void)ctx->drain();
     return rccl_fail(ctx, rc, "ncclAllGather");
   }
-  std::vector<G1XYZZ> all((size_t)pts * comm->n_ranks);
   ZK_HIP(ctx, hipMemcpyAsync(all.data(), comm->d_gather, bytes * comm->n_ranks, hipMemcpyDeviceToHost, ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<G1XYZZ> sum(sp.nwin, G1XYZZ::infinity()), win(sp.nwin);
-  for (uint32_t k = 0; k < comm->n_ranks; k++) {
-    MsmEngine<Fq28>::windows_from_partials(sp, all.data() + (size_t)k * pts, win.data());
-    for (int w = 0; w < sp.nwin; w++) sum[w].add(win[w]);
-  }
-  const G1XYZZ res = msm_combine_windows<Fq>(sum.data(), sp.nwin, sp.c);
+  const G1XYZZ res = combine_rank_partials(sp, all.data(), comm->n_ranks);
   g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }
@@ -207,23 +264,17 @@ int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const
   if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
   const MsmPlan pl = msm_make_plan(n);
   const uint32_t R = comm->n_ranks, nwin = (uint32_t)pl.nwin;
-  auto first_of = [&](uint32_t k) { return (uint32_t)(((uint64_t)k * nwin) / R); };
-  const uint32_t w0 = first_of(comm->rank), w1 = first_of(comm->rank + 1);
-  uint32_t max_w = 0;
-  for (uint32_t k = 0; k < R; k++) max_w = std::max(max_w, first_of(k + 1) - first_of(k));
+  const uint32_t w0 = split_first_window(comm->rank, nwin, R), w1 = split_first_window(comm->rank + 1, nwin, R);
+  const uint32_t max_w = split_max_windows(pl, R);
+  const int per_window = MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin;
+  const uint64_t slot_pts = (uint64_t)per_window * max_w;
+  const uint64_t slot_bytes = sizeof(G1XYZZ) * slot_pts;
+  // (as in zkmi_msm_g1_allgather_combine: nothing between the first launch and the collective can fail on this rank alone)
+  if (slot_pts > (uint64_t)MsmEngine<Fq28>::SLOT_PTS) return ctx->fail(ZKMI_ERR_BAD_ARG, "plan has more partial sums than a slot holds");
   ZK_HIP(ctx, ctx->sort.reserve(n));
   ZK_HIP(ctx, ctx->g1.reserve(n));
-  // sub-plan of a rank: the plan with its window range (what the sort of that rank runs)
-  auto sub_plan = [&](uint32_t k) {
-    MsmPlan q = pl;
-    q.nwin_total = pl.nwin;
-    q.win_first = (int)first_of(k);
-    q.nwin = (int)(first_of(k + 1) - first_of(k));
-    return q;
-  };
-  const int per_window = MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin;
-  const uint64_t slot_bytes = sizeof(G1XYZZ) * (uint64_t)per_window * max_w;
-  if ((uint64_t)per_window * max_w > (uint64_t)MsmEngine<Fq28>::SLOT_PTS) return ZKMI_ERR_BAD_ARG;
+  ZK_HIP(ctx, comm_reserve(comm, slot_bytes * R));
+  std::vector<G1XYZZ> all(slot_pts * R);
   if (w1 > w0) {
     ctx->sort.win_first = (int)w0;
     ctx->sort.win_count = (int)(w1 - w0);
@@ -232,31 +283,60 @@ int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const
     if (e != hipSuccess) return ctx->hip_fail(e, "sort");
     ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
   }
-  if (comm->gather_cap < slot_bytes * R) {
-    if (comm->d_gather) (void)hipFree(comm->d_gather);
-    comm->d_gather = nullptr;
-    comm->gather_cap = 0;
-    ZK_HIP(ctx, hipMalloc(&comm->d_gather, slot_bytes * R));
-    comm->gather_cap = slot_bytes * R;
-  }
   // (a rank's slot is the head of its `partial` array: whatever lies behind its own windows is ignored by the readers)
   const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)slot_bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
   if (rc != 0) {
     (void)ctx->drain();
     return rccl_fail(ctx, rc, "ncclAllGather");
   }
-  std::vector<uint8_t> all(slot_bytes * R);
   ZK_HIP(ctx, hipMemcpyAsync(all.data(), comm->d_gather, slot_bytes * R, hipMemcpyDeviceToHost, ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<G1XYZZ> win(nwin, G1XYZZ::infinity());
-  for (uint32_t k = 0; k < R; k++) {
-    const MsmPlan q = sub_plan(k);
-    if (q.nwin > 0)
-      MsmEngine<Fq28>::windows_from_partials(q, reinterpret_cast<const G1XYZZ*>(all.data() + slot_bytes * k), win.data() + q.win_first);
-  }
-  const G1XYZZ res = msm_combine_windows<Fq>(win.data(), (int)nwin, pl.c);
+  const G1XYZZ res = combine_window_slots(pl, all.data(), slot_pts, R);
   g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+// The two host combinations above on caller-supplied slots (no GPU, no RCCL): what every rank computes after the all-gather.
+// partials = n_ranks slots of XYZZ points in the library's host form (4 x 48-byte Montgomery coordinates, the bytes the
+// reductions leave in HBM).  window_split = 0: point split, a slot = partials_per_msm(plan of plan_n) points;
+// window_split = 1: a slot = (partials per window) x (most windows any rank owns) points.
+int32_t zkmi_msm_g1_combine_partials(const uint8_t* partials, uint32_t n_ranks, uint64_t plan_n, int32_t window_split,
+                                     uint8_t out_affine[96]) {
+  if (!partials || !out_affine || n_ranks == 0 || n_ranks > 4096 || plan_n == 0 || plan_n > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
+  const MsmPlan pl = msm_make_plan(plan_n);
+  std::vector<G1XYZZ> all;
+  G1XYZZ res;
+  if (!window_split) {
+    const size_t pts = (size_t)MsmEngine<Fq28>::partials_per_msm(pl);
+    all.resize(pts * n_ranks);
+    memcpy(all.data(), partials, sizeof(G1XYZZ) * all.size());
+    res = combine_rank_partials(pl, all.data(), n_ranks);
+  } else {
+    const uint64_t slot_pts = (uint64_t)(MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin) * split_max_windows(pl, n_ranks);
+    all.resize(slot_pts * n_ranks);
+    memcpy(all.data(), partials, sizeof(G1XYZZ) * all.size());
+    res = combine_window_slots(pl, all.data(), slot_pts, n_ranks);
+  }
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
+/* slot geometry of the two exchanges for a plan of plan_n terms: out[0] = windows, out[1] = partial sums per window,
+ * out[2] = points per slot (point split), out[3] = points per slot (window split over n_ranks), out[4] = bytes per point,
+ * out[5] = window bits, out[6] = log2 of the reduction's segment length, out[7] = top_spread_log */
+int32_t zkmi_msm_exchange_layout(uint64_t plan_n, uint32_t n_ranks, uint32_t out[8]) {
+  if (!out || plan_n == 0 || plan_n > MSM_MAX_TERMS || n_ranks == 0) return ZKMI_ERR_BAD_ARG;
+  const MsmPlan pl = msm_make_plan(plan_n);
+  const int pts = MsmEngine<Fq28>::partials_per_msm(pl);
+  out[0] = (uint32_t)pl.nwin;
+  out[1] = (uint32_t)(pts / pl.nwin);
+  out[2] = (uint32_t)pts;
+  out[3] = (uint32_t)(pts / pl.nwin) * split_max_windows(pl, n_ranks);
+  out[4] = (uint32_t)sizeof(G1XYZZ);
+  out[5] = (uint32_t)pl.c;
+  out[6] = (uint32_t)pl.seg_log;
+  out[7] = (uint32_t)pl.top_spread_log;
   return ZKMI_OK;
 }
 

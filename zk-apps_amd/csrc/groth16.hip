@@ -321,6 +321,7 @@ struct zkmi_pk {
   // proofs/s for 2^20 bit constraints: profiles/r04/experiments/rb1_fold_ab.txt).  The proof bytes do not depend on it.
   uint32_t* h_zent = nullptr;
   mutable bool fold_dense = true;
+  mutable uint64_t last_entries = 0, last_full = 0;  // what note_density() last read / compared it with (zkmi_pk_schedule_state)
   ~zkmi_pk() {
     if (device >= 0) (void)hipSetDevice(device);  // the key's buffers live on its context's device (the ctx may be gone)
     (void)hipDeviceSynchronize();  // nothing queued by an earlier call may still read the key or write its pinned flags
@@ -711,6 +712,14 @@ int32_t zkmi_pk_shape(const zkmi_pk* pk, uint32_t* n_vars, uint32_t* n_pub, uint
   if (n_vars) *n_vars = pk->n_vars;
   if (n_pub) *n_pub = pk->n_pub;
   if (log_n) *log_n = pk->log_n;
+  return ZKMI_OK;
+}
+
+int32_t zkmi_pk_schedule_state(const zkmi_pk* pk, uint64_t out[3]) {
+  if (!pk || !out) return ZKMI_ERR_BAD_ARG;
+  out[0] = (pk->d_rz[0] != nullptr && pk->fold_dense) ? 1 : 0;
+  out[1] = pk->last_entries;
+  out[2] = pk->last_full;
   return ZKMI_OK;
 }
 
@@ -1142,7 +1151,12 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
   // called once the A MSM of this slot is in (its accumulation ran behind the digit sort of z and k_entries_to_host)
   auto note_density = [&]() {
     if (!pk->d_rz[par]) return;
-    const uint64_t full = (uint64_t)(pk->n_vars - 1) * G * (uint64_t)ctx->g1.slot_plan[s0].ndigits;
+    // digit positions that can be non-zero: the top one is empty when the digit width divides 255 (msm_make_plan_shared)
+    const MsmPlan& zp = ctx->g1.slot_plan[s0];
+    const int live = zp.ndigits - ((zp.ndigits - 1) * zp.c >= 255 ? 1 : 0);
+    const uint64_t full = (uint64_t)(pk->n_vars - 1) * G * (uint64_t)live;
+    pk->last_entries = pk->h_zent[par];
+    pk->last_full = full;
     pk->fold_dense = 10ull * pk->h_zent[par] >= 9ull * full;
   };
   const bool merged_b1 = ctx->h_mode[par] == zkmi_ctx::H_INTO_LB;             // acc_h arrives as r * B1 + L + H

@@ -400,8 +400,10 @@ k_fpart_scan_rows(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t NP, uin
   if (lane == 63) fpart[NP + q] = incl;
 }
 // one workgroup: fpart[q] = first record slot of partition q (exclusive prefix of the totals fpart[NP + q])
+// It also leaves the sort's record count where the other sort paths leave their per-partition totals: part_total[0] = all
+// records, part_total[1 .. P) = 0 (the prover's k_entries_to_host sums the P words: the non-zero digits of the assignment)
 __global__ void __launch_bounds__(1024)
-k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart) {
+k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restrict__ part_total, uint32_t P) {
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (NP + 1023u) / 1024u;
@@ -420,6 +422,7 @@ k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart) {
     fpart[q] = run;
     run += fpart[NP + q];
   }
+  if (tid < P) part_total[tid] = tid == 0 ? part[1023] : 0u;
 }
 
 // one workgroup per fine partition: histogram -> scan -> count / begin -> scatter (see above).
@@ -1113,7 +1116,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     hipLaunchKernelGGL(k_fpart_pass<false>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                        rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
     hipLaunchKernelGGL(k_fpart_scan_rows, dim3(NP), dim3(64), 0, st, blkcnt, nblk, NP, fpart);
-    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart);
+    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart, part_total, P);
     const bool stage_on = ZK_TUNE("ZKMI_SORT_STAGE", 1) != 0;
     const size_t stage_bytes = sizeof(uint32_t) * 2 * 1024 * (size_t)plan.ndigits;
     if (stage_on && NP <= 512 && plan.ndigits <= (int)FPASS_MAXD)
