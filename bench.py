@@ -344,8 +344,10 @@ def small_domain_rate(z, ctx, relation, log_n=14, count=512):
     ctx.groth16_prove_batch_dev(pk, *[a[:128] for a in args])
     ctx.sync()
     t0 = time.perf_counter()
+    c0 = cpu_seconds()
     proofs = ctx.groth16_prove_batch_dev(pk, *args)
     ctx.sync()
+    cpu_s = cpu_seconds() - c0
     dt = time.perf_counter() - t0
     ok = all(z.groth16_verify(vk, wits[j][32 : 32 * r1.n_pub], proofs[i]) for i, j in ((0, 0), (count - 1, (count - 1) % 2)))
     lat = []  # one proof at a time on an idle GPU (the wallet's case): witness resident -> 192 bytes on the host
@@ -358,6 +360,11 @@ def small_domain_rate(z, ctx, relation, log_n=14, count=512):
     r1.free()
     return {"log_n": log_n, "proofs": count, "proofs_per_s": count / dt, "ms_per_proof": 1e3 * dt / count, "verified_by_pairing": bool(ok),
             "single_proof_latency_ms": 1e3 * sorted(lat)[2],
+            # what the host spends per proof (assembly pool + driving thread + HIP runtime), and what eight such ranks would
+            # ask of the node's CPUs at this rate (the GPU box grants 16: DESIGN.md section 5)
+            "host_cpu_s_per_proof": cpu_s / count,
+            "host_cpus_busy": cpu_s / dt,
+            "host_cpus_busy_x8_ranks": 8 * cpu_s / dt,
             "note": "same entry point (zkmi_groth16_prove_batch_dev); groups of up to 64 proofs share one digit sort, one "
                     "accumulation launch per query and batched NTT passes"}
 
@@ -377,15 +384,27 @@ def spawn_ranks(n_gpus):
     return subprocess.call(cmd, cwd=ROOT)
 
 
+def cpu_seconds():
+    """user + system CPU time of this process, all threads (the library's assembly pool and the HIP runtime's included)"""
+    import resource
+
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return ru.ru_utime + ru.ru_stime
+
+
 def timed_region(ctx, use_dist, fn):
-    """barrier + synchronize on both sides of fn(); returns (result, elapsed seconds = MAX over ranks)."""
+    """barrier + synchronize on both sides of fn(); returns (result, elapsed seconds = MAX over ranks).
+    timed_region.cpu_s = this rank's CPU seconds inside fn() (before the closing barrier: a rank that waits for the others
+    inside an RCCL barrier spins, which is the launcher's cost, not the prover's)."""
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.sync()
     t0 = time.perf_counter()
+    c0 = cpu_seconds()
     res = fn()
     ctx.sync()
+    timed_region.cpu_s = cpu_seconds() - c0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -710,6 +729,10 @@ def main():
         "roofline": roofline,
         "hip_versions": dict(zip(("build", "runtime"), z.hip_versions())),
         "source_revision": source_revision(),
+        # the host side (rank 0): CPUs the process is granted / ranks on the node / threads its assembly pool uses
+        # (csrc/host_pool.hpp), CPU seconds per proof inside the timed region and the CPUs that keeps busy
+        "host": dict(z.host_info(), host_cpu_s_per_proof=timed_region.cpu_s / max(1, args.steps),
+                     host_cpus_busy=timed_region.cpu_s / elapsed if elapsed > 0 else None),
     }
     if rank == 0 and not args.no_secondary:
         # PCIe-inclusive rate (SURVEY.md 8d "end-to-end proofs/s includes witness upload"): the same K proofs from

@@ -56,6 +56,14 @@ typedef struct zkmi_pk zkmi_pk;
 const char* zkmi_version(void);
 /* HIP_VERSION the library was built with / hipRuntimeGetVersion of the runtime it is bound to (diagnostics) */
 int32_t zkmi_hip_versions(int32_t* out_build, int32_t* out_runtime);
+/* The prover's host side: proof assembly (row a10: O(1) scalar multiplications, compression) runs on one persistent pool
+ * of threads per process, sized by what the process may actually use -- min(logical CPUs, affinity mask, cgroup CPU quota)
+ * divided by the processes of the job on this node (LOCAL_WORLD_SIZE, as torch.distributed.run exports it), at most 16.
+ * ZKMI_HOST_THREADS=<n> (environment) or zkmi_set_host_threads override it; n = 0: the library's choice again.
+ * zkmi_host_info: out[0] = CPUs granted, out[1] = local ranks, out[2] = threads per process (the caller's included),
+ * out[3] = pool workers started so far.  The batch prover's driving thread sleeps between polls while it waits. */
+int32_t zkmi_host_info(uint32_t out[4]);
+int32_t zkmi_set_host_threads(uint32_t n);
 int32_t zkmi_device_count(int32_t* out_count);
 int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx);
 int32_t zkmi_ctx_destroy(zkmi_ctx* ctx);
@@ -195,6 +203,8 @@ int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatch
 /* Host-executed self-test of the scalar multiplications of proof assembly (fixed-base tables for delta, joint
  * two-scalar multiplication) against plain double-and-add in G1 and G2; *out_mismatches must be 0. */
 int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
+/* Host self-test of the assembly pool (concurrent callers, every item exactly once); *out_mismatches must be 0. */
+int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint32_t* out_mismatches);
 /* Test hook for the bucket set two MSMs share (the prover's L and H queries): sum_i a_i P_i + sum_i b_i P_i
  * with the first MSM's accumulation left unreduced and the second one's kernels adding INTO its bucket array, one
  * reduction for both (prepared bases run the shared-bucket schedule, others the windowed one).  Scalars in HBM. */

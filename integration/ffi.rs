@@ -85,6 +85,8 @@ extern "C" {
                             out_pk: *mut *mut zkmi_pk, out_vk: *mut u8, vk_cap: u64) -> i32;
     pub fn zkmi_ark_vk_read(buf: *const u8, len: u64, compressed: i32, out_vk: *mut u8, vk_cap: u64, out_n_pub: *mut u32, out_consumed: *mut u64) -> i32;
     pub fn zkmi_pk_shape(pk: *const zkmi_pk, n_vars: *mut u32, n_pub: *mut u32, log_n: *mut u32) -> i32;
+    pub fn zkmi_host_info(out: *mut u32) -> i32;
+    pub fn zkmi_set_host_threads(n: u32) -> i32;
     pub fn zkmi_pk_schedule_state(pk: *const zkmi_pk, out: *mut u64) -> i32;
     pub fn zkmi_pk_free(pk: *mut zkmi_pk) -> i32;
 

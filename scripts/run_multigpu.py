@@ -13,6 +13,11 @@ config 3  one G1 MSM of 2^msm_log_n points split by points: each rank generates 
           the closed form sum_i s_i (G + i Q) = [sum s_i] G + [sum i s_i] Q on every rank.
 
 Rank 0 prints one JSON line per config.  Also runs with world size 1 (plain `python scripts/run_multigpu.py`).
+
+--one-gpu (TEST MODE, for boxes with a single GPU): all ranks share GPU 0 -- which RCCL refuses ("duplicate GPU") -- so
+torch.distributed runs over gloo and libzkmi's exchange over the all-gather double of tests/fake_rccl (ZKMI_RCCL_LIB).
+Everything else is the same code: every rank owns its slice / its proofs, plans from the global size, exchanges its
+partial sums through zkmi_comm and combines.  The lines then say `n_gpus: 1, ranks: N`; timings mean nothing.
 """
 import argparse
 import json
@@ -35,16 +40,29 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--proofs", type=int, default=64)
     ap.add_argument("--msm-log-n", type=int, default=26)
+    ap.add_argument("--one-gpu", action="store_true", help="TEST MODE: all ranks share GPU 0 (gloo + tests/fake_rccl), see the docstring")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    one_gpu = args.one_gpu
+    if one_gpu:
+        local_rank = 0
+        fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+        if not os.path.exists(fake):
+            sys.exit("run_multigpu.py --one-gpu: %s not built (make -C tests/fake_rccl)" % fake)
+        os.environ["ZKMI_RCCL_LIB"] = fake  # read by libzkmi.so when it first resolves RCCL
     torch.cuda.set_device(local_rank)
     if "MASTER_ADDR" not in os.environ:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ddev = torch.device("cpu") if one_gpu else torch.device("cuda")  # where the tensors of torch.distributed collectives live
+    gpus = {"n_gpus": 1 if one_gpu else world, "ranks": world, "one_gpu_world": one_gpu}
 
     from zkmi_loader import load_pkg
     from bench import SplitMix64, relation_and_witness
@@ -73,20 +91,20 @@ def main():
         proofs = ctx.groth16_prove_batch_dev(pk, [d_wits[i % len(d_wits)].data_ptr() for i in range(hi - lo)], rs, ss) if hi > lo else []
         ctx.sync()
         barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ddev)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ok = all(z.groth16_verify(vk, wits[i % len(wits)][32 : 32 * r1.n_pub], p) for i, p in enumerate(proofs))
         # every rank proves the same number of proofs when world divides --proofs; pad for the gather otherwise
         per = (args.proofs + world - 1) // world
         blob = b"".join(proofs) + bytes(192 * (per - len(proofs)))
         gathered = par.allgather_bytes(blob)
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ddev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if rank == 0:
             n_got = sum(1 for g in gathered for k in range(per) if any(g[192 * k : 192 * k + 192]))
-            print(json.dumps({"config": 2, "workload": "%d independent withdraw proofs at N=2^%d over %d GPU(s)" % (args.proofs, args.log_n, world),
+            print(json.dumps({"config": 2, "workload": "%d independent withdraw proofs at N=2^%d over %d rank(s)" % (args.proofs, args.log_n, world),
                               "proofs": args.proofs, "proofs_gathered": n_got, "all_verified": bool(okt.item()),
-                              "seconds": float(dt.item()), "proofs_per_s": args.proofs / float(dt.item()), "n_gpus": world}), flush=True)
+                              "seconds": float(dt.item()), "proofs_per_s": args.proofs / float(dt.item()), **gpus}), flush=True)
         assert okt.item() == 1
         pk.free()
         r1.free()
@@ -105,7 +123,7 @@ def main():
         idx = torch.arange(a, b, dtype=torch.int64, device="cuda")
         s0 = raw.to(torch.int64).sum(dim=0)
         s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0)
-        sums = torch.stack([s0, s1]).contiguous()
+        sums = torch.stack([s0, s1]).contiguous().to(ddev)
         allsums = [torch.empty_like(sums) for _ in range(world)]
         dist.all_gather(allsums, sums)
         tot = wtot = 0
@@ -121,17 +139,17 @@ def main():
         t0 = time.perf_counter()
         got = par.msm_g1_split_dev(z, ctx, raw.data_ptr(), m, bases, n)
         barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ddev)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         G = z.g1_generator()
         Q = z.g1_mul(G, (0xC0FFEE).to_bytes(32, "little"))
         want = z.g1_add(z.g1_mul(G, tot.to_bytes(32, "little")), z.g1_mul(Q, wtot.to_bytes(32, "little")))
-        okt = torch.tensor([1 if got == want else 0], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([1 if got == want else 0], dtype=torch.int32, device=ddev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if rank == 0:
-            print(json.dumps({"config": 3, "workload": "G1 MSM of 2^%d points split by points over %d GPU(s), RCCL all-gather of per-window partials"
+            print(json.dumps({"config": 3, "workload": "G1 MSM of 2^%d points split by points over %d rank(s), RCCL all-gather of per-window partials"
                               % (args.msm_log_n, world), "matches_closed_form_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
-                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
+                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, **gpus}), flush=True)
         assert okt.item() == 1
         # the same exchange behind the C ABI: zkmi_comm (RCCL communicator created from rank 0's 128-byte id) +
         # zkmi_msm_g1_allgather_combine (ncclAllGather of the device-resident partial sums, combination on every rank)
@@ -141,9 +159,9 @@ def main():
         t0 = time.perf_counter()
         got_c = ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
         barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ddev)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        okt = torch.tensor([1 if got_c == want and got_c == got else 0], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([1 if got_c == want and got_c == got else 0], dtype=torch.int32, device=ddev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         # BASELINE configs[3] as worded: the WINDOWS split over the ranks, every rank over ALL points (it needs every scalar
         # and base resident: only run where that fits this script's budget), RCCL all-gather of the window partials
@@ -159,19 +177,19 @@ def main():
             raw_all = torch.cat(parts).contiguous()
             bases_all = ctx.bases_g1_synthetic(n)
             got_w = ctx.msm_g1_window_split_allgather(comm, raw_all.data_ptr(), n, bases_all)
-            okw = torch.tensor([1 if got_w == want else 0], dtype=torch.int32, device="cuda")
+            okw = torch.tensor([1 if got_w == want else 0], dtype=torch.int32, device=ddev)
             dist.all_reduce(okw, op=dist.ReduceOp.MIN)
             bases_all.free()
             del raw_all
         comm.free()
         if rank == 0 and okw is not None:
             print(json.dumps({"config": 3, "workload": "the same MSM with its WINDOWS split over the ranks (zkmi_msm_g1_window_split_allgather)",
-                              "matches_closed_form_on_every_rank": bool(okw.item()), "n_gpus": world}), flush=True)
+                              "matches_closed_form_on_every_rank": bool(okw.item()), **gpus}), flush=True)
         assert okw is None or okw.item() == 1
         if rank == 0:
             print(json.dumps({"config": 3, "workload": "the same MSM through zkmi_msm_g1_allgather_combine (RCCL behind the C ABI)",
                               "matches_closed_form_and_python_path_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
-                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
+                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, **gpus}), flush=True)
         assert okt.item() == 1
         # the same split against PREPARED bases (an SRS serves many MSMs: zkmi_bases_g1_prepare once per rank): every
         # rank's share is then one point (shared-bucket schedule), the ranks all-gather 96 bytes each and add
@@ -185,14 +203,14 @@ def main():
         for p in parts[1:]:
             got2 = z.g1_add(got2, p)
         barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ddev)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        okt = torch.tensor([1 if got2 == want else 0], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([1 if got2 == want else 0], dtype=torch.int32, device=ddev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if rank == 0:
             print(json.dumps({"config": 3, "workload": "the same MSM against prepared bases (digit tables per rank), RCCL all-gather of one point per rank",
                               "matches_closed_form_on_every_rank": bool(okt.item()), "seconds": float(dt.item()),
-                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, "n_gpus": world}), flush=True)
+                              "algorithmic_GBps": 128.0 * n / float(dt.item()) / 1e9, **gpus}), flush=True)
         assert okt.item() == 1
         bases.free()
 

@@ -264,6 +264,36 @@ def test_assembly_scalar_multiplications_selftest(zk):
     assert bad.value == 0
 
 
+def test_host_pool_and_cpu_budget(zk):
+    """The prover's host side (csrc/host_pool.hpp): the persistent assembly pool runs every item exactly once under
+    concurrent callers, and the thread budget follows what the process is granted, divided by the ranks of the node."""
+    import ctypes as C
+    import subprocess
+    import sys
+
+    bad = C.c_uint32(99)
+    assert zk.lib.zkmi_selftest_host_pool(C.c_uint32(6), C.c_uint32(300), C.byref(bad)) == 0
+    assert bad.value == 0
+    info = zk.host_info()
+    assert 1 <= info["threads"] <= min(16, info["cpus_granted"]) and info["pool_workers"] <= 16
+    assert info["cpus_granted"] <= os.cpu_count()
+    zk.set_host_threads(3)
+    assert zk.host_info()["threads"] == 3
+    zk.set_host_threads(0)
+    assert zk.host_info()["threads"] == info["threads"]
+    # a rank of an 8-process job gets an eighth of the grant (at least one thread); ZKMI_HOST_THREADS overrides
+    code = ("import sys; sys.path.insert(0, %r)\nfrom zkmi_loader import load_pkg\n"
+            "print(sorted(load_pkg().Zkmi().host_info().items()))\n" % ROOT)
+    def child(**env):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKMI_SHARE_TORCH_HIP="0", **env),
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        return dict(eval(out.stdout.strip().splitlines()[-1]))
+    eight = child(LOCAL_WORLD_SIZE="8")
+    assert eight["local_ranks"] == 8 and eight["threads"] == max(1, min(16, eight["cpus_granted"] // 8))
+    assert child(LOCAL_WORLD_SIZE="8", ZKMI_HOST_THREADS="5")["threads"] == 5
+
+
 def test_host_verifier_on_golden_proof(zk):
     gd = golden("groth16_n128.json")
     wit = H(gd["witness"])

@@ -436,6 +436,12 @@ def test_groth16_2p22_with_g2_and_pairing(ctx, zk):
     pk, vk = ctx.groth16_setup(r1, frs([rng.fr() for _ in range(5)]))
     proof = ctx.groth16_prove(pk, z, ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr()))
     assert zk.groth16_verify(vk, z[32 : 32 * r1.n_pub], proof) is True
+    # ... and by the oracle's own verifier on the decoded proof (Python big integers, polynomial-basis Fq12)
+    vkd = {
+        "alpha_g1": ec.g1_from_bytes(vk[:96]), "beta_g2": ec.g2_from_bytes(vk[96:288]), "gamma_g2": ec.g2_from_bytes(vk[288:480]),
+        "delta_g2": ec.g2_from_bytes(vk[480:672]), "gamma_abc_g1": [ec.g1_from_bytes(vk[672 + 96 * i: 768 + 96 * i]) for i in range(r1.n_pub)],
+    }
+    assert g16.verify(vkd, unfrs(z[32: 32 * r1.n_pub]), g16.proof_from_bytes(proof))
     pk.free()
 
 
@@ -1473,6 +1479,9 @@ def _run_multigpu(nproc, extra):
 
     from conftest import ROOT
 
+    if "--one-gpu" in extra:  # the all-gather double for ranks that share a GPU (tests/fake_rccl/fake_rccl.cpp)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "fake_rccl")], stdout=subprocess.DEVNULL)
+
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -1553,6 +1562,33 @@ def test_multigpu_script_world2():
     a = next(o for w, o in by.items() if "zkmi_msm_g1_allgather_combine" in w)
     assert a["matches_closed_form_and_python_path_on_every_rank"] and a["n_gpus"] == 2
     assert next(o for w, o in by.items() if "WINDOWS split" in w)["matches_closed_form_on_every_rank"]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multigpu_script_ranks_sharing_one_gpu(world):
+    """Ranks > 0 on hardware.  The pool has one GPU per box and RCCL refuses two ranks on one device, so the multi-rank legs
+    never ran: here `world` processes share GPU 0, torch.distributed runs over gloo and libzkmi's exchange over the
+    all-gather double of tests/fake_rccl (ZKMI_RCCL_LIB).  Everything else is the product path of BASELINE configs 2 and 3:
+    every rank proves its share of the proofs (all verified, all gathered), owns its slice of the 2^20-point MSM under the
+    plan of the global size, exchanges its partial sums through zkmi_comm (point split, window split with ranks that own
+    one, two or NO window at world 8 x 16 windows ... ) and combines; every rank must reach the closed form."""
+    out = _run_multigpu(world, ["--one-gpu", "--log-n", "14", "--proofs", str(3 * world + 1), "--msm-log-n", "20"])
+    c2 = out[0]
+    assert c2["config"] == 2 and c2["all_verified"] and c2["proofs_gathered"] == 3 * world + 1 and c2["ranks"] == world
+    assert all(o["ranks"] == world and o["n_gpus"] == 1 for o in out)
+    by = {o.get("workload", ""): o for o in out}
+    assert out[1]["config"] == 3 and out[1]["matches_closed_form_on_every_rank"]
+    assert next(o for w, o in by.items() if "zkmi_msm_g1_allgather_combine" in w)["matches_closed_form_and_python_path_on_every_rank"]
+    assert next(o for w, o in by.items() if "WINDOWS split" in w)["matches_closed_form_on_every_rank"]
+    assert next(o for w, o in by.items() if "prepared bases" in w)["matches_closed_form_on_every_rank"]
+
+
+def test_exchange_under_the_big_window_plan_with_ranks_sharing_one_gpu():
+    """The same with the plan of BASELINE config 3's size: 4 ranks, 2^24 points (the partitioned 20-bit windows: 13 windows
+    x 16 partial sums per rank, the top window spread over its partitions)."""
+    out = _run_multigpu(4, ["--one-gpu", "--config", "3", "--msm-log-n", "24"])
+    assert all(o.get("matches_closed_form_on_every_rank", o.get("matches_closed_form_and_python_path_on_every_rank")) for o in out)
+    assert all(o["ranks"] == 4 for o in out) and len(out) >= 3
 
 
 def test_arkworks_key_layout_load_and_write(ctx, zk):
@@ -1748,6 +1784,65 @@ def test_groth16_witness_of_bits_and_edge_blinding_factors_vs_cpp_oracle(ctx, zk
         assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * len(rs), rs, ss) == want  # and without the fold
         pk.free()
     assert all(zk.groth16_verify(ovk, wit[32: 32 * n_pub], p) for p in want)
+    r1.free()
+
+
+def test_fold_decision_follows_the_digit_density(ctx, zk):
+    """The prover folds B1 into the L + H reduction only while the assignments of a key fill at least 9 in 10 of their digits
+    (groth16.hip note_density).  The count comes from the digit sort of z -- on EVERY sort path: round 4's fine-partition
+    sort (one-proof groups at 2^17 .. 2^21, the bench's path) never wrote it and the decision read stale memory.  Here:
+    one-proof groups at 2^17 (the fine path), a relation any assignment satisfies (z_i * 1 = z_i), so ONE key sees a witness
+    of bits and a dense one; the reported count must equal the host's count of non-zero signed digits both times."""
+    import random
+
+    import torch
+
+    lg, n_pub = 17, 2
+    n_vars = (1 << lg) - n_pub
+    nc = n_vars - n_pub
+    one = (1).to_bytes(32, "little")
+    rp = list(range(nc + 1))
+    cols = list(range(n_pub, n_vars))
+    mats = [(rp, cols, one * nc), (rp, [0] * nc, one * nc), (rp, cols, one * nc)]
+    r1 = zk.r1cs_create(n_vars, n_pub, mats)
+    assert r1.log_n == lg
+    c, nd = zk.msm_plan_query(n_vars - 1, shared=True)[:2]
+    bias = sum(((1 << (c - 1)) - 1) << (c * w) for w in range(nd))
+    live = nd - (1 if (nd - 1) * c >= 255 else 0)
+
+    def nonzero_digits(vals):
+        tot = 0
+        for v in vals:
+            k = v + bias
+            for w in range(nd):
+                tot += ((k >> (c * w)) & ((1 << c) - 1)) != (1 << (c - 1)) - 1
+        return tot
+
+    rnd = random.Random(1717)
+    z_bits = [1, 1] + [1 if rnd.random() < 0.6 else 0 for _ in range(n_vars - 2)]
+    z_dense = [1, 5] + [rnd.randrange(R) for _ in range(n_vars - 2)]
+    rng = ec.SplitMix64(0xF01D)
+    toxic = frs([rng.fr() for _ in range(5)])
+    ctx.set_group_size(1)
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    ctx.set_group_size(0)
+    assert pk.schedule_state()[0] is True  # a fresh key folds
+    rs = [ec.fr_to_bytes(rng.fr()) for _ in range(4)]
+    ss = [ec.fr_to_bytes(rng.fr()) for _ in range(4)]
+    full = (n_vars - 1) * live
+    for zv, dense in ((z_bits, False), (z_dense, True), (z_bits, False)):
+        wit = frs(zv)
+        d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        proofs = ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * 4, rs, ss)
+        assert zk.groth16_verify(vk, wit[32: 32 * n_pub], proofs[0]) and zk.groth16_verify(vk, wit[32: 32 * n_pub], proofs[-1])
+        folding, entries, want_full = pk.schedule_state()
+        assert want_full == full
+        assert entries == nonzero_digits(zv[1:]), "the digit sort's count of non-zero digits differs from the host's"
+        assert folding is dense
+        # the bytes do not depend on the decision: the single-proof call never folds
+        assert ctx.groth16_prove_dev(pk, d.data_ptr(), rs[0], ss[0]) == proofs[0]
+    pk.free()
     r1.free()
 
 

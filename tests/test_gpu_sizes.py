@@ -115,12 +115,41 @@ def test_msm_g2_2p22_closed_form(ctx):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("lg", [18, 20])
+def _oracle_vk_dict(vk, n_pub):
+    return {
+        "alpha_g1": ec.g1_from_bytes(vk[:96]),
+        "beta_g2": ec.g2_from_bytes(vk[96:288]),
+        "gamma_g2": ec.g2_from_bytes(vk[288:480]),
+        "delta_g2": ec.g2_from_bytes(vk[480:672]),
+        "gamma_abc_g1": [ec.g1_from_bytes(vk[672 + 96 * i: 768 + 96 * i]) for i in range(n_pub)],
+    }
+
+
+def test_msm_g2_2p22_vs_cpp_oracle(ctx):
+    """Row a9 at BASELINE config 4's size: the G2 MSM of 2^22 terms (896 MiB of algorithmic bytes; above 2^21 terms the
+    digit sort is the record sort, not the fine-partition one) against the C++ oracle's windowed Pippenger over Fq2, plain
+    and over prepared bases -- beside the closed form below, which is independent Python arithmetic."""
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    n = 1 << 22
+    sc = _canonical_bytes(n, 22).tobytes()
+    b = ctx.bases_g2_synthetic(n)
+    want = ocpp.msm_g2(sc, b.read(0, n))
+    assert ctx.msm_g2(sc, b) == want
+    b.prepare()
+    assert ctx.msm_g2(sc, b) == want
+    b.free()
+
+
+@pytest.mark.parametrize("lg", [18, 20, 22])
 def test_proof_bytes_vs_cpp_oracle_over_the_oracle_side_key(ctx, zk, lg):
-    """Rows a7 + a10 at the headline size: the ORACLE runs its own trusted setup (oracle_groth16_setup, pinned to the
-    Python oracle on the N = 128 golden key) and its own prover; the product runs its setup and its GPU prover from
-    the same toxic waste, witness, r and s.  Verifying keys and the 192 proof bytes must be identical, and the proof
-    must pass the pairing check under the oracle's key."""
+    """Rows a7 + a10 at the headline size (2^20) and at BASELINE config 4's (2^22: "G2 MSM + pairing ... full Groth16 proof",
+    on the reference's update_note relation with Poseidon hashing, not the chain stand-in): the ORACLE runs its own trusted
+    setup (oracle_groth16_setup, pinned to the Python oracle on the N = 128 golden key) and its own prover; the product runs
+    its setup and its GPU prover from the same toxic waste, witness, r and s.  Verifying keys and the 192 proof bytes must
+    be identical, and the proof must pass the pairing check under the oracle's key -- in the product's verifier and, at
+    2^22, in the Python oracle's own (oracle/groth16.verify: polynomial-basis Fq12, no code shared with the product)."""
     import torch
     from oracle import cpp as ocpp
     from test_cpu_host import _note_update_case
@@ -148,8 +177,17 @@ def test_proof_bytes_vs_cpp_oracle_over_the_oracle_side_key(ctx, zk, lg):
     assert ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) == want
     assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * 3, [r_] * 3, [s_] * 3) == [want] * 3
     assert zk.groth16_verify(ovk, frs(publics), want) is True
+    if lg == 22:
+        from oracle import groth16 as g16
+
+        assert g16.verify(_oracle_vk_dict(ovk, r1.n_pub), list(publics), g16.proof_from_bytes(want))
+        bad = list(publics)
+        bad[-1] = (bad[-1] + 1) % R
+        assert not g16.verify(_oracle_vk_dict(ovk, r1.n_pub), bad, g16.proof_from_bytes(want))
     pk.free()
     r1.free()
+    del d, okey, mats
+    torch.cuda.empty_cache()
 
 
 def test_grouped_key_survives_a_bigger_msm_on_the_same_context(ctx, zk):

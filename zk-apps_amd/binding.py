@@ -167,6 +167,15 @@ class Zkmi:
         self._chk(self.lib.zkmi_hip_versions(C.byref(b), C.byref(r)))
         return b.value, r.value
 
+    def host_info(self):
+        """zkmi_host_info: dict(cpus_granted, local_ranks, threads, pool_workers)."""
+        out = (C.c_uint32 * 4)()
+        self._chk(self.lib.zkmi_host_info(out))
+        return dict(zip(("cpus_granted", "local_ranks", "threads", "pool_workers"), out))
+
+    def set_host_threads(self, n):
+        self._chk(self.lib.zkmi_set_host_threads(C.c_uint32(n)))
+
     def version(self):
         return self.lib.zkmi_version().decode()
 

@@ -8,6 +8,7 @@
 #include <signal.h>
 #include <unistd.h>
 #include "ctx.hpp"
+#include "host_pool.hpp"
 #include "msm_impl.hpp"  // msm_combine_windows (host)
 
 using namespace zkmi;
@@ -90,6 +91,25 @@ int32_t zkmi_hip_versions(int32_t* out_build, int32_t* out_runtime) {
   int v = 0;
   if (hipRuntimeGetVersion(&v) != hipSuccess) return ZKMI_ERR_HIP;
   *out_runtime = v;
+  return ZKMI_OK;
+}
+
+// The host side of the prover (host_pool.hpp): out[0] = CPUs' worth of time this process is granted (logical CPUs, affinity
+// mask, cgroup quota), out[1] = processes of the job on this node (LOCAL_WORLD_SIZE), out[2] = threads the assembly of a
+// group of proofs will occupy (the driving thread included), out[3] = worker threads the pool has started so far
+int32_t zkmi_host_info(uint32_t out[4]) {
+  if (!out) return ZKMI_ERR_BAD_ARG;
+  out[0] = zkmi::host_cpus_granted();
+  out[1] = zkmi::host_local_ranks();
+  out[2] = zkmi::host_cpu_budget();
+  out[3] = zkmi::HostPool::instance().workers();
+  return ZKMI_OK;
+}
+// threads per process for proof assembly from now on (0 = back to the library's choice); a host that runs several
+// contexts, or shares its CPUs with other work, knows better than the cgroup files
+int32_t zkmi_set_host_threads(uint32_t n) {
+  if (n > zkmi::HOST_THREADS_MAX) return ZKMI_ERR_BAD_ARG;
+  zkmi::host_threads_override().store(n);
   return ZKMI_OK;
 }
 

@@ -27,6 +27,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "tune.hpp"
+#include "host_pool.hpp"
 #include "pairing.hpp"
 #include "r1cs.hpp"
 
@@ -1222,24 +1223,8 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     assemble_proof(pk, acc_a[b], acc_b1[b], acc_l[b], acc_h[b], acc_b2[b], r_bytes + 32ull * b, s_bytes + 32ull * b,
                    out_proofs + 192ull * b);
   };
-  {
-    // host threads for the assembly of a group: ZKMI_HOST_THREADS, default min(16, hardware threads)
-    static const unsigned cap = []() {
-      const char* env = getenv("ZKMI_HOST_THREADS");
-      const int v = env ? atoi(env) : 0;
-      return (unsigned)(v >= 1 && v <= 256 ? v : 16);
-    }();
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt > cap) nt = cap;
-    if (nt < 1) nt = 1;
-    if (nt > G) nt = G;
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; k++)
-      th.emplace_back([&, k]() {
-        for (uint32_t b = k; b < G; b += nt) one(b);
-      });
-    for (auto& x : th) x.join();
-  }
+  // the assembly of a group on the process's persistent pool, within the CPUs this rank may use (host_pool.hpp)
+  HostPool::instance().run(G, host_cpu_budget(), one);
   return ZKMI_OK;
 }
 
@@ -1365,6 +1350,12 @@ static int32_t prove_batch(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t n_proofs, 
   }
   if (n_proofs == 0) return ZKMI_OK;
   constexpr int RING = zkmi_ctx::PROOF_RING;
+  // the driving thread of a batch sleeps between polls while it waits for the GPU (host_pool.hpp); restored on every exit
+  struct SpinGuard {
+    zkmi_ctx* c;
+    explicit SpinGuard(zkmi_ctx* x) : c(x) { c->g1.host_spin = c->g2.host_spin = false; }
+    ~SpinGuard() { c->g1.host_spin = c->g2.host_spin = true; }
+  } spin_guard(ctx);
   // on an error the other proofs in flight still have work queued on every ctx stream: drain them
   // before handing control (and the right to free buffers) back to the caller
   auto bail = [&](int32_t code) {

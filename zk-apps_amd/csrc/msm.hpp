@@ -152,6 +152,9 @@ struct MsmEngine {
   hipEvent_t redo_done[SLOTS] = {};   // k_accum_redo finished (it still reads the sort)
   uint32_t* redo = nullptr;           // [0] = count, [1..] = buckets a call-free accumulation kernel left to k_accum_redo
   MsmPlan slot_plan[SLOTS];
+  // how finish_host* waits for a slot's event: spinning inside hipEventSynchronize (one MSM or one proof by itself: latency)
+  // or polling with sleeps (the batch prover sets false: its driving thread must not hold one of the rank's few CPUs)
+  bool host_spin = true;
   uint64_t cap_buckets = 0;
   uint64_t min_buckets = 0;  // floor set by reserve_buckets
   ~MsmEngine() {

@@ -33,6 +33,7 @@
 #include <type_traits>
 #include <vector>
 #include "curve.hpp"
+#include "host_pool.hpp"
 #include "msm.hpp"
 
 namespace zkmi {
@@ -1463,7 +1464,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
 
 template <class F>
 hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
-  hipError_t e = hipEventSynchronize(done[slot]);
+  hipError_t e = wait_event(done[slot], host_spin);  // (host_pool.hpp: the batch prover's driving thread polls, then sleeps)
   if (e != hipSuccess) return e;
   windows_from_partials(slot_plan[slot], h_partial + (size_t)slot * SLOT_PTS, out_windows);
   return hipSuccess;

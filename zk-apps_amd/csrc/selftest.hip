@@ -117,3 +117,39 @@ extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* o
   *out_mismatches = bad;
   return ZKMI_OK;
 }
+
+// Host self-test of the assembly pool (host_pool.hpp): `callers` threads submit `jobs` jobs each, of 1 .. 64 items and
+// widths 1 .. 17, concurrently; every item must run exactly once and every run() must return only after its own items.
+#include <atomic>
+#include <thread>
+#include <vector>
+#include "host_pool.hpp"
+extern "C" int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint32_t* out_mismatches) {
+  if (!out_mismatches || callers == 0 || callers > 32) return ZKMI_ERR_BAD_ARG;
+  std::atomic<uint32_t> bad{0};
+  auto caller = [&](uint32_t c) {
+    Rng rng{0x9001u + c};
+    for (uint32_t j = 0; j < jobs; j++) {
+      const uint32_t n = 1 + (uint32_t)(rng.next() % 64), width = 1 + (uint32_t)(rng.next() % 17);
+      std::vector<std::atomic<uint32_t>> hits(n);
+      for (auto& h : hits) h.store(0);
+      std::atomic<uint64_t> sum{0};
+      HostPool::instance().run(n, width, [&](uint32_t i) {
+        hits[i].fetch_add(1);
+        uint64_t v = i + 1;
+        for (int k = 0; k < 200; k++) v = v * 6364136223846793005ull + 1442695040888963407ull;  // a little work
+        sum.fetch_add((v & 1) + i + 1);
+      });
+      uint64_t lo = (uint64_t)n * (n + 1) / 2;
+      for (uint32_t i = 0; i < n; i++)
+        if (hits[i].load() != 1) bad.fetch_add(1);
+      if (sum.load() < lo || sum.load() > lo + n) bad.fetch_add(1);
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t c = 1; c < callers; c++) th.emplace_back(caller, c);
+  caller(0);
+  for (auto& t : th) t.join();
+  *out_mismatches = bad.load();
+  return ZKMI_OK;
+}
