@@ -177,6 +177,17 @@ int main(int argc, char** argv) {
   uint32_t mism = 1;
   EXPECT(zkmi_selftest_fq28(3, 50, &mism) == 0 && mism == 0);
   EXPECT(zkmi_selftest_assembly(9, 6, &mism) == 0 && mism == 0);
+  EXPECT(zkmi_selftest_host_pool(4, 50, &mism) == 0 && mism == 0);
+  {
+    // the host combination behind the RCCL all-gather (comm.hip) on all-infinity slots at the 2^26 plan's geometry, 8 ranks
+    uint32_t lay[8];
+    EXPECT(zkmi_msm_exchange_layout(1ull << 26, 8, lay) == 0 && lay[0] == 13 && lay[4] == 192);
+    std::vector<uint8_t> slots((size_t)lay[4] * (lay[2] > lay[3] ? lay[2] : lay[3]) * 8, 0);
+    uint8_t res[96];
+    EXPECT(zkmi_msm_g1_combine_partials(slots.data(), 8, 1ull << 26, 0, res) == 0);
+    EXPECT(zkmi_msm_g1_combine_partials(slots.data(), 8, 1ull << 26, 1, res) == 0);
+    EXPECT(zkmi_msm_g1_combine_partials(slots.data(), 0, 1ull << 26, 0, res) == ZKMI_ERR_BAD_ARG);
+  }
   EXPECT(zkmi_selftest_poseidon(ZKMI_FIELD_BLS12_381_FR, 5, 10, &mism) == 0 && mism == 0);
 
   // --- the C++ oracle: small NTT round trip and MSMs over the product's generator multiples

@@ -8,6 +8,8 @@
 // group element, compared after affine normalisation.
 // Formulas: EFD "xyzz" madd-2008-s (8M+2S), add-2008-s (12M+2S), dbl-2008-s-1.
 #pragma once
+#include <stddef.h>
+#include <vector>
 #include "field.hpp"
 
 namespace zkmi {
@@ -195,6 +197,82 @@ struct FixedBase4 {
     return acc;
   }
 };
+
+// The same with 8-bit windows and AFFINE table entries: 32 mixed additions (8M + 2S) per multiplication instead of 64
+// complete ones (12M + 2S) -- proof assembly is what a rank's few host CPUs spend their time on when small proofs travel in
+// groups (2 700 proofs/s per GPU at 2^14: DESIGN.md section 5), and three of its four scalar multiplications are by points
+// fixed at key-load time.  32 x 255 points: 0.78 MB (G1) / 1.57 MB (G2) of host memory per table.
+template <class F>
+void batch_to_affine(const XYZZ<F>* pts, size_t n, Affine<F>* out);
+template <class F>
+struct FixedBase8 {
+  std::vector<Affine<F>> tab;  // tab[w * 255 + d - 1] = d * 256^w * P
+  void build(const Affine<F>& p) {
+    std::vector<XYZZ<F>> t(32 * 255);
+    XYZZ<F> base = XYZZ<F>::from_affine(p);
+    for (int w = 0; w < 32; w++) {
+      XYZZ<F>* row = t.data() + (size_t)w * 255;
+      row[0] = base;
+      for (int d = 1; d < 255; d++) {
+        row[d] = row[d - 1];
+        row[d].add(base);
+      }
+      base = row[254];
+      base.add(row[0]);  // 256 * (256^w P)
+    }
+    tab.resize(t.size());
+    batch_to_affine(t.data(), t.size(), tab.data());
+  }
+  XYZZ<F> mul(const uint32_t* k /* 8 limbs */) const {
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (int w = 0; w < 32; w++) {
+      const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 255u;
+      if (d) acc.madd(tab[(size_t)w * 255 + d - 1]);
+    }
+    return acc;
+  }
+};
+
+// One shared inversion for n points (Montgomery's trick on the zzz coordinates; Fq2 inverts through its norm, so a batch
+// costs ONE base-field inversion either way): a group of 64 proofs normalises its 192 proof elements together.
+template <class F>
+void batch_to_affine(const XYZZ<F>* pts, size_t n, Affine<F>* out) {
+  std::vector<F> pre(n);
+  F run = F::one();
+  for (size_t i = 0; i < n; i++) {
+    pre[i] = run;
+    if (!pts[i].is_inf()) run = run * pts[i].zzz;
+  }
+  F inv = run.inv();
+  for (size_t i = n; i-- > 0;) {
+    if (pts[i].is_inf()) {
+      out[i] = Affine<F>::infinity();
+      continue;
+    }
+    const F zi = inv * pre[i];  // 1 / zzz_i
+    inv = inv * pts[i].zzz;
+    const F zz_inv = (zi * pts[i].zz).sqr();  // (zz / zzz)^2 = 1 / zz
+    out[i] = {pts[i].x * zz_inv, pts[i].y * zi};
+  }
+}
+
+// k * P for ONE variable point: 4-bit windows, 255 doublings + <= 64 additions (plain double-and-add: + ~128)
+template <class F>
+inline XYZZ<F> scalar_mul_w4(const XYZZ<F>& p, const uint32_t* k) {
+  XYZZ<F> tp[15];
+  tp[0] = p;
+  for (int d = 1; d < 15; d++) {
+    tp[d] = tp[d - 1];
+    tp[d].add(p);
+  }
+  XYZZ<F> acc = XYZZ<F>::infinity();
+  for (int w = 63; w >= 0; w--) {
+    for (int i = 0; i < 4; i++) acc.dbl_inplace();
+    const uint32_t d = scalar_nibble(k, w);
+    if (d) acc.add(tp[d - 1]);
+  }
+  return acc;
+}
 
 // a * P + b * Q for 256-bit scalars: one doubling chain, 4-bit windows (Straus)
 template <class F>

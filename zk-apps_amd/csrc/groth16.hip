@@ -23,6 +23,7 @@
 #include <string>
 #include <memory>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <vector>
 #include "ctx.hpp"
@@ -300,9 +301,12 @@ struct zkmi_pk {
   Affine<Fq2_28>* b2_tab = nullptr;
   G1Affine alpha_g1, beta_g1, delta_g1, a0, b1_0;
   G2Affine beta_g2, delta_g2, b2_0;
-  // host tables for r * delta, s * delta, rs * delta of proof assembly (built once per key)
-  std::unique_ptr<FixedBase4<Fq>> delta1_tab;
-  std::unique_ptr<FixedBase4<Fq2>> delta2_tab;
+  // host tables of proof assembly (built once per key): r * delta_1, s * delta_2 and r * (beta_1 + b1_0) are multiplications
+  // by points the key fixes; the constant summands of A and B in affine form
+  std::unique_ptr<FixedBase8<Fq>> delta1_tab, k1_tab;
+  std::unique_ptr<FixedBase8<Fq2>> delta2_tab;
+  G1Affine ka;   // alpha_1 + a0
+  G2Affine kb2;  // beta_2 + b2_0
   // per proof in flight (ring of zkmi_ctx::PROOF_RING): witness in canonical words (digit source of the
   // A/B/L MSMs) and h coefficients in canonical words, bit-reversed order (digit source of the H MSM)
   Fr* d_z[zkmi_ctx::PROOF_RING] = {};
@@ -440,10 +444,20 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
 
 // delta_g1 / delta_g2 are final -> fixed-base tables of proof assembly
 static void pk_build_delta_tables(zkmi_pk* pk) {
-  pk->delta1_tab.reset(new FixedBase4<Fq>());
+  pk->delta1_tab.reset(new FixedBase8<Fq>());
   pk->delta1_tab->build(pk->delta_g1);
-  pk->delta2_tab.reset(new FixedBase4<Fq2>());
+  pk->delta2_tab.reset(new FixedBase8<Fq2>());
   pk->delta2_tab->build(pk->delta_g2);
+  G1XYZZ k1 = G1XYZZ::from_affine(pk->beta_g1);
+  k1.madd(pk->b1_0);
+  pk->k1_tab.reset(new FixedBase8<Fq>());
+  pk->k1_tab->build(k1.to_affine());
+  G1XYZZ ka = G1XYZZ::from_affine(pk->alpha_g1);
+  ka.madd(pk->a0);
+  pk->ka = ka.to_affine();
+  G2XYZZ kb = G2XYZZ::from_affine(pk->beta_g2);
+  kb.madd(pk->b2_0);
+  pk->kb2 = kb.to_affine();
 }
 
 // queries are final in the host representation -> build the device MSM copies
@@ -1071,55 +1085,50 @@ static int32_t prove_enqueue_h(zkmi_ctx* ctx, const zkmi_pk* pk, uint32_t G, int
   return ZKMI_OK;
 }
 
-// Host part: wait for the slot set's partials, combine windows, assemble A, B, C
-//  and compress.  The GPU may already be running the next proof.
-// A, B, C of one proof from its five MSM results + compression; pure host arithmetic
-// Stage 1 needs only the MSMs over z that finish first (A, B1, B2): A, B (in G1 and G2) and s*A + r*B1 - rs*delta.
+// Proof assembly, pure host arithmetic; the GPU may already be running the next proof.
+//   A = alpha + a0 + MSM(a, z) + r delta            B = beta + b_0 + MSM(b, z) + s delta   (in G1 and in G2)
+//   C = s A + r B_1 - r s delta + MSM(l, aux) + MSM(h, h)
+// B_1 is not part of the proof; expanding it inside C, the r s delta terms cancel:
+//   C = s A + r (beta_1 + b1_0) + r MSM(b1, z) + L + H
+// so ONE multiplication by a variable point is left (s A; with r MSM(b1, z) when B1 was not folded into the device-side
+// reduction: one doubling chain for both), and three by points the key fixes -- r delta_1, r (beta_1 + b1_0), s delta_2 --
+// which come from 8-bit-window affine tables (32 mixed additions each).  Round 4 computed r delta, s delta, r s delta and
+// s delta_2 from 4-bit tables of XYZZ points and always ran the two-point chain: 0.51 ms of one CPU per proof against ~0.25
+// now -- what a rank's share of the node's CPUs is spent on when proofs of 2^14 constraints leave at 2 700 per second.
 struct AssemblyHead {
   G1XYZZ g_a, g_c;
   G2XYZZ g2_b;
 };
-// What assembly can compute from (r, s) and the key alone, i.e. before any MSM has finished: r * delta, s * delta,
-// rs * delta in G1 and s * delta in G2 from the key's fixed-base tables (a single proof computes them while the GPU works)
+// What assembly can compute from (r, s) and the key alone, i.e. before any MSM has finished (a single proof computes them
+// while the GPU works)
 struct AssemblyPre {
   uint32_t rk[8], sk[8];
-  G1XYZZ d_r, d_s, d_rs;
-  G2XYZZ d2_s;
+  G1XYZZ d_r, r_k1;  // r * delta_1, r * (beta_1 + b1_0)
+  G2XYZZ d2_s;       // s * delta_2
 };
 static AssemblyPre assemble_pre(const zkmi_pk* pk, const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
   AssemblyPre p;
-  uint32_t rsk[8];
   memcpy(p.rk, r_bytes, 32);
   memcpy(p.sk, s_bytes, 32);
-  Fr rm, sm;
-  fr_from_wire(r_bytes, &rm);
-  fr_from_wire(s_bytes, &sm);
-  fr_limbs(rm * sm, rsk);
   p.d_r = pk->delta1_tab->mul(p.rk);
-  p.d_s = pk->delta1_tab->mul(p.sk);
-  p.d_rs = pk->delta1_tab->mul(rsk);
+  p.r_k1 = pk->k1_tab->mul(p.rk);
   p.d2_s = pk->delta2_tab->mul(p.sk);
   return p;
 }
-// A and s * A + r * B1 - rs * delta (one doubling chain) once the A and B1 MSMs are in
+// A and s * A + r * B1 - rs * delta once the A and B1 MSMs are in (acc_b1 = infinity: B1's MSM reaches C through the
+// device-side reduction it shares with L and H)
 static void assemble_g1(const zkmi_pk* pk, const AssemblyPre& p, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, AssemblyHead& h) {
   h.g_a = p.d_r;
-  h.g_a.madd(pk->a0);
+  h.g_a.madd(pk->ka);
   h.g_a.add(acc_a);
-  h.g_a.madd(pk->alpha_g1);
-  G1XYZZ g1_b = p.d_s;
-  g1_b.madd(pk->b1_0);
-  g1_b.add(acc_b1);
-  g1_b.madd(pk->beta_g1);
-  h.g_c = scalar_mul2(h.g_a, p.sk, g1_b, p.rk);
-  h.g_c.add(p.d_rs.neg());
+  h.g_c = acc_b1.is_inf() ? scalar_mul_w4(h.g_a, p.sk) : scalar_mul2(h.g_a, p.sk, acc_b1, p.rk);
+  h.g_c.add(p.r_k1);
 }
 // B once the G2 MSM is in: two additions
 static void assemble_g2(const zkmi_pk* pk, const AssemblyPre& p, const G2XYZZ& acc_b2, AssemblyHead& h) {
   h.g2_b = p.d2_s;
-  h.g2_b.madd(pk->b2_0);
+  h.g2_b.madd(pk->kb2);
   h.g2_b.add(acc_b2);
-  h.g2_b.madd(pk->beta_g2);
 }
 static AssemblyHead assemble_head(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G2XYZZ& acc_b2,
                                   const uint8_t r_bytes[32], const uint8_t s_bytes[32]) {
@@ -1136,12 +1145,6 @@ static void assemble_tail(AssemblyHead& h, const G1XYZZ& acc_l, const G1XYZZ& ac
   g1_compress(h.g_a.to_affine(), out_proof);
   g2_compress(h.g2_b.to_affine(), out_proof + 48);
   g1_compress(h.g_c.to_affine(), out_proof + 144);
-}
-// A, B, C of one proof from its five MSM results + compression; pure host arithmetic
-static void assemble_proof(const zkmi_pk* pk, const G1XYZZ& acc_a, const G1XYZZ& acc_b1, const G1XYZZ& acc_l, const G1XYZZ& acc_h,
-                           const G2XYZZ& acc_b2, const uint8_t r_bytes[32], const uint8_t s_bytes[32], uint8_t out_proof[192]) {
-  AssemblyHead h = assemble_head(pk, acc_a, acc_b1, acc_b2, r_bytes, s_bytes);
-  assemble_tail(h, acc_l, acc_h, out_proof);
 }
 
 // Host part: wait for the slot set's partials, combine windows, assemble and compress the G proofs of the group
@@ -1198,33 +1201,53 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
       fprintf(stderr, "zkmi: finish: A,B1 ready %ld us, G1 part assembled %ld, B2 ready + B assembled %ld, L ready %ld, H ready %ld, tail done %ld\n", tm[0], tm[1],
               tm[2], tm[3], tm[4], tm[5]);
     return ZKMI_OK;
-  } else {
-    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_a.data(), s0 + 0));
-    note_density();
-    if (merged_b1)
-      for (auto& p : acc_b1) p = G1XYZZ::infinity();
-    else
-      ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_b1.data(), s0 + 1));
-    if (merged)
-      for (auto& p : acc_l) p = G1XYZZ::infinity();
-    else
-      ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_l.data(), s0 + 2));
-    ZK_HIP(ctx, ctx->g2.finish_host_batch(acc_b2.data(), g2s));
-    ZK_HIP(ctx, ctx->g1.finish_host_batch(acc_h.data(), s0 + 3));
   }
-  // the flag copy precedes the h coefficients on the front stream, which the H MSM waited for
+  // A group: the driving thread only waits for the slots' events; every proof's share of the work -- combining its
+  // partition sums into the five MSM results (~1 400 field products), the scalar multiplications of assembly -- is one task
+  // of the process's persistent pool, within the CPUs this rank may use (host_pool.hpp).
+  ZK_HIP(ctx, ctx->g1.wait_slot(s0 + 0));
+  note_density();
+  if (!merged_b1) ZK_HIP(ctx, ctx->g1.wait_slot(s0 + 1));
+  if (!merged) ZK_HIP(ctx, ctx->g1.wait_slot(s0 + 2));
+  ZK_HIP(ctx, ctx->g2.wait_slot(g2s));
+  ZK_HIP(ctx, ctx->g1.wait_slot(s0 + 3));
+  // the flag words precede the h coefficients on the front stream, which the H MSM waited for
   {
     const uint32_t flags = pk->h_unsat[par];
     pk->h_unsat[par] = 0;
     if (flags & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
     if (flags) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
   }
-  auto one = [&](uint32_t b) {
-    assemble_proof(pk, acc_a[b], acc_b1[b], acc_l[b], acc_h[b], acc_b2[b], r_bytes + 32ull * b, s_bytes + 32ull * b,
-                   out_proofs + 192ull * b);
+  std::vector<AssemblyHead> heads(G);
+  const std::function<void(uint32_t)> one = [&](uint32_t b) {
+    const G1XYZZ inf = G1XYZZ::infinity();
+    const G1XYZZ a = ctx->g1.host_result_vec(s0 + 0, (int)b);
+    const G1XYZZ b1 = merged_b1 ? inf : ctx->g1.host_result_vec(s0 + 1, (int)b);  // folded: arrives inside the H slot's sum
+    const G2XYZZ b2 = ctx->g2.host_result_vec(g2s, (int)b);
+    AssemblyHead h = assemble_head(pk, a, b1, b2, r_bytes + 32ull * b, s_bytes + 32ull * b);
+    if (!merged) h.g_c.add(ctx->g1.host_result_vec(s0 + 2, (int)b));
+    h.g_c.add(ctx->g1.host_result_vec(s0 + 3, (int)b));
+    heads[b] = h;
   };
-  // the assembly of a group on the process's persistent pool, within the CPUs this rank may use (host_pool.hpp)
   HostPool::instance().run(G, host_cpu_budget(), one);
+  // the 3 G proof elements of the group are normalised with ONE base-field inversion per curve instead of one each
+  std::vector<G1XYZZ> p1(2 * (size_t)G);
+  std::vector<G2XYZZ> p2(G);
+  for (uint32_t b = 0; b < G; b++) {
+    p1[2 * b] = heads[b].g_a;
+    p1[2 * b + 1] = heads[b].g_c;
+    p2[b] = heads[b].g2_b;
+  }
+  std::vector<G1Affine> a1(p1.size());
+  std::vector<G2Affine> a2(p2.size());
+  batch_to_affine(p1.data(), p1.size(), a1.data());
+  batch_to_affine(p2.data(), p2.size(), a2.data());
+  for (uint32_t b = 0; b < G; b++) {
+    uint8_t* out = out_proofs + 192ull * b;
+    g1_compress(a1[2 * b], out);
+    g2_compress(a2[b], out + 48);
+    g1_compress(a1[2 * b + 1], out + 144);
+  }
   return ZKMI_OK;
 }
 
@@ -1302,12 +1325,24 @@ int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mism
   std::unique_ptr<FixedBase4<Fq2>> t2(new FixedBase4<Fq2>());
   t1->build(p1);
   t2->build(p2);
+  // what assembly uses since round 5: 8-bit windows over affine entries, the one-point window multiplication, the shared inversion
+  std::unique_ptr<FixedBase8<Fq>> u1(new FixedBase8<Fq>());
+  std::unique_ptr<FixedBase8<Fq2>> u2(new FixedBase8<Fq2>());
+  u1->build(p1);
+  u2->build(p2);
+  std::vector<G1XYZZ> n1;
+  std::vector<G2XYZZ> n2;
   const G1XYZZ q1 = scalar_mul(G1XYZZ::from_affine(p1), k, 8);  // a second, unrelated G1 point
   for (uint32_t it = 0; it < iters; it++) {
     scalar(it, k);
     scalar(it + 2, k2);
     if (!same1(t1->mul(k), scalar_mul(G1XYZZ::from_affine(p1), k, 8))) bad++;
     if (!same2(t2->mul(k), scalar_mul(G2XYZZ::from_affine(p2), k, 8))) bad++;
+    if (!same1(u1->mul(k), scalar_mul(G1XYZZ::from_affine(p1), k, 8))) bad++;
+    if (!same2(u2->mul(k), scalar_mul(G2XYZZ::from_affine(p2), k, 8))) bad++;
+    if (!same1(scalar_mul_w4(q1, k), scalar_mul(q1, k, 8))) bad++;
+    n1.push_back(u1->mul(k));  // (infinity for k = 0: the batch must carry it through)
+    n2.push_back(u2->mul(k2));
     G1XYZZ want = scalar_mul(G1XYZZ::from_affine(p1), k, 8);
     want.add(scalar_mul(q1, k2, 8));
     if (!same1(scalar_mul2(G1XYZZ::from_affine(p1), k, q1, k2), want)) bad++;
@@ -1318,6 +1353,20 @@ int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mism
     G1XYZZ opp = scalar_mul(G1XYZZ::from_affine(p1), k, 8);
     opp.add(scalar_mul(G1XYZZ::from_affine(p1).neg(), k, 8));
     if (!opp.is_inf() || !scalar_mul2(G1XYZZ::from_affine(p1), k, G1XYZZ::from_affine(p1).neg(), k).is_inf()) bad++;
+  }
+  {
+    std::vector<G1Affine> a1(n1.size());
+    std::vector<G2Affine> a2(n2.size());
+    batch_to_affine(n1.data(), n1.size(), a1.data());
+    batch_to_affine(n2.data(), n2.size(), a2.data());
+    for (size_t i = 0; i < n1.size(); i++) {
+      const G1Affine w = n1[i].to_affine();
+      if (!(a1[i].x == w.x && a1[i].y == w.y)) bad++;
+    }
+    for (size_t i = 0; i < n2.size(); i++) {
+      const G2Affine w = n2[i].to_affine();
+      if (!(a2[i].x == w.x && a2[i].y == w.y)) bad++;
+    }
   }
   *out_mismatches = bad;
   return ZKMI_OK;

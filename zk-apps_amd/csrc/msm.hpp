@@ -195,6 +195,10 @@ struct MsmEngine {
   static int partials_per_msm(const MsmPlan& pl);  // XYZZ<HF> points a reduction writes per MSM (device `partial`, slot-major)
   // batched shared sort (MsmSort::run_shared_batch): one result per scalar vector
   hipError_t finish_host_batch(XYZZ<HF>* out, int slot = 0);
+  // the same in two steps, so that the combination of the vectors' partition sums can run on several threads: wait for
+  // the slot's partials, then the result of vector v (reads the pinned slot only)
+  hipError_t wait_slot(int slot);
+  XYZZ<HF> host_result_vec(int slot, int v) const;
 };
 
 // host-format affine points (Montgomery, R = 2^384) -> device format (R = 2^392 limbs)

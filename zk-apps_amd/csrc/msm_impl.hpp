@@ -1524,6 +1524,24 @@ hipError_t MsmEngine<F>::finish_host_batch(XYZZ<HF>* out, int slot) {
   return hipSuccess;
 }
 
+template <class F>
+hipError_t MsmEngine<F>::wait_slot(int slot) {
+  return wait_event(done[slot], host_spin);
+}
+template <class F>
+XYZZ<typename MsmEngine<F>::HF> MsmEngine<F>::host_result_vec(int slot, int v) const {
+  const MsmPlan& pl = slot_plan[slot];
+  const int vp = pl.vec_parts > 1 ? pl.vec_parts : 1;
+  const int njobs = 1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0);
+  const XYZZ<HF>* h = h_partial + (size_t)slot * SLOT_PTS + (size_t)v * vp * njobs;
+  MsmPlan mine = pl;  // the partitions of this vector only
+  mine.nwin = vp;
+  XYZZ<HF> win[64];
+  windows_from_partials(mine, h, win);
+  if (vp == 1) return win[0];
+  return msm_combine_partitions<HF>(win, h, vp, njobs, pl.nb);
+}
+
 template <class HF>
 XYZZ<HF> msm_combine_windows(const XYZZ<HF>* windows, int nwin, int c) {
   XYZZ<HF> total = XYZZ<HF>::infinity();
