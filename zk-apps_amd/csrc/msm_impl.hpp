@@ -613,6 +613,23 @@ __device__ __forceinline__ XYZZ<F> block_tree_sum(XYZZ<F> acc, XYZZ<F>* sh) {
 // last (ticket word per heavy bucket, left at zero for the slot's next MSM): there is no separate combine launch -- a
 // kernel of 330-register waves (G2) that found no SIMD until the accumulation beside it had drained, with the reduction
 // waiting behind it (0.23 ms of one 2^14 proof's critical path for a list in which no bucket was split at all).
+//
+// Round 5: a bucket is cut into as many sub-ranges as it can feed (~4 points per thread), up to MSM_HSPLIT_MAX -- no longer
+// at most 64.  A witness of bits puts 630 000 points into ONE bucket per query; 64 sub-ranges x 64 lane pairs left every
+// lane pair of the G2 kernel a chain of 154 dependent additions on an otherwise empty chip: 5.3 ms of a 9.5 ms proof
+// (profiles/r05/experiments/heavy_bucket_before.txt).  The partial sums live in one pool per MSM slot (MSM_HEAVY_CAP x
+// MSM_HSPLIT entries as before), handed out in list order: entry h owns [item0, item0 + nsplit) where item0 = the
+// sub-ranges of the entries before it -- the number every workgroup already computes to deal the work items.
+constexpr uint32_t MSM_HSPLIT_MAX = 1024;
+constexpr uint32_t MSM_HPOOL = MSM_HEAVY_CAP * MSM_HSPLIT;  // partial-sum slots per MSM slot
+// sub-ranges of list entry h (count points, pts points per workgroup pass), given the pool slots already handed out
+__device__ __forceinline__ uint32_t heavy_nsplit(uint32_t h, uint32_t count, uint32_t pts, uint32_t item0) {
+  if (h >= MSM_HEAVY_CAP) return 1u;  // beyond the ticket words: one workgroup per bucket
+  uint32_t n = (count + pts - 1) / pts;
+  n = n < 1 ? 1 : (n > MSM_HSPLIT_MAX ? MSM_HSPLIT_MAX : n);
+  if (item0 + n > MSM_HPOOL) n = 1;  // pool exhausted (thousands of split buckets: pathological): unsplit
+  return n;
+}
 template <class F>
 __global__ void __launch_bounds__(MSM_TREE_T)
 k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
@@ -638,60 +655,59 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
   // proofs -- one per proof, ~600 points = 2 sub-ranges each -- were walked 8 at a time by 2 of the 64 columns: 5.8 ms per
   // launch at 2^14, a quarter of the group's kernel time; dealt flat the same list is one round of 128 workgroups.)
   const uint32_t n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-  uint32_t item0 = 0;  // number of the bucket's first work item
+  uint32_t item0 = 0;  // number of the bucket's first work item = its first pool slot
   // (a launch for the entries beyond the split capacity -- one item per bucket -- strides the list directly)
   const bool tail = h_first >= MSM_HEAVY_CAP;
   for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
     const uint32_t b = heavy[1 + h];
-    uint32_t beg = begin[b], end = beg + count[b];
-    uint32_t nsplit = 1;
-    if (h < MSM_HEAVY_CAP) {
-      // as many sub-ranges as the bucket can feed: ~4 points per thread before the tree (a bucket of 400 points on
-      // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group).
-      // (8 points per thread -- one workgroup, no partials and no second tree for the 600 bit variables of a small
-      // proof -- measured no better: 2^14 2 501 against 2 554-2 573 proofs/s.)
-      nsplit = (count[b] + 4 * MSM_TREE_T - 1) / (4 * MSM_TREE_T);
-      nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
-    }
-    // this workgroup's sub-range of the bucket, if any: item0 + r = wg (mod n_wg); nsplit <= MSM_HSPLIT <= n_wg, so at most one
-    const uint32_t r = tail ? 0u : (wg + n_wg - item0 % n_wg) % n_wg;
+    const uint32_t cnt = count[b], beg0 = begin[b];
+    // as many sub-ranges as the bucket can feed: ~4 points per thread before the tree (a bucket of 400 points on
+    // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group).
+    // (8 points per thread -- one workgroup, no partials and no second tree for the 600 bit variables of a small
+    // proof -- measured no better: 2^14 2 501 against 2 554-2 573 proofs/s.)
+    const uint32_t nsplit = tail ? 1u : heavy_nsplit(h, cnt, 4 * MSM_TREE_T, item0);
+    const uint32_t base = item0;
+    // this workgroup's sub-ranges of the bucket: item numbers base + r = wg (mod n_wg)
+    const uint32_t r0 = tail ? 0u : (wg + n_wg - base % n_wg) % n_wg;
     item0 += nsplit;
-    if (r >= nsplit) continue;  // block-uniform
-    if (nsplit > 1) {
-      const uint32_t len = (count[b] + nsplit - 1) / nsplit;
-      const uint32_t sb = beg + r * len;
-      end = (sb + len < end) ? sb + len : end;
-      beg = sb < end ? sb : end;
-    }
-    XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
-      const uint32_t v = sorted[j];
-      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
-      if (v >> 31) p.y = p.y.neg();
-      acc.madd(p);
-    }
-    acc = block_tree_sum(acc, sh);
-    if (nsplit == 1) {
-      if (threadIdx.x == 0) put(b, acc);
-    } else {
-      if (threadIdx.x == 0) {
-        store_vec(heavy_partial + (size_t)h * MSM_HSPLIT + r, acc);
-        __threadfence();  // the partial is visible device-wide before the ticket is taken
-        is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+    for (uint32_t r = r0; r < nsplit; r += n_wg) {  // block-uniform
+      uint32_t beg = beg0, end = beg0 + cnt;
+      if (nsplit > 1) {
+        const uint32_t len = (cnt + nsplit - 1) / nsplit;
+        const uint32_t sb = beg + r * len;
+        end = (sb + len < end) ? sb + len : end;
+        beg = sb < end ? sb : end;
       }
-      __syncthreads();
-      if (is_last) {  // block-uniform
-        __threadfence();
-        XYZZ<F> v = XYZZ<F>::infinity();
-        if (threadIdx.x < nsplit) v = load_vec(heavy_partial + (size_t)h * MSM_HSPLIT + threadIdx.x);
-        v = block_tree_sum(v, sh);
+      XYZZ<F> acc = XYZZ<F>::infinity();
+      for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
+        const uint32_t v = sorted[j];
+        Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+        if (v >> 31) p.y = p.y.neg();
+        acc.madd(p);
+      }
+      acc = block_tree_sum(acc, sh);
+      if (nsplit == 1) {
+        if (threadIdx.x == 0) put(b, acc);
+      } else {
         if (threadIdx.x == 0) {
-          put(b, v);
-          ticket[h] = 0;
+          store_vec(heavy_partial + (size_t)base + r, acc);
+          __threadfence();  // the partial is visible device-wide before the ticket is taken
+          is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (is_last) {  // block-uniform
+          __threadfence();
+          XYZZ<F> v = XYZZ<F>::infinity();
+          for (uint32_t k = threadIdx.x; k < nsplit; k += blockDim.x) v.add(load_vec(heavy_partial + (size_t)base + k));
+          v = block_tree_sum(v, sh);
+          if (threadIdx.x == 0) {
+            put(b, v);
+            ticket[h] = 0;
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -948,44 +964,43 @@ k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t*
   const bool tail = h_first >= MSM_HEAVY_CAP;
   for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
     const uint32_t b = heavy[1 + h];
-    uint32_t beg = begin[b], end = beg + count[b];
-    uint32_t nsplit = 1;
-    if (h < MSM_HEAVY_CAP) {  // ~4 points per lane pair before the tree
-      nsplit = (count[b] + 4 * npair - 1) / (4 * npair);
-      nsplit = nsplit < 1 ? 1 : (nsplit > MSM_HSPLIT ? MSM_HSPLIT : nsplit);
-    }
-    const uint32_t r = tail ? 0u : (wg + n_wg - item0 % n_wg) % n_wg;
+    const uint32_t cnt = count[b], beg0 = begin[b];
+    const uint32_t nsplit = tail ? 1u : heavy_nsplit(h, cnt, 4 * npair, item0);  // ~4 points per lane pair before the tree
+    const uint32_t base = item0;  // first pool slot of the bucket's partial sums (see k_accum_heavy)
+    const uint32_t r0 = tail ? 0u : (wg + n_wg - base % n_wg) % n_wg;
     item0 += nsplit;
-    if (r >= nsplit) continue;  // block-uniform
-    if (nsplit > 1) {
-      const uint32_t len = (count[b] + nsplit - 1) / nsplit;
-      const uint32_t sb = beg + r * len;
-      end = (sb + len < end) ? sb + len : end;
-      beg = sb < end ? sb : end;
-    }
-    XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-    for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));  // pair-uniform
-    acc = pair_tree_sum(acc, sh, pair, npair, comp);
-    if (nsplit == 1) {
-      if (pair == 0) st_xyzz_split(buckets + b, acc, comp);
-    } else {
-      if (pair == 0) {
-        st_xyzz_split(heavy_partial + (size_t)h * MSM_HSPLIT + r, acc, comp);
-        __threadfence();  // each lane's half of the partial is visible device-wide ...
+    for (uint32_t r = r0; r < nsplit; r += n_wg) {  // block-uniform
+      uint32_t beg = beg0, end = beg0 + cnt;
+      if (nsplit > 1) {
+        const uint32_t len = (cnt + nsplit - 1) / nsplit;
+        const uint32_t sb = beg + r * len;
+        end = (sb + len < end) ? sb + len : end;
+        beg = sb < end ? sb : end;
       }
-      __syncthreads();  // ... before the ticket is taken
-      if (threadIdx.x == 0) is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+      XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+      for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));  // pair-uniform
+      acc = pair_tree_sum(acc, sh, pair, npair, comp);
+      if (nsplit == 1) {
+        if (pair == 0) st_xyzz_split(buckets + b, acc, comp);
+      } else {
+        if (pair == 0) {
+          st_xyzz_split(heavy_partial + (size_t)base + r, acc, comp);
+          __threadfence();  // each lane's half of the partial is visible device-wide ...
+        }
+        __syncthreads();  // ... before the ticket is taken
+        if (threadIdx.x == 0) is_last = atomicAdd(ticket + h, 1u) == nsplit - 1 ? 1u : 0u;
+        __syncthreads();
+        if (is_last) {  // block-uniform
+          __threadfence();
+          XYZZ<Fq2P> v = XYZZ<Fq2P>::infinity();
+          for (uint32_t k = pair; k < nsplit; k += npair) v.add(ld_xyzz_split(heavy_partial + (size_t)base + k, comp));  // pair-uniform
+          v = pair_tree_sum(v, sh, pair, npair, comp);
+          if (pair == 0) st_xyzz_split(buckets + b, v, comp);
+          if (threadIdx.x == 0) ticket[h] = 0;
+        }
+      }
       __syncthreads();
-      if (is_last) {  // block-uniform; nsplit <= MSM_HSPLIT = npair
-        __threadfence();
-        XYZZ<Fq2P> v = XYZZ<Fq2P>::infinity();
-        if (pair < nsplit) v = ld_xyzz_split(heavy_partial + (size_t)h * MSM_HSPLIT + pair, comp);
-        v = pair_tree_sum(v, sh, pair, npair, comp);
-        if (pair == 0) st_xyzz_split(buckets + b, v, comp);
-        if (threadIdx.x == 0) ticket[h] = 0;
-      }
     }
-    __syncthreads();
   }
 }
 template <int UNUSED = 0>

@@ -434,6 +434,24 @@ k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restric
 // position falls into, a run that overshoots the stage's slack is written directly.
 constexpr uint32_t FINE_STAGE = 36000;   // entries the LDS stage holds (144 000 B)
 constexpr uint32_t FINE_ROUND = 32768;   // positions per round; FINE_STAGE - FINE_ROUND = slack for a straddling run
+// LDS counter updates of one wave, aggregated when all its active lanes name the SAME counter: a witness of bits sends
+// 630 000 records to one bucket, i.e. 64-way same-address ds_add conflicts on every wave-instruction of both passes (with
+// the round structure below: 3.7 ms of k_fpart_sort for a 2^20 bit witness, 0.15 ms for a dense one).  Returns the value
+// the lane's own atomicAdd(&ctr[idx], 1) would have returned (any order within the wave is as good as another).
+__device__ __forceinline__ uint32_t wave_counter_add(uint32_t* ctr, uint32_t idx, bool valid) {
+  const uint64_t mask = __ballot(valid);
+  if (mask == 0) return 0u;
+  const int leader = __ffsll((unsigned long long)mask) - 1;
+  const uint32_t idx0 = (uint32_t)__shfl((int)idx, leader);
+  if (__ballot(valid && idx != idx0) == 0) {  // wave-uniform
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&ctr[idx0], (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+  }
+  return valid ? atomicAdd(&ctr[idx], 1u) : 0u;
+}
+
 __global__ void __launch_bounds__(1024)
 k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
              uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged) {
@@ -444,9 +462,13 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
   extern __shared__ uint32_t stage[];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   const uint32_t pbase = fpart[q], ptot = fpart[NP + q];
+  const uint32_t ptot_up = (ptot + 1023u) & ~1023u;  // whole waves walk the records: the aggregated counter updates need every lane
   hist[tid] = 0;
   __syncthreads();
-  for (uint32_t r = tid; r < ptot; r += 1024) atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
+  for (uint32_t r = tid; r < ptot_up; r += 1024) {
+    const bool valid = r < ptot;
+    (void)wave_counter_add(hist, valid ? rec_bkt[pbase + r] : 0u, valid);
+  }
   __syncthreads();
   const uint32_t c0 = hist[tid];
   part[tid] = c0;
@@ -465,27 +487,30 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
   hist[tid] = ex;  // cursor
   __syncthreads();
   if (!staged) {
-    for (uint32_t r = tid; r < ptot; r += 1024) {
-      const uint32_t pos = atomicAdd(&hist[rec_bkt[pbase + r]], 1u);
-      sorted[pbase + pos] = rec_entry[pbase + r];
+    for (uint32_t r = tid; r < ptot_up; r += 1024) {
+      const bool valid = r < ptot;
+      const uint32_t pos = wave_counter_add(hist, valid ? rec_bkt[pbase + r] : 0u, valid);
+      if (valid) sorted[pbase + pos] = rec_entry[pbase + r];
     }
     return;
   }
   const uint32_t rounds = (ptot + FINE_ROUND - 1) / FINE_ROUND;
   uint32_t start = 0;  // first position this round owns = end of the previous round's last run (>= lo)
-  for (uint32_t rd = 0; rd < rounds; rd++) {
+  for (uint32_t rd = 0; rd < rounds;) {
     const uint32_t lo = rd * FINE_ROUND;
-    for (uint32_t r = tid; r < ptot; r += 1024) {
-      const uint32_t b = rec_bkt[pbase + r];
-      if (rounds > 1 && beg[b] / FINE_ROUND != rd) continue;
-      const uint32_t pos = atomicAdd(&hist[b], 1u);
+    for (uint32_t r = tid; r < ptot_up; r += 1024) {
+      const bool in = r < ptot;
+      const uint32_t b = in ? rec_bkt[pbase + r] : 0u;
+      const bool valid = in && (rounds == 1 || beg[b] / FINE_ROUND == rd);
+      const uint32_t pos = wave_counter_add(hist, b, valid);
+      if (!valid) continue;
       const uint32_t e = rec_entry[pbase + r];
       if (pos - lo < FINE_STAGE) stage[pos - lo] = e;
       else sorted[pbase + pos] = e;  // a run longer than the slack: the rest goes out directly
     }
     __syncthreads();
     // positions [lo, hi) were staged: hi = end of the last bucket of this round, capped by the stage
-    uint32_t hi = ptot;
+    uint32_t hi = ptot, next_rd = rounds;
     if (rd + 1 < rounds) {
       // first bucket of a later round = first b with beg[b] >= (rd + 1) * FINE_ROUND; its beg is the end of this round
       // (found by every thread from the monotone beg[] with a binary search: 10 steps)
@@ -496,11 +521,15 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
         else l = m + 1;
       }
       hi = (l < FINE_NB) ? beg[l] : ptot;
+      // the next round that OWNS a bucket: a run of 600 000 positions spans 18 rounds in which no bucket begins, and each
+      // of them used to walk all the partition's records for nothing
+      next_rd = (l < FINE_NB && beg[l] < ptot) ? beg[l] / FINE_ROUND : rounds;
     }
     uint32_t top = hi - lo;
     if (top > FINE_STAGE) top = FINE_STAGE;
     for (uint32_t k = start - lo + tid; k < top; k += 1024) sorted[pbase + lo + k] = stage[k];
     start = hi;
+    rd = next_rd;
     __syncthreads();
   }
 }
