@@ -768,10 +768,14 @@ def test_msm_degenerate_bases_and_scalars(ctx, group):
     P2, P3 = mul(2), mul(3)
     pts = [G, G, neg(G), G, None, P2, neg(P2), P3, P3]
     k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890AB % R
+    # (6 000 repetitions: 54 000 points per bucket -- several wave-items per heavy bucket in k_accum_heavy_nc, lanes that meet
+    # P + P and leave a marker, split buckets and tickets in the partial-sum mode of k_accum_heavy; also over prepared bases)
     for reps, scalars in (
         (1, [k] * 9),
         (1, [k, k, k, R - 1, 5, 0, 1, R - 1, R - 1]),
         (400, [k] * 9),
+        (6000, [k] * 9),
+        (6000, [k, k, k, R - 1, 5, 0, 1, R - 1, R - 1]),
     ):
         bases = pts * reps
         sc = scalars * reps
@@ -784,6 +788,10 @@ def test_msm_degenerate_bases_and_scalars(ctx, group):
         b = ctx.bases_g1(raw_b) if group == 1 else ctx.bases_g2(raw_b)
         got = (ctx.msm_g1 if group == 1 else ctx.msm_g2)(frs(sc), b)
         assert got == (to_b(want) if want is not None else bytes(width)), (reps, scalars[:3])
+        if reps >= 6000:
+            b.prepare()
+            got = (ctx.msm_g1 if group == 1 else ctx.msm_g2)(frs(sc), b)
+            assert got == (to_b(want) if want is not None else bytes(width)), (reps, scalars[:3], "prepared")
         b.free()
 
 

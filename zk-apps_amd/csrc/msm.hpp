@@ -138,8 +138,9 @@ struct MsmEngine {
   XYZZ<F>* segsum = nullptr;  // SLOTS x seg_cap: reductions of different slots may run on different streams
   XYZZ<F>* segw = nullptr;
   uint64_t seg_cap = 0;
-  XYZZ<F>* heavy_partial = nullptr;  // SLOTS x MSM_HEAVY_CAP x MSM_HSPLIT partial sums of heavy buckets
+  XYZZ<F>* heavy_partial = nullptr;  // SLOTS x (MSM_HPOOL + MSM_HNC_POOL) partial sums of heavy buckets (msm_impl.hpp)
   uint32_t* heavy_ticket = nullptr;  // SLOTS x MSM_HEAVY_CAP: workgroups of a split heavy bucket that have finished (k_accum_heavy)
+  uint32_t* heavy_plan = nullptr;    // SLOTS x MSM_HPLAN_WORDS: k_heavy_plan's work list for k_accum_heavy_nc (msm_impl.hpp)
   // per-(window, job) sums converted to the host representation; several MSMs can be
   // in flight on the stream, each with its own slot, pinned host copy and event
   XYZZ<HF>* partial = nullptr;    // device, SLOTS x SLOT_PTS

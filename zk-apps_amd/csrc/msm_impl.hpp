@@ -561,24 +561,37 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
 // The kernel also CLEARS the list for the slot's next MSM: every workgroup reads the length first, and the last one to
 // finish (a ticket word behind the list) resets length and ticket -- no hipMemsetAsync launch in front of an accumulation
 // (a kernel of its own that waited up to 0.8 ms for a slot on a full chip).  The buffer is zeroed once when it is allocated.
+// Round 5: one WAVE per listed bucket (lane l adds entries l, l + 64, ...; LDS tree of the 64 partial sums) instead of one
+// lane: the synthetic bases of the benchmarks and tests, P_i = G + i Q, meet P + P by arithmetic coincidence (a running sum
+// P_a - P_b + P_c IS P_(a - b + c)) about once per 10^7 insertions, and the one lane that then walked its bucket's ~32
+// entries with 16 us per dependent addition held the whole reduction back by 0.2 - 0.5 ms per MSM.
+template <class F>
+__device__ __forceinline__ XYZZ<F> block_tree_sum(XYZZ<F> acc, XYZZ<F>* sh);
 template <class F>
 __global__ void __launch_bounds__(64)
 k_accum_redo(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ begin,
              const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
              XYZZ<F>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket, uint32_t into) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   const uint32_t n = redo[0];
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {  // block-uniform
     const uint32_t b = redo[1 + k];
     const uint32_t beg = begin[b], end = beg + count[b];
-    // into: the accumulation was adding to an earlier MSM's bucket sums and left the listed buckets untouched
-    XYZZ<F> acc = into ? load_vec(buckets + b) : XYZZ<F>::infinity();
-    for (uint32_t j = beg; j < end; j++) {
+    XYZZ<F> acc = XYZZ<F>::infinity();
+    for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
       const uint32_t v = sorted[j];
       Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
       if (v >> 31) p.y = p.y.neg();
       acc.madd(p);
     }
-    store_vec(buckets + b, acc);
+    acc = block_tree_sum(acc, sh);
+    if (threadIdx.x == 0) {
+      // into: the accumulation was adding to an earlier MSM's bucket sums and left the listed buckets untouched
+      if (into) acc.add(load_vec(buckets + b));
+      store_vec(buckets + b, acc);
+    }
+    __syncthreads();
   }
   // every workgroup has read the length by now; the last one to get here clears the list for the slot's next MSM
   __syncthreads();
@@ -609,6 +622,262 @@ __device__ __forceinline__ XYZZ<F> block_tree_sum(XYZZ<F> acc, XYZZ<F>* sh) {
   return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the heavy buckets' additions in a kernel that RUNS BESIDE the light accumulation.
+// k_accum_heavy (below) adds with the complete group law: 320 registers and scratch, one wave per SIMD (1.6 G additions/s
+// against the light kernel's 6.5), and -- two-wave workgroups of that size -- it is not placed while the light kernel
+// still has workgroups to issue: the heavy buckets of a witness-like MSM started when the light ones
+// had finished.  Now the additions of POINTS into partial sums -- all but a few per cent of the work -- are made by
+// one-wave workgroups with the light kernel's own loop (call-free mixed additions, next table entry prefetched through
+// LDS: 168 registers, no scratch), every lane on its own stride of a sub-range:
+//   k_heavy_plan       one workgroup: list entry h -> (bucket, first entry, points, first wave-item); points per lane
+//                      chosen so that the partial sums fit the pool
+//   k_accum_heavy_nc   wave-item = 64 x PL consecutive entries of a heavy bucket; lane l adds entries l, l + 64, ... and
+//                      stores ONE partial sum (G2: 32 lane pairs); a lane that meets P + P stores a marker instead
+//   k_accum_heavy<..>  in PARTIAL mode: sums each bucket's partials with the complete law (LDS trees, ticket for split
+//                      buckets: the code that used to add the points); a marked partial is recomputed there, serially,
+//                      from its <= PL points.  In POINT mode (plan too long for the pool, partitioned big windows,
+//                      A/B accumulate-into forms) it is the kernel of rounds 1-4.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t MSM_HNC_ENT = 1024;        // list entries the plan holds (= k_heavy_plan's block, <= MSM_HEAVY_CAP ticket words)
+constexpr uint32_t MSM_HNC_POOL = 131072;     // first-level partial sums per MSM slot
+constexpr uint32_t MSM_HNC_MIN_PL = 8;        // points per lane at least (the tree behind costs ~1.4 additions per partial)
+constexpr uint32_t MSM_HPLAN_WORDS = 4 + 4 * (MSM_HNC_ENT + 1);
+// hplan: [0] wave-items, [1] points per lane PL, [2] entries, [3] mode (0 = partial sums by k_accum_heavy_nc, 1 = point mode),
+// then per entry {bucket, first slot in sorted[], points, first wave-item}; entry [entries] = {.., .., .., wave-items}
+// ONE WAVE (16 entries per lane): a 1 024-thread workgroup is not placed while accumulation waves hold 504 of a SIMD's 512
+// registers (it sat 0.66 - 2.2 ms in front of the heavy kernels in the first traces of this round); a wave fits the slot
+// one retiring accumulation wave frees.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64)
+k_heavy_plan(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ count, const uint32_t* __restrict__ begin,
+             uint32_t* __restrict__ hplan, uint32_t lanes, uint32_t force_point_mode) {
+  constexpr uint32_t PER = MSM_HNC_ENT / 64;
+  const uint32_t lane = threadIdx.x, n = heavy[0];
+  if (force_point_mode || n > MSM_HNC_ENT) {
+    if (lane == 0) {
+      hplan[0] = 0;
+      hplan[1] = 0;
+      hplan[2] = 0;
+      hplan[3] = 1;
+    }
+    return;
+  }
+  // lane owns entries [lane * PER, (lane + 1) * PER)
+  uint32_t c[PER], mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t h = lane * PER + k;
+    c[k] = h < n ? count[heavy[1 + h]] : 0u;
+    mine += c[k];
+  }
+  auto wave_incl = [&](uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)v, off);
+      if ((int)lane >= off) v += t;
+    }
+    return v;
+  };
+  const uint32_t total = (uint32_t)__shfl((int)wave_incl(mine), 63);  // (entries < 2^32: the sort's slot arithmetic)
+  // partial sums = lanes x wave-items <= total / PL + lanes x n
+  const uint32_t room = MSM_HNC_POOL - lanes * MSM_HNC_ENT;
+  uint32_t pl = (total + room - 1) / room;
+  if (pl < MSM_HNC_MIN_PL) pl = MSM_HNC_MIN_PL;
+  const uint32_t per_item = lanes * pl;
+  uint32_t items[PER], my_items = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    items[k] = (c[k] + per_item - 1) / per_item;
+    my_items += items[k];
+  }
+  const uint32_t incl = wave_incl(my_items);
+  uint32_t run = incl - my_items;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t h = lane * PER + k;
+    if (h < n) {
+      const uint32_t b = heavy[1 + h];
+      uint32_t* e = hplan + 4 + 4 * h;
+      e[0] = b;
+      e[1] = begin[b];
+      e[2] = c[k];
+      e[3] = run;
+    }
+    run += items[k];
+  }
+  if (lane == 63) {
+    hplan[0] = incl;
+    hplan[1] = pl;
+    hplan[2] = n;
+    hplan[3] = 0;
+    hplan[4 + 4 * n + 3] = incl;
+  }
+}
+// the plan entry that owns wave-item `it` (last e with first_item[e] <= it): uniform over the wave
+__device__ __forceinline__ uint32_t heavy_plan_entry(const uint32_t* __restrict__ ent, uint32_t n_ent, uint32_t it) {
+  uint32_t lo = 0, hi = n_ent;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (ent[4 * mid + 3] <= it) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+// what a lane that met P + P (or P - P) leaves instead of its partial sum: "infinity" with a non-zero zzz word
+template <class F>
+__device__ __forceinline__ XYZZ<F> heavy_marker() {
+  XYZZ<F> m = XYZZ<F>::infinity();
+  m.zzz.l[0] = 1;
+  return m;
+}
+
+template <class F, int W>
+__global__ void __launch_bounds__(64, W)
+k_accum_heavy_nc(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hplan,
+                 XYZZ<F>* __restrict__ pool) {
+  constexpr int CHUNKS = sizeof(Affine<F>) / 16;
+  __shared__ uint4 tile[CHUNKS][64];
+  if (hplan[3] != 0) return;  // point mode: k_accum_heavy takes the list
+  const uint32_t n_items = hplan[0], pl = hplan[1], n_ent = hplan[2];
+  const uint32_t* __restrict__ const ent = hplan + 4;
+  const uint32_t lane = threadIdx.x;
+  auto fetch = [&](uint32_t v) {
+    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[q][0], 16, 0, 0);
+  };
+  auto take = [&](Affine<F>& p) {
+    uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) d[q] = tile[q][lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const uint32_t e = heavy_plan_entry(ent, n_ent, it);
+    const uint32_t beg = ent[4 * e + 1], cnt = ent[4 * e + 2], first = ent[4 * e + 3];
+    const uint32_t w0 = beg + (it - first) * 64u * pl;
+    const uint32_t w1 = (w0 + 64u * pl < beg + cnt) ? w0 + 64u * pl : beg + cnt;
+    XYZZ<F>* const dst = pool + (size_t)it * 64 + lane;
+    XYZZ<F> acc;
+    uint32_t j = w0 + lane;
+    bool have = false;
+    for (; j < w1; j += 64) {  // the lane's first entry that is not the point at infinity starts its sum
+      const uint32_t v = sorted[j];
+      Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+      if (affine_is_zero_words(p)) continue;
+      if (v >> 31) p.y = p.y.neg();
+      acc.x = p.x;
+      acc.y = p.y;
+      acc.zz = F::one();
+      acc.zzz = F::one();
+      have = true;
+      j += 64;
+      break;
+    }
+    if (!have) {
+      store_vec(dst, XYZZ<F>::infinity());
+      continue;
+    }
+    uint32_t v_cur = 0, v_next = 0;
+    if (j < w1) {
+      v_cur = sorted[j];
+      fetch(v_cur);
+      if (j + 64 < w1) v_next = sorted[j + 64];
+    }
+    bool bad = false;
+    for (; j < w1; j += 64) {
+      Affine<F> p;
+      take(p);
+      const uint32_t v = v_cur;
+      if (j + 64 < w1) {
+        fetch(v_next);
+        v_cur = v_next;
+        if (j + 128 < w1) v_next = sorted[j + 128];
+      }
+      if (affine_is_zero_words(p)) continue;
+      if (!madd_generic(acc, p, 0u - (v >> 31))) {
+        bad = true;  // k_accum_heavy recomputes this lane's <= PL points with the complete law
+        break;
+      }
+    }
+    if (bad) store_vec(dst, heavy_marker<F>());
+    else store_vec(dst, acc);
+    // (a lane that left the loop early still has a direct-to-LDS load in flight into its own column of the tile: the next
+    // item's first fetch into the same column is ordered behind it, and take() waits for both)
+  }
+}
+
+// G2: 32 lane pairs per wave-item (field28.hpp Fq2P), the light G2 kernel's loop
+template <int W>
+__global__ void __launch_bounds__(64, W)
+k_accum_heavy_nc_g2(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hplan,
+                    XYZZ<Fq2_28>* __restrict__ pool) {
+  if (hplan[3] != 0) return;
+  const uint32_t n_items = hplan[0], pl = hplan[1], n_ent = hplan[2];
+  const uint32_t* __restrict__ const ent = hplan + 4;
+  const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u;
+  auto load_point = [&](uint32_t v, Affine<Fq2P>& p) {  // true = the point at infinity (all four components exact zeros)
+    const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));
+    p.x.v = ld_comp(src + comp);
+    p.y.v = ld_comp(src + 2 + comp);
+    uint32_t o = (uint32_t)p.y.v.l[0];
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+    if (o != 0) return false;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) o |= (uint32_t)p.x.v.l[i] | (uint32_t)p.y.v.l[i];
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+    return o == 0;
+  };
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const uint32_t e = heavy_plan_entry(ent, n_ent, it);
+    const uint32_t beg = ent[4 * e + 1], cnt = ent[4 * e + 2], first = ent[4 * e + 3];
+    const uint32_t w0 = beg + (it - first) * 32u * pl;
+    const uint32_t w1 = (w0 + 32u * pl < beg + cnt) ? w0 + 32u * pl : beg + cnt;
+    Fq28* const dst = reinterpret_cast<Fq28*>(pool + (size_t)it * 32 + pair);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+    XYZZ<Fq2P> acc;
+    uint32_t j = w0 + pair;
+    bool have = false, bad = false;
+    for (; j < w1; j += 32) {
+      Affine<Fq2P> p;
+      const uint32_t v = sorted[j];
+      if (load_point(v, p)) continue;
+      acc.x = p.x;
+      acc.y = (v >> 31) ? p.y.neg() : p.y;
+      acc.zz = Fq2P::one();
+      acc.zzz = Fq2P::one();
+      have = true;
+      j += 32;
+      break;
+    }
+    if (have) {
+      for (; j < w1; j += 32) {
+        Affine<Fq2P> p;
+        const uint32_t v = sorted[j];
+        if (load_point(v, p)) continue;
+        if (!madd_generic(acc, p, 0u - (v >> 31))) {  // pair-uniform
+          bad = true;
+          break;
+        }
+      }
+    }
+    if (!have || bad) {
+      const Fq28 z = Fq28::zero();
+      Fq28 mk = z;
+      mk.l[0] = (bad && comp == 0) ? 1 : 0;  // marker: zzz.c0 word 0 (k_accum_heavy_g2_split recomputes the pair's points)
+      st_comp(dst + comp, z);
+      st_comp(dst + 2 + comp, z);
+      st_comp(dst + 4 + comp, z);
+      st_comp(dst + 6 + comp, mk);
+    } else {
+      st_comp(dst + comp, acc.x.v);
+      st_comp(dst + 2 + comp, acc.y.v);
+      st_comp(dst + 4 + comp, acc.zz.v);
+      st_comp(dst + 6 + comp, acc.zzz.v);
+    }
+  }
+}
+
 // grid = (MSM_HSPLIT, groups).  The sub-ranges of a split bucket are added up by whichever of its workgroups finishes
 // last (ticket word per heavy bucket, left at zero for the slot's next MSM): there is no separate combine launch -- a
 // kernel of 330-register waves (G2) that found no SIMD until the accumulation beside it had drained, with the reduction
@@ -636,15 +905,41 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
               const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
               const uint32_t* __restrict__ sorted, XYZZ<F>* __restrict__ buckets,
               XYZZ<F>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t into, uint32_t h_first,
-              uint32_t h_limit) {
+              uint32_t h_limit, const uint32_t* __restrict__ hplan, const XYZZ<F>* __restrict__ pool_nc) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
   __shared__ uint32_t is_last;
+  // PARTIAL mode (hplan given and its mode word 0): the "points" of list entry h are the partial sums k_accum_heavy_nc left
+  // in pool_nc -- 64 per wave-item, in wave-item order -- and the list is the plan's; POINT mode: the kernel of rounds 1-4
+  const bool pmode = hplan != nullptr && hplan[3] == 0;
+  const uint32_t* __restrict__ const ent = hplan + 4;
+  const uint32_t pl_nc = pmode ? hplan[1] : 0u;
+  // a partial sum, or -- where its lane met P + P -- the lane's points again with the complete law
+  auto partial_at = [&](uint32_t h, uint32_t j) {
+    XYZZ<F> v = load_vec(pool_nc + j);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) o |= (uint32_t)v.zz.l[i];
+    if (o == 0 && v.zzz.l[0] == 1) {
+      const uint32_t it = j >> 6, ln = j & 63u;
+      const uint32_t beg = ent[4 * h + 1], cnt = ent[4 * h + 2], first = ent[4 * h + 3];
+      const uint32_t w0 = beg + (it - first) * 64u * pl_nc;
+      const uint32_t w1 = (w0 + 64u * pl_nc < beg + cnt) ? w0 + 64u * pl_nc : beg + cnt;
+      v = XYZZ<F>::infinity();
+      for (uint32_t jj = w0 + ln; jj < w1; jj += 64) {
+        const uint32_t sv = sorted[jj];
+        Affine<F> p = load_vec(bases + (sv & 0x7fffffffu));
+        if (sv >> 31) p.y = p.y.neg();
+        v.madd(p);
+      }
+    }
+    return v;
+  };
   // list entries [h_first, min(length, h_limit)): one launch takes the whole list, or -- plans whose partial top window
   // puts thousands of buckets above the threshold (windowed c = 20: 2^14 buckets of 4 500 points at 2^26 terms) -- the
   // first MSM_HEAVY_CAP entries go to a (MSM_HSPLIT, 8) grid and the rest to a second launch with one workgroup per
   // list entry (a (MSM_HSPLIT, 8) grid would walk them with 8 workgroups)
-  const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;
+  const uint32_t n_heavy = pmode ? hplan[2] : (heavy[0] < h_limit ? heavy[0] : h_limit);
   // into: the bucket's sum is added to what an earlier MSM left in the bucket (complete addition, one thread)
   auto put = [&](uint32_t b, XYZZ<F> v) {
     if (into) v.add(load_vec(buckets + b));
@@ -659,8 +954,10 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
   // (a launch for the entries beyond the split capacity -- one item per bucket -- strides the list directly)
   const bool tail = h_first >= MSM_HEAVY_CAP;
   for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
-    const uint32_t b = heavy[1 + h];
-    const uint32_t cnt = count[b], beg0 = begin[b];
+    const uint32_t b = pmode ? ent[4 * h] : heavy[1 + h];
+    // (partial mode: positions in pool_nc -- 64 partial sums per wave-item of the entry)
+    const uint32_t cnt = pmode ? (ent[4 * (h + 1) + 3] - ent[4 * h + 3]) * 64u : count[b];
+    const uint32_t beg0 = pmode ? ent[4 * h + 3] * 64u : begin[b];
     // as many sub-ranges as the bucket can feed: ~4 points per thread before the tree (a bucket of 400 points on
     // all 64 x 128 threads is 64 trees of points at infinity: measured 10 % of all instructions of a 2^14 group).
     // (8 points per thread -- one workgroup, no partials and no second tree for the 600 bit variables of a small
@@ -679,11 +976,15 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
         beg = sb < end ? sb : end;
       }
       XYZZ<F> acc = XYZZ<F>::infinity();
-      for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
-        const uint32_t v = sorted[j];
-        Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
-        if (v >> 31) p.y = p.y.neg();
-        acc.madd(p);
+      if (pmode) {
+        for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) acc.add(partial_at(h, j));
+      } else {
+        for (uint32_t j = beg + threadIdx.x; j < end; j += blockDim.x) {
+          const uint32_t v = sorted[j];
+          Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+          if (v >> 31) p.y = p.y.neg();
+          acc.madd(p);
+        }
       }
       acc = block_tree_sum(acc, sh);
       if (nsplit == 1) {
@@ -953,18 +1254,43 @@ k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t*
                        const uint32_t* __restrict__ count, const uint32_t* __restrict__ heavy,
                        const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets,
                        XYZZ<Fq2_28>* __restrict__ heavy_partial, uint32_t* __restrict__ ticket, uint32_t h_first,
-                       uint32_t h_limit) {
+                       uint32_t h_limit, const uint32_t* __restrict__ hplan, const XYZZ<Fq2_28>* __restrict__ pool_nc) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
   __shared__ uint32_t is_last;
   const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
-  const uint32_t n_heavy = heavy[0] < h_limit ? heavy[0] : h_limit;  // list range [h_first, h_limit): see k_accum_heavy
+  // PARTIAL / POINT mode: see k_accum_heavy (here 32 partial sums per wave-item, one per lane pair of k_accum_heavy_nc_g2)
+  const bool pmode = hplan != nullptr && hplan[3] == 0;
+  const uint32_t* __restrict__ const ent = hplan + 4;
+  const uint32_t pl_nc = pmode ? hplan[1] : 0u;
+  auto partial_at = [&](uint32_t h, uint32_t j) {  // pair-uniform
+    XYZZ<Fq2P> v = ld_xyzz_split(pool_nc + j, comp);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) o |= (uint32_t)v.zz.v.l[i];
+    uint32_t mk = (comp == 0 && v.zzz.v.l[0] == 1) ? 1u : 0u;
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+    mk |= (uint32_t)__builtin_amdgcn_mov_dpp((int)mk, 0xB1, 0xF, 0xF, true);
+    if (o == 0 && mk == 1) {
+      const uint32_t it = j >> 5, pr = j & 31u;
+      const uint32_t beg = ent[4 * h + 1], cnt = ent[4 * h + 2], first = ent[4 * h + 3];
+      const uint32_t w0 = beg + (it - first) * 32u * pl_nc;
+      const uint32_t w1 = (w0 + 32u * pl_nc < beg + cnt) ? w0 + 32u * pl_nc : beg + cnt;
+      v = XYZZ<Fq2P>::infinity();
+      for (uint32_t jj = w0 + pr; jj < w1; jj += 32) v.madd(ld_affine_split(bases, sorted[jj], comp));
+    } else if (o == 0) {
+      v = XYZZ<Fq2P>::infinity();
+    }
+    return v;
+  };
+  const uint32_t n_heavy = pmode ? hplan[2] : (heavy[0] < h_limit ? heavy[0] : h_limit);  // list range [h_first, h_limit): see k_accum_heavy
   const uint32_t n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;  // flat deal of (bucket, sub-range) items
   uint32_t item0 = 0;
   const bool tail = h_first >= MSM_HEAVY_CAP;
   for (uint32_t h = tail ? h_first + wg : h_first; h < n_heavy; h += tail ? n_wg : 1u) {
-    const uint32_t b = heavy[1 + h];
-    const uint32_t cnt = count[b], beg0 = begin[b];
+    const uint32_t b = pmode ? ent[4 * h] : heavy[1 + h];
+    const uint32_t cnt = pmode ? (ent[4 * (h + 1) + 3] - ent[4 * h + 3]) * 32u : count[b];
+    const uint32_t beg0 = pmode ? ent[4 * h + 3] * 32u : begin[b];
     const uint32_t nsplit = tail ? 1u : heavy_nsplit(h, cnt, 4 * npair, item0);  // ~4 points per lane pair before the tree
     const uint32_t base = item0;  // first pool slot of the bucket's partial sums (see k_accum_heavy)
     const uint32_t r0 = tail ? 0u : (wg + n_wg - base % n_wg) % n_wg;
@@ -978,7 +1304,11 @@ k_accum_heavy_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t*
         beg = sb < end ? sb : end;
       }
       XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-      for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));  // pair-uniform
+      if (pmode) {
+        for (uint32_t j = beg + pair; j < end; j += npair) acc.add(partial_at(h, j));  // pair-uniform
+      } else {
+        for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));  // pair-uniform
+      }
       acc = pair_tree_sum(acc, sh, pair, npair, comp);
       if (nsplit == 1) {
         if (pair == 0) st_xyzz_split(buckets + b, acc, comp);
@@ -1008,14 +1338,18 @@ __global__ void __launch_bounds__(64, 2)
 k_accum_redo_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin,
                       const uint32_t* __restrict__ count, const uint32_t* __restrict__ sorted,
                       XYZZ<Fq2_28>* __restrict__ buckets, uint32_t* __restrict__ redo, uint32_t* __restrict__ ticket) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  XYZZ<Fq2_28>* sh = reinterpret_cast<XYZZ<Fq2_28>*>(lds_raw);
   const uint32_t n = redo[0];
-  const uint32_t comp = threadIdx.x & 1u;
-  for (uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 1; k < n; k += (gridDim.x * blockDim.x) >> 1) {  // pair-uniform
+  const uint32_t pair = threadIdx.x >> 1, comp = threadIdx.x & 1u, npair = blockDim.x >> 1;
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {  // block-uniform: a wave (32 lane pairs) per listed bucket
     const uint32_t b = redo[1 + k];
     const uint32_t beg = begin[b], end = beg + count[b];
     XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
-    for (uint32_t j = beg; j < end; j++) acc.madd(ld_affine_split(bases, sorted[j], comp));
-    st_xyzz_split(buckets + b, acc, comp);
+    for (uint32_t j = beg + pair; j < end; j += npair) acc.madd(ld_affine_split(bases, sorted[j], comp));
+    acc = pair_tree_sum(acc, sh, pair, npair, comp);
+    if (pair == 0) st_xyzz_split(buckets + b, acc, comp);
+    __syncthreads();
   }
   // every workgroup has read the length by now; the last one to get here clears the list for the slot's next MSM
   __syncthreads();
@@ -1049,6 +1383,8 @@ void MsmEngine<F>::release() {
   tree_stage = nullptr;
   if (heavy_partial) (void)hipFree(heavy_partial);
   heavy_partial = nullptr;
+  if (heavy_plan) (void)hipFree(heavy_plan);
+  heavy_plan = nullptr;
   if (heavy_ticket) (void)hipFree(heavy_ticket);
   heavy_ticket = nullptr;
   if (redo) (void)hipFree(redo);
@@ -1114,7 +1450,9 @@ hipError_t MsmEngine<F>::reserve(uint64_t n, bool shared_too) {
   if ((e = hipMalloc(&segw, sizeof(XYZZ<F>) * seg_cap * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&partial, sizeof(XYZZ<HF>) * SLOTS * SLOT_PTS)) != hipSuccess) return e;
   if ((e = hipMalloc(&tree_stage, sizeof(XYZZ<F>) * MSM_STAGE_PTS * nslots)) != hipSuccess) return e;
-  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * MSM_HEAVY_CAP * MSM_HSPLIT * nslots)) != hipSuccess) return e;  // per slot
+  // per slot: MSM_HPOOL partial sums of split buckets (k_accum_heavy) + MSM_HNC_POOL first-level ones (k_accum_heavy_nc)
+  if ((e = hipMalloc(&heavy_partial, sizeof(XYZZ<F>) * ((size_t)MSM_HPOOL + MSM_HNC_POOL) * nslots)) != hipSuccess) return e;
+  if ((e = hipMalloc(&heavy_plan, sizeof(uint32_t) * MSM_HPLAN_WORDS * nslots)) != hipSuccess) return e;
   if ((e = hipMalloc(&heavy_ticket, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots)) != hipSuccess) return e;
   if ((e = hipMemset(heavy_ticket, 0, sizeof(uint32_t) * MSM_HEAVY_CAP * nslots)) != hipSuccess) return e;  // every use leaves zeros behind
   if ((e = hipMalloc(&redo, sizeof(uint32_t) * (need + 2) * nslots)) != hipSuccess) return e;  // one list per slot
@@ -1234,24 +1572,42 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   hipStream_t heavy_stream[MSM_MULTI_MAX];
   auto launch_heavy = [&](int m) {
     const MsmSort& sort = *sorts[m];
-    XYZZ<F>* const hp = heavy_partial + (size_t)slots[m] * MSM_HEAVY_CAP * MSM_HSPLIT;  // MSMs of different slots may overlap
+    // MSMs of different slots may overlap: partial sums, plan and tickets per slot
+    XYZZ<F>* const hp = heavy_partial + (size_t)slots[m] * ((size_t)MSM_HPOOL + MSM_HNC_POOL);
+    XYZZ<F>* const pool_nc = hp + MSM_HPOOL;
+    uint32_t* const hplan = heavy_plan + (size_t)slots[m] * MSM_HPLAN_WORDS;
+    uint32_t* const tk = heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP;
     const bool wide_tail = !pl.shared && pl.c > 16;  // partitioned big windows: see k_accum_heavy
+    // the call-free kernels take the additions of points (DESIGN.md 4.1 "heavy buckets"); not for lists the plan cannot
+    // hold (decided on the device), the partitioned big windows' thousands of entries, or the A/B accumulate-into forms
+    // (A/B library: ZKMI_HEAVY_NC=0 = the complete-law kernel of rounds 1-4 for everything)
+    const bool nc = ZK_TUNE("ZKMI_HEAVY_NC", 1) != 0 && !wide_tail && !into_of(m);
+    constexpr uint32_t lanes = std::is_same<F, Fq2_28>::value ? 32u : 64u;
+    if (nc) {
+      hipLaunchKernelGGL(k_heavy_plan<0>, dim3(1), dim3(64), 0, heavy_stream[m], sort.heavy, sort.count, sort.begin, hplan, lanes, 0u);
+      // one-wave workgroups, grid-strided over the wave-items: twice the chip's wave slots (an empty list costs one placement)
+      if constexpr (std::is_same<F, Fq2_28>::value)
+        hipLaunchKernelGGL((k_accum_heavy_nc_g2<2>), dim3(4096), dim3(64), 0, heavy_stream[m], d_bases[m], sort.sorted, hplan, pool_nc);
+      else
+        hipLaunchKernelGGL((k_accum_heavy_nc<F, 3>), dim3(6144), dim3(64), 0, heavy_stream[m], d_bases[m], sort.sorted, hplan, pool_nc);
+    }
+    const uint32_t* const plan_arg = nc ? hplan : nullptr;
     if constexpr (std::is_same<F, Fq2_28>::value) {
       hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
-                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, 0u, wide_tail ? MSM_HEAVY_CAP : 0xffffffffu);
+                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, 0u,
+                         wide_tail ? MSM_HEAVY_CAP : 0xffffffffu, plan_arg, pool_nc);
       if (wide_tail)
         hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
-                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                           heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, MSM_HEAVY_CAP, 0xffffffffu);
+                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, MSM_HEAVY_CAP, 0xffffffffu,
+                           (const uint32_t*)nullptr, pool_nc);
     } else {
       hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
-                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                         heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u, 0u, wide_tail ? MSM_HEAVY_CAP : 0xffffffffu);
+                         d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, into_of(m) ? 1u : 0u, 0u,
+                         wide_tail ? MSM_HEAVY_CAP : 0xffffffffu, plan_arg, pool_nc);
       if (wide_tail)
         hipLaunchKernelGGL(k_accum_heavy<F>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
-                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp,
-                           heavy_ticket + (size_t)slots[m] * MSM_HEAVY_CAP, into_of(m) ? 1u : 0u, MSM_HEAVY_CAP, 0xffffffffu);
+                           d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, into_of(m) ? 1u : 0u, MSM_HEAVY_CAP,
+                           0xffffffffu, (const uint32_t*)nullptr, pool_nc);
     }
   };
   for (int m = 0; m < nm; m++) {
@@ -1381,6 +1737,11 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     nchunk = segs_per_win / per_block;
     if (nchunk > MSM_TREE_T) nchunk = MSM_TREE_T;
     if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS) nchunk = 1;
+  } else if (!pl.shared && tot_b <= (1u << 19) && segs_per_win > per_block) {
+    // one windowed MSM of up to 2^19 buckets: as many slices as the stage holds (16 windows x 13 jobs: 16), see plan_set_heavy
+    // (... and as the chip holds at once: 3 328 workgroups of 9 dependent additions each, in three rounds, took longer than 208 of 23)
+    nchunk = MSM_TREE_T;
+    while (nchunk > 1 && ((uint64_t)njobs * pl.nwin * nchunk > 1024 || nchunk * per_block > segs_per_win)) nchunk >>= 1;
   } else if (!pl.shared && pl.c > 16) {
     // partitioned big windows: 2^(c-5) segments per (window, job) list on ONE workgroup are a chain of 2^(c-12) dependent
     // additions (5 ms at c = 20); sliced, as many slices as the stage holds (16 at 13 windows x 16 jobs)
@@ -1410,10 +1771,10 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       // heavy buckets are never listed, so the heavy kernels may still be running
       uint32_t* const redo = redo_of(m);
       if constexpr (std::is_same<F, Fq2_28>::value)
-        hipLaunchKernelGGL(k_accum_redo_g2_split<0>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk,
+        hipLaunchKernelGGL(k_accum_redo_g2_split<0>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 32, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk,
                            redo, redo + cap_buckets + 1);
       else
-        hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
+        hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 64, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
                            redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
       // the list reads the sort: the next sort must wait for this kernel too
       if ((e = hipEventRecord(redo_done[slot], st_reduce)) != hipSuccess) return e;

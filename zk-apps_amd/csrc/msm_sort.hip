@@ -728,6 +728,10 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
   // additions, against 16 + 23 with 8-bucket segments and one workgroup per job), 16 buckets once there are enough
   // segments to fill the chip
   p.seg_log = buckets <= (1u << 14) ? 1 : buckets <= (1u << 15) ? 2 : buckets <= (1u << 16) ? 3 : 4;
+  // One windowed MSM by itself (the generic entry points up to 2^23 terms: 16 windows x 2^15 buckets) is a latency chain like a
+  // small proof's: nothing else fills the chip while its reduction runs -- 32 dependent additions per 16-bucket segment
+  // (0.52 ms at 2^20 terms) and 23 per tree-sum job (0.36 ms).  8-bucket segments and sliced job lists: 16 + 13.
+  if (!p.shared && buckets <= (1u << 19) && p.seg_log > 3) p.seg_log = 3;
   {
     const int seg_env = ZK_TUNE("ZKMI_SEG_LOG", 0);  // A/B library: segment length of big plans
     // (the segment arrays hold max(buckets / 16, 2^16) entries: msm_impl.hpp msm_max_segments)
