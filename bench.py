@@ -245,6 +245,7 @@ def pmc_traffic(path, kernel):
     guide's x2 correction for 128-byte coalesced requests is NOT applied.
     A missing file or kernel yields traffic = None with a note (the timing above it stays valid)."""
     pmc_traffic.valu = pmc_traffic.name = pmc_traffic.total_valu = pmc_traffic.source = None
+    pmc_traffic.held_clock_ghz = pmc_traffic.alone_ms = None
     if path == "none":
         return None, "PMC summary lookup disabled (--pmc-summary none)"
     try:
@@ -280,6 +281,8 @@ def pmc_traffic(path, kernel):
             if fetch is None or write is None:
                 break
             pmc_traffic.valu = r.get("SQ_INSTS_VALU_avg_per_dispatch")
+            pmc_traffic.held_clock_ghz = r.get("held_clock_ghz_avg_per_dispatch")
+            pmc_traffic.alone_ms = (r.get("alone_ns_avg_per_dispatch") or 0) / 1e6 or None
             return (fetch + write) * 1024.0, (
                 "bytes/launch = (FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) from %s (separate rocprofv3 --pmc passes of "
                 "this command; uncorrected: per-lane gathers of table entries, 64-B requests)" % (fetch, write, path))
@@ -291,9 +294,17 @@ pmc_traffic.valu = None
 pmc_traffic.name = None
 pmc_traffic.total_valu = None
 pmc_traffic.source = None
-# 1024 SIMDs x 2.4 GHz / 4 cycles: v_mad_u64_u32 / v_mad_i64_i32 (78 % of the kernel's instructions) issue once per
+pmc_traffic.held_clock_ghz = None
+pmc_traffic.alone_ms = None
+# 1024 SIMDs x 2.4 GHz / 4 cycles: v_mad_u64_u32 / v_mad_i64_i32 (77 % of the kernel's instructions) issue once per
 # 4 cycles per SIMD (scripts/ubench.hip); under this load the chip holds ~1.95 GHz, so ~500 G/s is what is attainable
 VALU_ISSUE_PEAK = 614.4e9
+# The same ceiling for the accumulation loop's ACTUAL opcode mix: its 4 619 VALU instructions per addition cost 0.972
+# multiply-add slots on average (simple VOP2 operations -- 8 % of the mix -- issue in 0.55 of a slot, 64-bit shifts / adds,
+# v_mul_lo and VOP3 forms in 1.05: scripts/isa_mix_report.py over scripts/ubench_ops.hip's measured issue costs,
+# profiles/r05/experiments/isa_mix_k_accum_g1_nc.txt)
+VALU_MIX_SLOTS_PER_INSTR = 0.972
+VALU_ISSUE_PEAK_ACTUAL_MIX = VALU_ISSUE_PEAK / VALU_MIX_SLOTS_PER_INSTR
 
 
 def secondary_measurements(z, ctx, log_n):
@@ -560,8 +571,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the H2D-inclusive and whole-MSM measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
-    ap.add_argument("--pmc-summary", default="profiles/r04/pmc_summary_bench_steps3.json")
-    ap.add_argument("--msm-pmc-summary", default="profiles/r04/pmc_summary_msm26_steps1.json")
+    ap.add_argument("--pmc-summary", default="profiles/r05/pmc_summary_bench_steps3.json")
+    ap.add_argument("--msm-pmc-summary", default="profiles/r05/pmc_summary_msm26_steps1.json")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20 if args.workload == "proofs" else 3
@@ -778,9 +789,19 @@ def main():
         # the roofline that actually bounds the dominant kernel, as an object of its own: `roofline` keeps the HBM figures
         # BASELINE.json's metric asks for (bound = "hbm"), a consumer that classifies kernels by `bound` reads this one
         vi = out["roofline"]["valu_issue"]
-        out["roofline_valu"] = {"kernel": out["roofline"]["kernel"], "bound": "valu", "achieved": vi["achieved"], "peak": vi["peak"],
-                                "unit": vi["unit"], "frac": vi["frac"],
-                                "whole_proof_frac": out["roofline"].get("valu_issue_whole_proof", {}).get("frac")}
+        held = pmc_traffic.held_clock_ghz
+        out["roofline_valu"] = {"kernel": out["roofline"]["kernel"], "bound": "valu", "achieved": vi["achieved"],
+                                # peak for the kernel's ACTUAL opcode mix at 2.4 GHz (631.8); peak_flat = every instruction one 4-cycle slot (614.4)
+                                "peak": VALU_ISSUE_PEAK_ACTUAL_MIX / 1e9, "peak_flat": vi["peak"],
+                                "unit": vi["unit"], "frac": vi["achieved"] * 1e9 / VALU_ISSUE_PEAK_ACTUAL_MIX, "frac_of_flat_peak": vi["frac"],
+                                "whole_proof_frac": out["roofline"].get("valu_issue_whole_proof", {}).get("frac"),
+                                # the clock the chip holds under this kernel alone (GRBM_GUI_ACTIVE / 8 / duration, PMC summary) and
+                                # both ceilings at THAT clock: what the fractions above read against the silicon's sustained clock
+                                "held_clock_ghz": held,
+                                "alone": None if not (held and pmc_traffic.alone_ms and pmc_traffic.valu) else {
+                                    "ms": pmc_traffic.alone_ms, "achieved": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6,
+                                    "frac_of_peak_at_2.4GHz": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6 / (VALU_ISSUE_PEAK_ACTUAL_MIX / 1e9),
+                                    "frac_of_peak_at_held_clock": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6 / (VALU_ISSUE_PEAK_ACTUAL_MIX / 1e9 * held / 2.4)}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n, args.relation)
     if rank == 0:

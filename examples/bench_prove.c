@@ -205,6 +205,28 @@ static int check_proof(const zkey* k, size_state* st, int w, int j, const uint8_
   return 0;
 }
 
+/* n base points through the PRODUCT's ABI only (the generators of synthetic bases are test scaffolding,
+ * include/zkmi_testing.h): 4 096 distinct points G + i Q made on the host once, repeated cyclically up to n and uploaded with
+ * zkmi_bases_g1_load.  Repeated bases are valid inputs, and with random scalars two copies of a point now and then meet in
+ * one bucket with the same digit: the P + P redo paths get exercised on the way. */
+static int make_bases(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
+  enum { DISTINCT = 4096 };
+  static uint8_t* pts = NULL;
+  if (!pts) {
+    pts = malloc((size_t)96 * DISTINCT);
+    uint8_t q[96], k[32] = {0xEE, 0xFF, 0xC0};
+    if (!pts || zkmi_g1_generator(pts) != ZKMI_OK || zkmi_g1_mul(pts, k, q) != ZKMI_OK) return 1;
+    for (int i = 1; i < DISTINCT; i++)
+      if (zkmi_g1_add(pts + 96 * (size_t)(i - 1), q, pts + 96 * (size_t)i) != ZKMI_OK) return 1;
+  }
+  uint8_t* all = malloc((size_t)96 * n);
+  if (!all) return 1;
+  for (uint64_t i = 0; i < n; i++) memcpy(all + 96 * i, pts + 96 * (size_t)(i % DISTINCT), 96);
+  const int32_t rc = zkmi_bases_g1_load(ctx, all, n, 0, out);
+  free(all);
+  return rc == ZKMI_OK ? 0 : 1;
+}
+
 static int churn(zkmi_ctx* ctx, long ops, uint64_t seed) {
   enum { LG_MIN = 13, LG_MAX = 17 };
   static size_state sizes[LG_MAX + 1];
@@ -300,7 +322,10 @@ static int churn(zkmi_ctx* ctx, long ops, uint64_t seed) {
     } else if (kind < 84) {
       /* ---- a generic MSM (grows the sort buffers past what grouped keys reserved); prepared bases half of the time ---- */
       const int q = (int)(sm_next(&g) % 3);
-      if (!bases[q]) CHECK(zkmi_bases_g1_synthetic(ctx, msm_n[q], &bases[q]));
+      if (!bases[q] && make_bases(ctx, msm_n[q], &bases[q])) {
+        fprintf(stderr, "op %ld: could not make %llu base points\n", op, (unsigned long long)msm_n[q]);
+        return 1;
+      }
       if (!prepared[q] && (sm_next(&g) & 1)) {
         CHECK(zkmi_bases_g1_prepare(ctx, bases[q]));
         prepared[q] = 1;

@@ -99,12 +99,6 @@ int32_t zkmi_bases_g1_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int
 int32_t zkmi_bases_g1_free(zkmi_bases_g1* b);
 int32_t zkmi_bases_g2_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bases_g2** out);
 int32_t zkmi_bases_g2_free(zkmi_bases_g2* b);
-/* Synthetic bases P0 = G, P_{i+1} = P_i + [0xC0FFEE]G generated on the device
- * (SURVEY.md §8d).  Used by bench.py and the large-size property tests. */
-int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out);
-int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out);
-/* the slice P_first .. P_{first+n-1} of the same sequence (a rank's share of a point-split MSM) */
-int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n, zkmi_bases_g1** out);
 /* Bases used for many MSMs of their full length (an SRS, a proving-key query): build the table 2^(c w) * P_i once
  * (ceil(255 / c) x n points of HBM).  Afterwards zkmi_msm_g{1,2}[_dev] with n == the number of bases run the prover's
  * shared-bucket schedule (12-13 insertions per scalar instead of 16); other n, and the *_windows entry points, keep the
@@ -196,21 +190,6 @@ int32_t zkmi_msm_g1_multi(zkmi_ctx* const* ctxs, uint32_t n_dev, const void* con
  * length, heavy-bucket threshold. */
 int32_t zkmi_msm_plan_query(uint64_t n, int32_t shared, uint32_t out[6]);
 
-/* Host-executed self-test of the device limb representation (field28.hpp)
- * against the 32-bit-limb host arithmetic; *out_mismatches must be 0. */
-int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
-
-/* Host-executed self-test of the scalar multiplications of proof assembly (fixed-base tables for delta, joint
- * two-scalar multiplication) against plain double-and-add in G1 and G2; *out_mismatches must be 0. */
-int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
-/* Host self-test of the assembly pool (concurrent callers, every item exactly once); *out_mismatches must be 0. */
-int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint32_t* out_mismatches);
-/* Test hook for the bucket set two MSMs share (the prover's L and H queries): sum_i a_i P_i + sum_i b_i P_i
- * with the first MSM's accumulation left unreduced and the second one's kernels adding INTO its bucket array, one
- * reduction for both (prepared bases run the shared-bucket schedule, others the windowed one).  Scalars in HBM. */
-int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, const void* d_scalars_b, uint64_t n,
-                                      const zkmi_bases_g1* bases, uint8_t out_affine[96]);
-
 /* ---- group / encoding helpers (host) -------------------------------------- */
 int32_t zkmi_g1_compress(const uint8_t affine[96], uint8_t out[48]);
 int32_t zkmi_g1_decompress(const uint8_t in[48], uint8_t out_affine[96]);
@@ -238,17 +217,8 @@ int32_t zkmi_r1cs_create(uint32_t n_vars, uint32_t n_pub, uint32_t n_constraints
                          const uint32_t* c_rowptr, const uint32_t* c_col, const uint8_t* c_val,
                          zkmi_r1cs** out);
 int32_t zkmi_r1cs_free(zkmi_r1cs* r);
-/* Shielder-shaped synthetic relation with 2^log_n variables and
- * constraints + instance variables = 2^log_n; witness/public-input order as
- * UpdateNoteInput::new / update_note_circuit
- * (shielder/relations/src/relations/update_note.rs:47-88, :121, :127). */
-int32_t zkmi_shielder_r1cs(uint32_t log_n, zkmi_r1cs** out);
-int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z /* 2^log_n x 32 B */);
-/* Row a1: the same assignment from the relation's semantic inputs, in the order
- * UpdateNoteInput::new loads them (update_note.rs:47-88): op_pub, new note, old note, Merkle
- * path (shape bits + siblings, merkle_proof.rs:27-34), op_priv, old account.  The two public
- * "hash outputs" new_note_hash and merkle_root are computed by the relation's stand-in chain
- * and come back at indices 4 and 5 of out_z.  Public inputs = out_z[1..7). */
+/* Semantic inputs of the hash-free chain stand-in of the first builds (the relation itself and its assignment
+ * generators are test scaffolding now: include/zkmi_testing.h; the relation with real hashing is zkmi_update_note_*). */
 typedef struct {
   uint8_t bytes[32];
 } zkmi_fr;
@@ -261,7 +231,6 @@ typedef struct {
   zkmi_fr path[10];            /* MerkleProof::path                              */
   zkmi_fr old_account[2];      /* TOKENS_NUMBER balances                         */
 } zkmi_update_note_input;
-int32_t zkmi_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input* in, uint8_t* out_z);
 /* value mod r (SHA-256 outputs used as Scalars by the mock can exceed r) */
 int32_t zkmi_fr_reduce(const uint8_t in[32], uint8_t out[32]);
 int32_t zkmi_r1cs_shape(const zkmi_r1cs* r, uint32_t* n_vars, uint32_t* n_pub, uint32_t* n_constraints, uint32_t* log_n);
@@ -278,8 +247,6 @@ int32_t zkmi_r1cs_is_satisfied(const zkmi_r1cs* r, const uint8_t* z);
  * coset shift 7 (bn256::Fr::MULTIPLICATIVE_GENERATOR). */
 typedef struct zkmi_bn_bases zkmi_bn_bases;
 int32_t zkmi_bn254_bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bn_bases** out);
-/* P_i = [1 + i * 0xC0FFEE] G, generated in HBM (tests / timing) */
-int32_t zkmi_bn254_bases_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bn_bases** out);
 int32_t zkmi_bn254_bases_read(zkmi_ctx* ctx, const zkmi_bn_bases* b, uint64_t first, uint64_t count, uint8_t* out);
 int32_t zkmi_bn254_bases_free(zkmi_bn_bases* b);
 /* Fixed-base preparation of an SRS that is committed to many times (a halo2 prover commits every
@@ -359,9 +326,6 @@ int32_t zkmi_poseidon_merkle_paths_dev(zkmi_ctx* ctx, const void* d_nodes, uint3
  * d_leaves n x 32 B, d_shape n x depth bytes, d_paths n x depth x 32 B -> d_roots n x 32 B. */
 int32_t zkmi_poseidon_merkle_roots_dev(zkmi_ctx* ctx, int32_t field, const void* d_leaves, const void* d_shape,
                                        const void* d_paths, uint32_t depth, uint64_t n, void* d_roots);
-/* Host-executed self-test: the sparse partial-round form the kernels run equals the plain
- * 64-round definition on `iters` random states; *out_mismatches must be 0. */
-int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
 
 /* ---- rows a1-a5 with real hashing: the update_note relation ---------------- *
  * update_note_circuit (shielder/relations/src/relations/update_note.rs:106-149) with

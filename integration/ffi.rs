@@ -149,8 +149,6 @@ extern "C" {
     // one MSM split by points over ranks (BASELINE config 3): per-window partials, all-gathered by the caller, combined anywhere
     pub fn zkmi_msm_g1_windows_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g1, plan_n: u64,
                                    out_windows_affine: *mut u8, out_nwin: *mut u32, out_window_bits: *mut u32) -> i32;
-    pub fn zkmi_selftest_msm_g1_sum2_dev(ctx: *mut zkmi_ctx, d_scalars_a: *const core::ffi::c_void, d_scalars_b: *const core::ffi::c_void, n: u64,
-                                         bases: *const zkmi_bases_g1, out_affine: *mut u8) -> i32;
     pub fn zkmi_msm_g1_combine(windows_affine: *const u8, n_ranks: u32, nwin: u32, window_bits: u32, out_affine: *mut u8) -> i32;
     // the same exchange over RCCL, one process per GPU (rank 0 draws the id, the host distributes its 128 bytes)
     pub fn zkmi_msm_g1_window_range_dev(ctx: *mut zkmi_ctx, d_scalars: *const core::ffi::c_void, n: u64, bases: *const zkmi_bases_g1, plan_n: u64,

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "../include/zkmi.h"
+#include "../include/zkmi_testing.h"
 
 extern "C" {
 int oracle_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset, int threads);

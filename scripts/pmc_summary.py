@@ -30,12 +30,20 @@ def main():
             # one row per (dispatch, counter); a counter may appear once per dimension instance: sum those
             per_dispatch = collections.defaultdict(float)
             names = {}
+            span = {}
             for r in csv.DictReader(open(path)):
                 key = (r["Dispatch_Id"], r["Counter_Name"])
                 per_dispatch[key] += float(r["Counter_Value"])
                 names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+                if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    span[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             for (disp, counter), v in per_dispatch.items():
                 agg[names[disp]][counter].append(v)
+                # the clock the chip held under this dispatch (counter passes serialise the kernels: every dispatch ran alone):
+                # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles (MI355X_MICROARCH.md, DVFS give-back)
+                if counter == "GRBM_GUI_ACTIVE" and span.get(disp, 0) > 0:
+                    agg[names[disp]]["alone_ns"].append(span[disp])
+                    agg[names[disp]]["held_clock_ghz"].append(v / 8.0 / span[disp])
     rows = []
     for kernel, counters in agg.items():
         row = {"kernel": kernel}

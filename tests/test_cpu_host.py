@@ -14,11 +14,29 @@ H = bytes.fromhex
 
 
 def test_library_exports_every_declared_symbol(zk):
+    """The product library exports exactly the product ABI: everything include/zkmi.h declares, and NONE of the test
+    scaffolding of include/zkmi_testing.h (synthetic bases, the chain stand-in relation, host self-tests: round 4 exported
+    those from libzkmi.so); the A/B + testing library libzkmi_exp.so exports both."""
+    import subprocess
+
     hdr = open(os.path.join(ROOT, "include", "zkmi.h")).read()
     names = set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) > 50
     for n in sorted(names):
         assert hasattr(zk.lib, n), f"{n} declared in include/zkmi.h but not exported"
+    thdr = open(os.path.join(ROOT, "include", "zkmi_testing.h")).read()
+    tnames = set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", thdr))
+    assert len(tnames) >= 12 and not (tnames & names)
+    assert zk.tlib is not zk.lib
+    for n in sorted(tnames):
+        assert not hasattr(zk.lib, n), f"{n} is test scaffolding but the product library exports it"
+        assert hasattr(zk.tlib, n), f"{n} declared in include/zkmi_testing.h but not exported by the testing library"
+    for n in sorted(names):
+        assert hasattr(zk.tlib, n), f"{n}: the A/B + testing library must carry the whole product ABI too"
+    # nothing exported that no header declares
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "zk-apps_amd", "libzkmi.so")], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (zkmi_[a-z0-9_]+)$", out, re.M))
+    assert exported == names, (sorted(exported - names), sorted(names - exported))
 
 
 def test_reference_side_bindings_name_only_exported_functions(zk):
@@ -260,7 +278,7 @@ def test_assembly_scalar_multiplications_selftest(zk):
     import ctypes as C
 
     bad = C.c_uint32(99)
-    assert zk.lib.zkmi_selftest_assembly(C.c_uint64(21), C.c_uint32(12), C.byref(bad)) == 0
+    assert zk.tlib.zkmi_selftest_assembly(C.c_uint64(21), C.c_uint32(12), C.byref(bad)) == 0
     assert bad.value == 0
 
 
@@ -272,7 +290,7 @@ def test_host_pool_and_cpu_budget(zk):
     import sys
 
     bad = C.c_uint32(99)
-    assert zk.lib.zkmi_selftest_host_pool(C.c_uint32(6), C.c_uint32(300), C.byref(bad)) == 0
+    assert zk.tlib.zkmi_selftest_host_pool(C.c_uint32(6), C.c_uint32(300), C.byref(bad)) == 0
     assert bad.value == 0
     info = zk.host_info()
     assert 1 <= info["threads"] <= min(16, info["cpus_granted"]) and info["pool_workers"] <= 16
@@ -489,7 +507,7 @@ def test_device_limb_representation_selftest(zk):
     import ctypes as C
 
     bad = C.c_uint32(1)
-    assert zk.lib.zkmi_selftest_fq28(C.c_uint64(7), C.c_uint32(5000), C.byref(bad)) == 0
+    assert zk.tlib.zkmi_selftest_fq28(C.c_uint64(7), C.c_uint32(5000), C.byref(bad)) == 0
     assert bad.value == 0
 
 
@@ -799,7 +817,7 @@ def test_poseidon_sparse_form_equals_definition(zk):
 
     for field in (0, 1):
         bad = C.c_uint32(1)
-        assert zk.lib.zkmi_selftest_poseidon(C.c_int32(field), C.c_uint64(11 + field), C.c_uint32(40), C.byref(bad)) == 0
+        assert zk.tlib.zkmi_selftest_poseidon(C.c_int32(field), C.c_uint64(11 + field), C.c_uint32(40), C.byref(bad)) == 0
         assert bad.value == 0
 
 

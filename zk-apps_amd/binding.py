@@ -160,6 +160,23 @@ class Zkmi:
         self.lib.zkmi_version.restype = C.c_char_p
         self.lib.zkmi_last_error.restype = C.c_char_p
         self.lib.zkmi_last_error.argtypes = [C.c_void_p]
+        self._tlib = None
+
+    @property
+    def tlib(self):
+        """The TESTING library (include/zkmi_testing.h: synthetic bases, the chain stand-in relation, host self-tests) --
+        test scaffolding the product library does not export.  It is the A/B + testing build libzkmi_exp.so; the objects it
+        creates are the product's own types, and a context made by the product library is the same struct there (one
+        source tree), so tests manufacture inputs here and hand them to libzkmi.so."""
+        if self._tlib is None:
+            if hasattr(self.lib, "zkmi_selftest_fq28"):
+                self._tlib = self.lib  # ZKMI_LIB selected the A/B + testing library itself
+            else:
+                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzkmi_exp.so")
+                if not os.path.exists(path):
+                    raise ZkmiError(-4, f"{path} (testing library) not built; run __graft_entry__.build()")
+                self._tlib = C.CDLL(path)
+        return self._tlib
 
     def hip_versions(self):
         """(HIP_VERSION of the build, version of the HIP runtime this process bound the library to)."""
@@ -318,12 +335,12 @@ class Zkmi:
     # ---- R1CS ---------------------------------------------------------------
     def shielder_r1cs(self, log_n):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_shielder_r1cs(C.c_uint32(log_n), C.byref(h)))
+        self._chk(self.tlib.zkmi_shielder_r1cs(C.c_uint32(log_n), C.byref(h)))
         return R1cs(self, h)
 
     def shielder_witness(self, log_n, seed):
         out = (C.c_uint8 * (32 << log_n))()
-        self._chk(self.lib.zkmi_shielder_witness(C.c_uint32(log_n), C.c_uint64(seed), out))
+        self._chk(self.tlib.zkmi_shielder_witness(C.c_uint32(log_n), C.c_uint64(seed), out))
         return bytes(out)
 
     # ---- Poseidon-5 ---------------------------------------
@@ -457,7 +474,7 @@ class Zkmi:
 
     def shielder_witness_from_input(self, log_n, inp):
         out = (C.c_uint8 * (32 << log_n))()
-        self._chk(self.lib.zkmi_shielder_witness_from_input(C.c_uint32(log_n), C.byref(inp), out))
+        self._chk(self.tlib.zkmi_shielder_witness_from_input(C.c_uint32(log_n), C.byref(inp), out))
         return bytes(out)
 
     def r1cs_create(self, n_vars, n_pub, mats):
@@ -647,17 +664,17 @@ class Context:
 
     def bases_g1_synthetic_range(self, first, n):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_bases_g1_synthetic_range(self.h, C.c_uint64(first), C.c_uint64(n), C.byref(h)))
+        self._chk(self.z.tlib.zkmi_bases_g1_synthetic_range(self.h, C.c_uint64(first), C.c_uint64(n), C.byref(h)))
         return Bases(self, h, 1, n)
 
     def bases_g1_synthetic(self, n):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_bases_g1_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        self._chk(self.z.tlib.zkmi_bases_g1_synthetic(self.h, C.c_uint64(n), C.byref(h)))
         return Bases(self, h, 1, n)
 
     def bases_g2_synthetic(self, n):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_bases_g2_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        self._chk(self.z.tlib.zkmi_bases_g2_synthetic(self.h, C.c_uint64(n), C.byref(h)))
         return Bases(self, h, 2, n)
 
     # MSM
@@ -700,7 +717,7 @@ class Context:
 
     def bn254_bases_synthetic(self, n):
         h = C.c_void_p()
-        self._chk(self.lib.zkmi_bn254_bases_synthetic(self.h, C.c_uint64(n), C.byref(h)))
+        self._chk(self.z.tlib.zkmi_bn254_bases_synthetic(self.h, C.c_uint64(n), C.byref(h)))
         return BnBases(self, h, n)
 
     def bn254_msm_g1(self, scalars, bases):
@@ -800,7 +817,7 @@ class Context:
     def selftest_msm_g1_sum2_dev(self, dptr_a, dptr_b, n, bases):
         """MSM(a) + MSM(b) over the same bases through ONE shared bucket set (test hook of the L + H merge)."""
         out = (C.c_uint8 * 96)()
-        self._chk(self.lib.zkmi_selftest_msm_g1_sum2_dev(self.h, C.c_void_p(dptr_a), C.c_void_p(dptr_b), C.c_uint64(n), bases.h, out))
+        self._chk(self.z.tlib.zkmi_selftest_msm_g1_sum2_dev(self.h, C.c_void_p(dptr_a), C.c_void_p(dptr_b), C.c_uint64(n), bases.h, out))
         return bytes(out)
 
     def msm_g1_window_range_dev(self, dptr, n, bases, plan_n, w_first, w_count):

@@ -71,6 +71,7 @@ void bn_to_wire(const Affine<BnFq28>& p, uint8_t* b) {
   memcpy(b + 32, y, 32);  // infinity = (0, 0) -> all zero
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only
 // P_i = [1 + i * 0xC0FFEE] G, G = (1, 2): distinct points manufactured in HBM for tests / timing
 __global__ void __launch_bounds__(64) k_bn_synth(Affine<BnFq28>* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(64) k_bn_synth(Affine<BnFq28>* __restrict__ ou
 #pragma unroll
   for (unsigned q = 0; q < sizeof(a) / 16; q++) d[q] = sgm[q];
 }
+#endif  // ZKMI_TESTING
 
 // ---- KZG opening: eval_polynomial + kate_division as ONE suffix scan ----------------------------------------------
 // With y = zeta, the synthetic division by (X - y) is q_i = sum_{j > i} p_j y^(j-i-1), and p(y) = sum_j p_j y^j: both are
@@ -392,6 +394,7 @@ int32_t zkmi_bn254_bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, 
   return ZKMI_OK;
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_bn254_bases_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bn_bases** out) {
   ZK_ENTER(ctx);
   if (!out || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
@@ -413,6 +416,7 @@ int32_t zkmi_bn254_bases_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bn_bases** ou
   *out = b;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 int32_t zkmi_bn254_bases_read(zkmi_ctx* ctx, const zkmi_bn_bases* b, uint64_t first, uint64_t count, uint8_t* out) {
   ZK_ENTER(ctx);

@@ -14,8 +14,10 @@
 using namespace zkmi;
 
 namespace zkmi {
+#ifdef ZKMI_TESTING
 hipError_t synthetic_bases_g1(G1Affine* d_out, uint64_t n, hipStream_t st, uint64_t first = 0);
 hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t st, uint64_t first = 0);
+#endif
 }
 
 template <class B>
@@ -344,9 +346,12 @@ int32_t zkmi_bases_g2_prepare(zkmi_ctx* ctx, zkmi_bases_g2* b) {
   return bases_prepare<Fq2_28>(ctx, b);
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_bases_g1_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g1** out) {
   return zkmi_bases_g1_synthetic_range(ctx, 0, n, out);
 }
+#endif  // ZKMI_TESTING
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n, zkmi_bases_g1** out) {
   ZK_ENTER(ctx);
   if (!ctx || !out || n == 0 || n >= (1ull << 31) || first >= (1ull << 40)) return ZKMI_ERR_BAD_ARG;
@@ -365,6 +370,8 @@ int32_t zkmi_bases_g1_synthetic_range(zkmi_ctx* ctx, uint64_t first, uint64_t n,
   *out = b;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) {
   ZK_ENTER(ctx);
   if (!ctx || !out || n == 0 || n >= (1ull << 31)) return ZKMI_ERR_BAD_ARG;
@@ -383,6 +390,7 @@ int32_t zkmi_bases_g2_synthetic(zkmi_ctx* ctx, uint64_t n, zkmi_bases_g2** out) 
   *out = b;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 int32_t zkmi_bases_g1_read(zkmi_ctx* ctx, const zkmi_bases_g1* b, uint64_t first, uint64_t count, uint8_t* out) {
   ZK_ENTER(ctx);
@@ -467,6 +475,7 @@ int32_t zkmi_msm_g2(zkmi_ctx* ctx, const uint8_t* scalars, uint64_t n, const zkm
   return zkmi_msm_g2_dev(ctx, ctx->d_tmp, n, bases, out_affine);
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, const void* d_scalars_b, uint64_t n,
                                       const zkmi_bases_g1* bases, uint8_t out_affine[96]) {
   ZK_ENTER(ctx);
@@ -498,6 +507,7 @@ int32_t zkmi_selftest_msm_g1_sum2_dev(zkmi_ctx* ctx, const void* d_scalars_a, co
   g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 int32_t zkmi_msm_g1_windows_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
                                 uint64_t plan_n, uint8_t* out_windows_affine, uint32_t* out_nwin,

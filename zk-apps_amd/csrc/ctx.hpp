@@ -6,6 +6,9 @@
 #include <string>
 #include <vector>
 #include "../../include/zkmi.h"
+#ifdef ZKMI_TESTING
+#include "../../include/zkmi_testing.h"  // test scaffolding: the A/B + testing library only
+#endif
 #include "curve.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"

@@ -1278,6 +1278,7 @@ static int32_t prove_impl(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, co
   return rc;
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 // Host self-test of the scalar multiplications of proof assembly (curve.hpp FixedBase4, scalar_mul2) against the plain
 // double-and-add, in G1 and G2, on seeded scalars including 0, 1 and r - 1.  No GPU involved.
 int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
@@ -1371,6 +1372,7 @@ int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mism
   *out_mismatches = bad;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 int32_t zkmi_groth16_prove(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* z, const uint8_t r_bytes[32],
                            const uint8_t s_bytes[32], uint8_t out_proof[192]) {

@@ -192,7 +192,7 @@ struct MsmEngine {
   hipError_t finish_host(XYZZ<HF>* out, int slot = 0);
   // per-window sums only (multi-GPU split: SURVEY.md §8e), nwin XYZZ points
   hipError_t finish_host_windows(XYZZ<HF>* out_windows, int slot = 0);
-  static void windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows);
+  static void windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows, bool parallel = false);
   static int partials_per_msm(const MsmPlan& pl);  // XYZZ<HF> points a reduction writes per MSM (device `partial`, slot-major)
   // batched shared sort (MsmSort::run_shared_batch): one result per scalar vector
   hipError_t finish_host_batch(XYZZ<HF>* out, int slot = 0);

@@ -30,6 +30,7 @@
 //   host: window_w = P[w][0] + SEG * sum_j 2^j P[w][1+j];  result = sum_w 2^(c w) window_w
 #pragma once
 #include <stdlib.h>
+#include <functional>
 #include <type_traits>
 #include <vector>
 #include "curve.hpp"
@@ -1842,7 +1843,8 @@ template <class F>
 hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
   hipError_t e = wait_event(done[slot], host_spin);  // (host_pool.hpp: the batch prover's driving thread polls, then sleeps)
   if (e != hipSuccess) return e;
-  windows_from_partials(slot_plan[slot], h_partial + (size_t)slot * SLOT_PTS, out_windows);
+  // (host_spin = one MSM or one proof by itself: the latency path)
+  windows_from_partials(slot_plan[slot], h_partial + (size_t)slot * SLOT_PTS, out_windows, host_spin);
   return hipSuccess;
 }
 
@@ -1851,14 +1853,14 @@ hipError_t MsmEngine<F>::finish_host_windows(XYZZ<HF>* out_windows, int slot) {
 template <class F>
 int MsmEngine<F>::partials_per_msm(const MsmPlan& pl) { return pl.nwin * (1 + msm_seg_bits(pl) + (pl.shared ? 1 : 0)); }
 template <class F>
-void MsmEngine<F>::windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows) {
+void MsmEngine<F>::windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, XYZZ<HF>* out_windows, bool parallel) {
   const int seg_bits = msm_seg_bits(pl);
   const int njobs = 1 + seg_bits + (pl.shared ? 1 : 0);
-  for (int w = 0; w < pl.nwin; w++) {
+  const std::function<void(uint32_t)> one = [&](uint32_t w) {
     XYZZ<HF> u = XYZZ<HF>::infinity();
     // (top window of a partitioned big-window plan: the top bits of the segment index number the partition its entries
     // were spread to, not the digit -- MsmPlan::top_spread_log)
-    const int bits = (pl.win_first + w == pl.total_windows() - 1 && pl.top_spread_log > 0) ? seg_bits - pl.top_spread_log : seg_bits;
+    const int bits = (pl.win_first + (int)w == pl.total_windows() - 1 && pl.top_spread_log > 0) ? seg_bits - pl.top_spread_log : seg_bits;
     for (int j = bits - 1; j >= 0; j--) {
       u.dbl_inplace();
       u.add(h[(size_t)w * njobs + 1 + j]);
@@ -1866,6 +1868,13 @@ void MsmEngine<F>::windows_from_partials(const MsmPlan& pl, const XYZZ<HF>* h, X
     for (int i = 0; i < pl.seg_log; i++) u.dbl_inplace();
     u.add(h[(size_t)w * njobs]);
     out_windows[w] = u;
+  };
+  // One MSM by itself: its 13-16 windows (or partitions) are ~30 group operations each -- 0.3 ms on one thread between the
+  // last kernel and the result, a seventh of a witness-like 2^20-term MSM; on the process's pool they run side by side.
+  if (parallel && pl.nwin >= 8) {
+    HostPool::instance().run((uint32_t)pl.nwin, host_cpu_budget(), one);
+  } else {
+    for (int w = 0; w < pl.nwin; w++) one((uint32_t)w);
   }
 }
 

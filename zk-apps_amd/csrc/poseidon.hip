@@ -321,6 +321,7 @@ int32_t zkmi_poseidon_spec(int32_t field, uint8_t* out_rc, uint8_t* out_mds) {
   return ZKMI_OK;
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 // host self-test: sparse form == plain form of the permutation on random states
 int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
   if (!field_ok(field) || !out_mismatches) return ZKMI_ERR_BAD_ARG;
@@ -363,6 +364,7 @@ int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uin
   *out_mismatches = bad;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 int32_t zkmi_poseidon_hash_batch_dev(zkmi_ctx* ctx, int32_t field, const void* d_in, uint64_t n_hashes, uint32_t arity,
                                      void* d_out) {

@@ -85,6 +85,7 @@ void r1cs_finish_shape(zkmi_r1cs* r) {
   r->log_n = lg;
 }
 
+#ifdef ZKMI_TESTING  // the hash-free chain stand-in of the first builds: golden fixtures only (libzkmi_exp.so)
 zkmi_r1cs* build_shielder_r1cs(uint32_t log_n) {
   if (log_n < 7 || log_n > 26) return nullptr;
   const uint32_t N = 1u << log_n;
@@ -201,6 +202,7 @@ bool build_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_in
   fill_chain(N, z);
   return true;
 }
+#endif  // ZKMI_TESTING
 
 static Fr eval_row(const zkmi_r1cs::Csr& m, uint32_t i, const std::vector<Fr>& z) {
   Fr acc = Fr::zero();
@@ -275,12 +277,15 @@ int32_t zkmi_r1cs_free(zkmi_r1cs* r) {
   return ZKMI_OK;
 }
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_shielder_r1cs(uint32_t log_n, zkmi_r1cs** out) {
   if (!out) return ZKMI_ERR_BAD_ARG;
   *out = build_shielder_r1cs(log_n);
   return *out ? ZKMI_OK : ZKMI_ERR_BAD_ARG;
 }
+#endif  // ZKMI_TESTING
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z) {
   if (!out_z || log_n < 7 || log_n > 26) return ZKMI_ERR_BAD_ARG;
   std::vector<Fr> z;
@@ -288,7 +293,9 @@ int32_t zkmi_shielder_witness(uint32_t log_n, uint64_t seed, uint8_t* out_z) {
   for (size_t i = 0; i < z.size(); i++) fr_to_wire(z[i], out_z + 32 * i);
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 int32_t zkmi_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_input* in, uint8_t* out_z) {
   if (!in || !out_z || log_n < 7 || log_n > 26) return ZKMI_ERR_BAD_ARG;
   std::vector<Fr> z;
@@ -296,6 +303,7 @@ int32_t zkmi_shielder_witness_from_input(uint32_t log_n, const zkmi_update_note_
   for (size_t i = 0; i < z.size(); i++) fr_to_wire(z[i], out_z + 32 * i);
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 // value mod r: SHA-256 outputs used as scalars by the mock exceed r
 int32_t zkmi_fr_reduce(const uint8_t in[32], uint8_t out[32]) {

@@ -30,6 +30,7 @@ struct Rng {
 };
 }  // namespace
 
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatches) {
   if (!out_mismatches) return ZKMI_ERR_BAD_ARG;
   Rng rng{seed};
@@ -117,6 +118,7 @@ extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* o
   *out_mismatches = bad;
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING
 
 // Host self-test of the assembly pool (host_pool.hpp): `callers` threads submit `jobs` jobs each, of 1 .. 64 items and
 // widths 1 .. 17, concurrently; every item must run exactly once and every run() must return only after its own items.
@@ -124,6 +126,7 @@ extern "C" int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* o
 #include <thread>
 #include <vector>
 #include "host_pool.hpp"
+#ifdef ZKMI_TESTING  // test scaffolding: libzkmi_exp.so only (include/zkmi_testing.h)
 extern "C" int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint32_t* out_mismatches) {
   if (!out_mismatches || callers == 0 || callers > 32) return ZKMI_ERR_BAD_ARG;
   std::atomic<uint32_t> bad{0};
@@ -153,3 +156,4 @@ extern "C" int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint
   *out_mismatches = bad.load();
   return ZKMI_OK;
 }
+#endif  // ZKMI_TESTING

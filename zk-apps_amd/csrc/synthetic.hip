@@ -5,6 +5,8 @@
 // double-and-add, then P_{t*B+j} = A_t + (j Q) in affine coordinates with one
 // shared inversion per run (Montgomery's trick).  Not on the proving path:
 // it only manufactures bench / property-test inputs without PCIe traffic.
+// Test scaffolding: compiled into libzkmi_exp.so only (-DZKMI_TESTING); the product library carries none of it.
+#ifdef ZKMI_TESTING
 #define ZK_CALL_MUL 1
 #include <vector>
 #include "curve.hpp"
@@ -115,3 +117,5 @@ hipError_t synthetic_bases_g2(G2Affine* d_out, uint64_t n, hipStream_t stt, uint
 }
 
 }  // namespace zkmi
+
+#endif  // ZKMI_TESTING
