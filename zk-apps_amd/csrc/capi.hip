@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include "ctx.hpp"
 #include "host_pool.hpp"
+#include "msm_pipe.hpp"
 #include "msm_impl.hpp"  // msm_combine_windows (host)
 
 using namespace zkmi;
@@ -419,6 +420,17 @@ int32_t zkmi_msm_g1_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const 
   const bool shared = bases->tab != nullptr && n == bases->n && n > 0;  // prepared bases, full length
   ZK_HIP(ctx, ctx->sort.reserve(n, shared));
   ZK_HIP(ctx, ctx->g1.reserve(n, shared));
+  const MsmPlan wpl = msm_make_plan(n);
+  if (!shared && msm_pipe_applies(wpl, n)) {
+    // a big windowed MSM: the sort of the lower windows runs beside the accumulation of the upper ones (msm_pipe.hpp)
+    ZK_HIP(ctx, ctx->sort_h.reserve(n));
+    ZK_HIP(ctx, msm_pipe_enqueue(ctx, static_cast<const uint32_t*>(d_scalars), n, bases->d28, wpl));
+    std::vector<G1XYZZ> win((size_t)wpl.nwin);
+    ZK_HIP(ctx, msm_pipe_finish_windows(ctx, wpl, win.data()));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g1_to_wire(msm_combine_windows<Fq>(win.data(), wpl.nwin, wpl.c).to_affine(), out_affine);
+    return ZKMI_OK;
+  }
   if (shared)
     ZK_HIP(ctx, ctx->sort.run_shared(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer()));
   else

@@ -17,6 +17,7 @@
 #include <new>
 #include <vector>
 #include "ctx.hpp"
+#include "msm_pipe.hpp"
 
 namespace {
 
@@ -230,17 +231,37 @@ int32_t zkmi_msm_g1_allgather_combine(zkmi_ctx* ctx, zkmi_comm* comm, const void
   const uint64_t bytes = sizeof(G1XYZZ) * (uint64_t)pts;
   ZK_HIP(ctx, ctx->sort.reserve(plan_n));
   ZK_HIP(ctx, ctx->g1.reserve(plan_n));
+  if (msm_pipe_applies(pl, n)) {
+    ZK_HIP(ctx, ctx->sort_h.reserve(plan_n));
+    ZK_HIP(ctx, ctx->staging(bytes));
+  }
   ZK_HIP(ctx, comm_reserve(comm, bytes * comm->n_ranks));
   std::vector<G1XYZZ> all((size_t)pts * comm->n_ranks);
-  ctx->sort.plan_override = pl.c;
-  const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
-  ctx->sort.plan_override = 0;
-  if (e != hipSuccess) return ctx->hip_fail(e, "sort");
-  ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
-  // the reduction (slot 0, on stream_aux) has left partials_per_msm points in the device array `partial`
-  const MsmPlan& sp = ctx->g1.slot_plan[0];
-  if (MsmEngine<Fq28>::partials_per_msm(sp) != pts) return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sort planned another window set");
-  const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
+  const void* send = ctx->g1.partial;
+  MsmPlan sp = pl;
+  if (msm_pipe_applies(pl, n)) {
+    // two window groups, the second one's sort beside the first one's accumulation (msm_pipe.hpp); their partial sums lie in
+    // slots 1 (windows [0, wb)) and 0 (the rest): brought together, in window order, in the staging buffer the gather sends
+    const hipError_t e = msm_pipe_enqueue(ctx, static_cast<const uint32_t*>(d_scalars), n, bases->d28, pl);
+    if (e != hipSuccess) return ctx->hip_fail(e, "pipelined sort / accumulation");
+    const int per_window = pts / pl.nwin, wb = msm_pipe_split(pl);
+    const size_t bytes_b = sizeof(G1XYZZ) * (size_t)per_window * wb;
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->g1.done[1], 0));  // (slot 0's reduction is on stream_aux itself)
+    uint8_t* stage = static_cast<uint8_t*>(ctx->d_tmp);
+    ZK_HIP(ctx, hipMemcpyAsync(stage, ctx->g1.partial + (size_t)MsmEngine<Fq28>::SLOT_PTS, bytes_b, hipMemcpyDeviceToDevice, ctx->stream_aux));
+    ZK_HIP(ctx, hipMemcpyAsync(stage + bytes_b, ctx->g1.partial, (size_t)bytes - bytes_b, hipMemcpyDeviceToDevice, ctx->stream_aux));
+    send = stage;
+  } else {
+    ctx->sort.plan_override = pl.c;
+    const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+    ctx->sort.plan_override = 0;
+    if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+    ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+    // the reduction (slot 0, on stream_aux) has left partials_per_msm points in the device array `partial`
+    sp = ctx->g1.slot_plan[0];
+    if (MsmEngine<Fq28>::partials_per_msm(sp) != pts) return ctx->fail(ZKMI_ERR_BAD_ARG, "internal: the sort planned another window set");
+  }
+  const int rc = r.all_gather(send, comm->d_gather, (size_t)bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
   if (rc != 0) {
     (void)ctx->drain();
     return rccl_fail(ctx, rc, "ncclAllGather");

@@ -100,6 +100,9 @@ struct MsmSort {
   MsmPlan plan;
   int plan_override = 0;  // force window bits (multi-GPU split: all ranks must agree)
   int win_first = 0, win_count = 0;  // run(): only these windows of the plan (win_count = 0: all); reset by the caller
+  // run_windowed_big: log2 of the buckets per LDS-histogram tile -- 15 (128 KB of counters: a CU to itself) or 14 (64 KB: fits
+  // beside an occupancy-capped accumulation, MSM_RUN_TWO_WAVES); 14 only for window ranges WITHOUT the plan's top window
+  int big_nb_log = 15;
   // events of kernels on OTHER streams that still read count/begin/heavy/sorted (the heavy-bucket
   // kernels of MsmEngine::run_device): the next sort waits for them before it overwrites the buffers
   mutable std::vector<hipEvent_t> readers;
@@ -127,7 +130,8 @@ template <> struct HostFieldOf<Fq28> { using type = Fq; };
 template <> struct HostFieldOf<Fq2_28> { using type = Fq2; };
 template <> struct HostFieldOf<BnFq28> { using type = BnFq; };
 
-enum { MSM_RUN_NO_REDUCE = 1, MSM_RUN_ADD_AT_REDUCE = 2 };  // MsmEngine::run_device flags (msm_impl.hpp run_device_multi)
+// MsmEngine::run_device flags (msm_impl.hpp run_device_multi); MSM_RUN_TWO_WAVES: the G1 accumulation capped at two waves per SIMD
+enum { MSM_RUN_NO_REDUCE = 1, MSM_RUN_ADD_AT_REDUCE = 2, MSM_RUN_TWO_WAVES = 4 };
 
 template <class F>
 struct MsmEngine {

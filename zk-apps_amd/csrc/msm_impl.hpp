@@ -377,6 +377,100 @@ k_accum_g1_nc(const AccumArgs<F, MULTI> args, uint32_t total_buckets) {
   }
   store_vec(buckets + b, acc);
 }
+#ifdef ZKMI_EXPERIMENTS
+// The same loop once more, as a function, for the occupancy-capped kernel below.  (NOT shared with k_accum_g1_nc: routed
+// through a function the three-wave kernel spills 92 bytes per lane -- its zero spills at exactly 168 registers are a draw
+// of the register allocator that any change of the surrounding code loses: DESIGN.md section 10.)
+template <class F, int BW, bool MULTI, bool INTO>
+__device__ __forceinline__ void accum_g1_nc_body(const AccumArgs<F, MULTI>& args, uint32_t total_buckets) {
+  const Affine<F>* __restrict__ const bases = args.bases();
+  XYZZ<F>* __restrict__ const buckets = args.buckets();
+  uint32_t* __restrict__ const redo = args.redo();
+  const uint32_t* __restrict__ const begin = args.sort().begin;
+  const uint32_t* __restrict__ const count = args.sort().count;
+  const uint32_t* __restrict__ const perm = args.sort().perm;
+  const uint32_t* __restrict__ const sorted = args.sort().sorted;
+  const uint32_t heavy_thr = args.sort().heavy_thr;
+  constexpr int CHUNKS = sizeof(Affine<F>) / 16;  // 7 (BLS12-381 Fq), 5 (BN254 Fq)
+  __shared__ uint4 tile[BW][CHUNKS][64];          // [wave][chunk][lane]
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (t >= total_buckets) return;
+  const uint32_t b = perm[t];  // lanes of a wave own buckets of near-equal load
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;  // k_accum_heavy owns it
+  const uint32_t beg = begin[b], end = beg + cnt;
+  auto fetch = [&](uint32_t v) {
+    const char* src = reinterpret_cast<const char*>(bases + (v & 0x7fffffffu));
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * q), (lds_ptr_t)&tile[wave][q][0], 16, 0, 0);
+  };
+  auto take = [&](Affine<F>& p) {  // LDS -> registers; the compiler waits for the outstanding LDS-DMA first
+    uint4* d = reinterpret_cast<uint4*>(&p);
+#pragma unroll
+    for (int q = 0; q < CHUNKS; q++) d[q] = tile[wave][q][lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have left the LDS: the buffer may be refilled
+  };
+  XYZZ<F> acc;
+  uint32_t j = beg;
+  // first entry that is not the point at infinity starts the accumulator (plain loads: runs once per bucket)
+  for (;; j++) {
+    if (j >= end) {
+      if constexpr (!INTO) store_vec(buckets + b, XYZZ<F>::infinity());  // (INTO: nothing to add, the bucket keeps its sum)
+      return;
+    }
+    const uint32_t v = sorted[j];
+    Affine<F> p = load_vec(bases + (v & 0x7fffffffu));
+    if (affine_is_zero_words(p)) continue;
+    if constexpr (INTO) {
+      acc = load_vec(buckets + b);  // entry j itself is added by the loop below
+      break;
+    }
+    if (v >> 31) p.y = p.y.neg();
+    acc.x = p.x;
+    acc.y = p.y;
+    acc.zz = F::one();
+    acc.zzz = F::one();
+    j++;
+    break;
+  }
+  uint32_t v_cur = 0, v_next = 0;
+  if (j < end) {
+    v_cur = sorted[j];
+    fetch(v_cur);
+    if (j + 1 < end) v_next = sorted[j + 1];
+  }
+  for (; j < end; j++) {
+    Affine<F> p;
+    take(p);
+    const uint32_t v = v_cur;
+    if (j + 1 < end) {
+      fetch(v_next);
+      v_cur = v_next;
+      if (j + 2 < end) v_next = sorted[j + 2];
+    }
+    if (affine_is_zero_words(p)) continue;
+    if (!madd_generic(acc, p, 0u - (v >> 31))) {
+      // doubling or cancellation: k_accum_redo recomputes the bucket (INTO: from the value it still holds -- nothing
+      // has been written)
+      redo[1 + atomicAdd(redo, 1u)] = b;
+      return;
+    }
+  }
+  store_vec(buckets + b, acc);
+}
+// The same loop CAPPED at two waves per SIMD with at most 176 registers (352 of a SIMD's 512: the kernel descriptor is
+// padded to the occupancy limit): it leaves 160 registers per SIMD, ~100 KB of LDS per CU and six wave slots per SIMD to
+// OTHER kernels.  The three-wave kernel above fills 504 registers and nothing runs beside it; the
+// issue rate of the additions is the same at two and at three waves (round 2).  Used by the pipelined form of one big
+// windowed MSM (BASELINE config 3): the digit sort of the second window group runs beside the first group's accumulation.
+template <class F>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(176)))
+k_accum_g1_nc_w2(const AccumArgs<F, false> args, uint32_t total_buckets) {
+  accum_g1_nc_body<F, 1, false, false>(args, total_buckets);
+}
+#endif  // ZKMI_EXPERIMENTS
 // acc += o for acc, o != O; false when the sum needs the complete group law (o = +-acc): same contract as madd_generic
 template <class F>
 __device__ __forceinline__ bool add_generic(XYZZ<F>& a, const XYZZ<F>& o) {
@@ -1719,6 +1813,14 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       }
 #endif
       (void)sort;
+#ifdef ZKMI_EXPERIMENTS
+      // (A/B library: the occupancy-capped kernel of the pipelined big MSM -- msm_pipe.hpp, measured neutral -- or, with
+      // ZKMI_ACCUM_W2=1, for every lone G1 accumulation: 12 % slower than three waves)
+      if ((flags & MSM_RUN_TWO_WAVES) || ZK_TUNE("ZKMI_ACCUM_W2", 0) == 1) {
+        hipLaunchKernelGGL(k_accum_g1_nc_w2<F>, dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
+        continue;
+      }
+#endif
       hipLaunchKernelGGL((k_accum_g1_nc<F, 3, 1>), dim3((tot_b + 63) / 64), dim3(64), 0, st, one, tot_b);
     }
   }

@@ -1054,9 +1054,12 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
 // sorted[] is packed group by group; bucket ids are window-major (w * 2^(c-1) + |digit| - 1), which is what the
 // reductions of the windowed schedule expect.
 hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipStream_t st, PhaseTimer* prof) {
-  const uint32_t nb = 1u << 15, nwin = (uint32_t)plan.nwin;
-  const int nb_log = 15;
-  const uint32_t P = nwin * big_parts_per_window(plan);
+  // (tiles of 2^14 buckets -- big_nb_log -- only where the top window, whose 15-bit digits are spread over the partitions by
+  // point index, is not among this sort's windows)
+  const bool has_top = plan.win_first + plan.nwin == plan.total_windows();
+  const int nb_log = (big_nb_log == 14 && !has_top) ? 14 : 15;
+  const uint32_t nb = 1u << nb_log, nwin = (uint32_t)plan.nwin;
+  const uint32_t P = nwin * (plan.nb >> nb_log);
   const uint32_t tot_b = nwin * plan.nb;
   const uint32_t nch = shared_chunks(P, n);
   if (P > PART_MAX || (uint64_t)nwin * n > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist || !rec_entry)
@@ -1081,7 +1084,9 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
   if (!nblk) nblk = 1;
   const uint32_t chunk = (uint32_t)((n + nblk - 1) / nblk);
   const int w_top_pos = plan.total_windows() - 1;
-  hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
+  // (the counting pass needs 42 registers per lane: beside an occupancy-capped accumulation -- nb_log 14 -- only two of its waves
+  // fit a SIMD's free registers, so its workgroups are 512 threads there)
+  hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(nb_log == 14 ? 512 : 1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
                      chunk, rc, blkcnt, rec_entry, rec_bkt, plan.win_first, w_top_pos);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
   hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
