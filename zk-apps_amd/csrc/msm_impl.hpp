@@ -1839,10 +1839,8 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   if (tot_b <= (1u << 16) && segs_per_win > per_block) {
     nchunk = segs_per_win / per_block;
     if (nchunk > MSM_TREE_T) nchunk = MSM_TREE_T;
-    {
-      const uint32_t cap = (uint32_t)ZK_TUNE("ZKMI_TREE_CHUNK_MAX", 128);  // A/B library: fewer, longer slices
-      while (nchunk > cap && nchunk > 1) nchunk >>= 1;
-    }
+    // (fewer, longer slices -- at most 16, 8 or 4 -- measured the same group rates and single-proof latencies within noise:
+    // profiles/r05/experiments/tree_slices_ab.txt)
     if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS) nchunk = 1;
   } else if (!pl.shared && tot_b <= (1u << 19) && segs_per_win > per_block) {
     // one windowed MSM of up to 2^19 buckets: as many slices as the stage holds (16 windows x 13 jobs: 16), see plan_set_heavy
