@@ -1,5 +1,6 @@
 """zkmi_msm_g1_dev for n = 2^lo .. 2^hi (uniform scalars, synthetic bases), wall clock and per-phase HIP-event times.
 Usage: python scripts/msm_scaling.py [lo [hi [prepared]]]  (defaults 20 26 0; prepared = 1: zkmi_bases_g1_prepare first)"""
+import os
 import sys
 import time
 
@@ -9,7 +10,7 @@ import torch
 from zkmi_loader import load_pkg
 
 pkg = load_pkg()
-z = pkg.Zkmi()
+z = pkg.Zkmi(os.environ.get("ZKMI_LIB"))
 ctx = z.context(0)
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 26

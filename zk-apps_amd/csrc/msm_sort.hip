@@ -131,13 +131,22 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
 // w * ppw + (bucket >> nb_log) of P = nwin * ppw -- and entries are plain point indices.  Either way every scalar is
 // read ONCE per pass for all its digits (the plain windowed sort reads it once per window and pass).
 constexpr uint32_t PART_MAX = 256;  // record groups of one sort: partitions (shared) / windows x partitions (windowed)
-template <bool WRITE, bool WIN = false>
+constexpr int FINE_LOG = 10;        // buckets per fine partition (the fine-partition sorts below)
+// FINE (counting pass of the big windowed plans): also the records per FINE partition -- 2^fine_log consecutive buckets of a
+// group -- summed over all blocks into fine_tot[group * (nb >> fine_log) + fine] (zeroed by the caller; dynamic LDS: one
+// counter per fine partition)
+template <bool WRITE, bool WIN = false, bool FINE = false>
 __global__ void __launch_bounds__(1024)
 k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P,
             uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry,
-            uint32_t* __restrict__ rec_bkt, int w0 = 0, int w_top_pos = -1) {
+            uint32_t* __restrict__ rec_bkt, int w0 = 0, int w_top_pos = -1, uint32_t* __restrict__ fine_tot = nullptr,
+            int fine_log = FINE_LOG) {
   __shared__ uint32_t cnt[PART_MAX];
+  extern __shared__ uint32_t fine_cnt[];
+  const int fan_log = nb_log - fine_log;
   if (threadIdx.x < PART_MAX) cnt[threadIdx.x] = (WRITE && threadIdx.x < P) ? blkcnt[blockIdx.x * P + threadIdx.x] : 0u;
+  if (FINE)
+    for (uint32_t f = threadIdx.x; f < (P << fan_log); f += blockDim.x) fine_cnt[f] = 0u;
   __syncthreads();
   const uint32_t ppw = WIN ? ((1u << (c - 1)) >> nb_log) : 0u;
   // the top window's digits are < 2^nb_log: its entries go to partition (point mod ppw) instead of partition 0 (MsmPlan::top_spread_log)
@@ -155,6 +164,7 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
       const uint32_t bkt = d - 1;
       const uint32_t q = WIN ? (uint32_t)w * ppw + (w == w_top ? (i & (ppw - 1u)) : (bkt >> nb_log)) : bkt >> nb_log;
       const uint32_t pos = atomicAdd(&cnt[q], 1u);
+      if (FINE) atomicAdd(&fine_cnt[(q << fan_log) + ((bkt & (nb - 1u)) >> fine_log)], 1u);
       if (WRITE) {
         rec_entry[pos] = (WIN ? i : (uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
         rec_bkt[pos] = bkt & (nb - 1u);
@@ -164,6 +174,11 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
   if (!WRITE) {
     __syncthreads();
     if (threadIdx.x < P) blkcnt[blockIdx.x * P + threadIdx.x] = cnt[threadIdx.x];
+    if (FINE)
+      for (uint32_t f = threadIdx.x; f < (P << fan_log); f += blockDim.x) {
+        const uint32_t v = fine_cnt[f];
+        if (v) atomicAdd(&fine_tot[f], v);
+      }
   }
 }
 
@@ -229,9 +244,9 @@ k_bucket_pass_rec(const uint32_t* __restrict__ rec_entry, const uint32_t* __rest
 // scatter into its own contiguous slice of sorted[] (106 KB, staged in LDS: the runs of a bucket are completed by one workgroup
 // within microseconds, so the lines are written once).  No per-tile histograms in HBM, no separate totals / scan /
 // bases kernels for this mode.
-constexpr int FINE_LOG = 10;                 // buckets per fine partition
-constexpr uint32_t FINE_NB = 1u << FINE_LOG;
+constexpr uint32_t FINE_NB = 1u << FINE_LOG;  // (FINE_LOG = 10: above, with the record pre-pass)
 constexpr uint32_t FINE_MAX_PARTS = 2048;    // 2^22 buckets (c = 23)
+constexpr uint32_t FINE_BIG_PARTS = 32768;   // big windowed plans (run_windowed_big): 13 windows x 2^19 buckets in fine partitions of 2^8 = 26 624
 constexpr uint32_t FPART_BLOCKS = 512;       // blocks of the record pre-pass
 
 // records grouped by fine partition: WRITE = false counts per (block, partition), WRITE = true writes
@@ -422,7 +437,7 @@ k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restric
     fpart[q] = run;
     run += fpart[NP + q];
   }
-  if (tid < P) part_total[tid] = tid == 0 ? part[1023] : 0u;
+  if (part_total && tid < P) part_total[tid] = tid == 0 ? part[1023] : 0u;
 }
 
 // one workgroup per fine partition: histogram -> scan -> count / begin -> scatter (see above).
@@ -432,7 +447,7 @@ k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restric
 // partitions that also receive the partial top digit hold ~3.6x the mean; witness-like scalars can put 20 % of all
 // entries into one bucket) is flushed in rounds of FINE_ROUND positions: bucket b belongs to the round its first
 // position falls into, a run that overshoots the stage's slack is written directly.
-constexpr uint32_t FINE_STAGE = 36000;   // entries the LDS stage holds (144 000 B)
+constexpr uint32_t FINE_STAGE = 36864;   // entries the LDS stage holds (147 456 B)
 constexpr uint32_t FINE_ROUND = 32768;   // positions per round; FINE_STAGE - FINE_ROUND = slack for a straddling run
 // LDS counter updates of one wave, aggregated when all its active lanes name the SAME counter: a witness of bits sends
 // 630 000 records to one bucket, i.e. 64-way same-address ds_add conflicts on every wave-instruction of both passes (with
@@ -452,10 +467,19 @@ __device__ __forceinline__ uint32_t wave_counter_add(uint32_t* ctr, uint32_t idx
   return valid ? atomicAdd(&ctr[idx], 1u) : 0u;
 }
 
+constexpr uint32_t FSORT_U = 4;     // records in flight per thread in the round form of k_fpart_sort
+constexpr uint32_t FSORT_RPT = 36;  // records per thread of its register form: partitions of up to 36 864 records (= FINE_STAGE)
+// fine_log: log2 of the buckets per fine partition (<= FINE_LOG: one counter per thread); bucket ids are q << fine_log | local.
+// A partition of at most FSORT_RPT x 1024 records takes the REGISTER form: every thread loads its records once, all loads in
+// flight together (72 per thread), and keeps them through histogram, scan and the scatter into the stage -- one pass over HBM
+// where the round form below reads the bucket ids once per pass and round with a handful of loads in flight (16 waves per CU
+// beside a 147 KB stage hide no latency: 58 G records/s at 131 072 records per partition, 75 G at 26 000).
 __global__ void __launch_bounds__(1024)
 k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
-             uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged) {
+             uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged,
+             int fine_log) {
   static_assert(FINE_NB == 1024, "one counter per thread");
+  static_assert(FSORT_RPT * 1024 <= FINE_STAGE, "the register form stages a whole partition");
   __shared__ uint32_t hist[FINE_NB];  // counts, then cursors (positions relative to the partition)
   __shared__ uint32_t beg[FINE_NB];   // first position of the bucket, relative to the partition
   __shared__ uint32_t part[1024];
@@ -463,11 +487,31 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   const uint32_t pbase = fpart[q], ptot = fpart[NP + q];
   const uint32_t ptot_up = (ptot + 1023u) & ~1023u;  // whole waves walk the records: the aggregated counter updates need every lane
+  const bool in_regs = staged && ptot <= FSORT_RPT * 1024;  // workgroup-uniform
+  uint32_t kb[FSORT_RPT], ke[FSORT_RPT];
   hist[tid] = 0;
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t k = 0; k < FSORT_RPT; k++) {
+      const uint32_t r = k * 1024 + tid;
+      kb[k] = r < ptot ? rec_bkt[pbase + r] : 0xffffffffu;
+      ke[k] = r < ptot ? rec_entry[pbase + r] : 0u;
+    }
+  }
   __syncthreads();
-  for (uint32_t r = tid; r < ptot_up; r += 1024) {
-    const bool valid = r < ptot;
-    (void)wave_counter_add(hist, valid ? rec_bkt[pbase + r] : 0u, valid);
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t k = 0; k < FSORT_RPT; k++)
+      if (k * 1024 < ptot_up) (void)wave_counter_add(hist, kb[k] != 0xffffffffu ? kb[k] : 0u, kb[k] != 0xffffffffu);
+  } else {
+    for (uint32_t r0 = tid; r0 < ptot_up; r0 += FSORT_U * 1024) {
+      uint32_t b[FSORT_U];
+#pragma unroll
+      for (uint32_t k = 0; k < FSORT_U; k++) b[k] = (r0 + k * 1024 < ptot) ? rec_bkt[pbase + r0 + k * 1024] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < FSORT_U; k++)
+        if (r0 + k * 1024 < ptot_up) (void)wave_counter_add(hist, b[k], r0 + k * 1024 < ptot);
+    }
   }
   __syncthreads();
   const uint32_t c0 = hist[tid];
@@ -480,12 +524,26 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
     __syncthreads();
   }
   const uint32_t ex = tid ? part[tid - 1] : 0u;
-  const size_t g = (size_t)q * FINE_NB + tid;
-  count[g] = c0;
-  begin[g] = pbase + ex;
+  if (tid < (1u << fine_log)) {
+    const size_t g = ((size_t)q << fine_log) + tid;
+    count[g] = c0;
+    begin[g] = pbase + ex;
+  }
   beg[tid] = ex;
   hist[tid] = ex;  // cursor
   __syncthreads();
+  if (in_regs) {
+#pragma unroll
+    for (uint32_t k = 0; k < FSORT_RPT; k++)
+      if (k * 1024 < ptot_up) {
+        const bool valid = kb[k] != 0xffffffffu;
+        const uint32_t pos = wave_counter_add(hist, valid ? kb[k] : 0u, valid);
+        if (valid) stage[pos] = ke[k];
+      }
+    __syncthreads();
+    for (uint32_t i = tid; i < ptot; i += 1024) sorted[pbase + i] = stage[i];
+    return;
+  }
   if (!staged) {
     for (uint32_t r = tid; r < ptot_up; r += 1024) {
       const bool valid = r < ptot;
@@ -498,15 +556,24 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
   uint32_t start = 0;  // first position this round owns = end of the previous round's last run (>= lo)
   for (uint32_t rd = 0; rd < rounds;) {
     const uint32_t lo = rd * FINE_ROUND;
-    for (uint32_t r = tid; r < ptot_up; r += 1024) {
-      const bool in = r < ptot;
-      const uint32_t b = in ? rec_bkt[pbase + r] : 0u;
-      const bool valid = in && (rounds == 1 || beg[b] / FINE_ROUND == rd);
-      const uint32_t pos = wave_counter_add(hist, b, valid);
-      if (!valid) continue;
-      const uint32_t e = rec_entry[pbase + r];
-      if (pos - lo < FINE_STAGE) stage[pos - lo] = e;
-      else sorted[pbase + pos] = e;  // a run longer than the slack: the rest goes out directly
+    for (uint32_t r0 = tid; r0 < ptot_up; r0 += FSORT_U * 1024) {
+      uint32_t b[FSORT_U], e[FSORT_U];
+      bool valid[FSORT_U];
+#pragma unroll
+      for (uint32_t k = 0; k < FSORT_U; k++) b[k] = (r0 + k * 1024 < ptot) ? rec_bkt[pbase + r0 + k * 1024] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < FSORT_U; k++) {
+        valid[k] = r0 + k * 1024 < ptot && (rounds == 1 || beg[b[k]] / FINE_ROUND == rd);
+        e[k] = valid[k] ? rec_entry[pbase + r0 + k * 1024] : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < FSORT_U; k++) {
+        if (r0 + k * 1024 >= ptot_up) continue;  // (wave-uniform: ptot_up is a multiple of 1024)
+        const uint32_t pos = wave_counter_add(hist, b[k], valid[k]);
+        if (!valid[k]) continue;
+        if (pos - lo < FINE_STAGE) stage[pos - lo] = e[k];
+        else sorted[pbase + pos] = e[k];  // a run longer than the slack: the rest goes out directly
+      }
     }
     __syncthreads();
     // positions [lo, hi) were staged: hi = end of the last bucket of this round, capped by the stage
@@ -532,6 +599,105 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
     rd = next_rd;
     __syncthreads();
   }
+}
+
+// ---- big windowed plans: records of a 2^15-bucket group -> records grouped by FINE partition ------------------------------
+// The (chunk, group) tiles of k_bucket_pass_rec scatter 4-byte entries at random into the group's 16 MB slice of sorted[]: at
+// 2^26 terms 872 M entries cost 26.9 GB of HBM writes for 3.5 GB of payload and 20.5 of the sort's 28.9 ms (round-5 counters,
+// profiles/r05/pmc_summary_msm26_steps1.json).  Instead the group's records are split once more, into its 32 .. 128 fine
+// partitions of 2^10 .. 2^8 buckets (as many as keep a fine partition within one LDS stage: 32 768 records on average at 2^26
+// terms), and k_fpart_sort finishes each fine partition inside one workgroup -- the scheme of the prover's sort, with one more
+// level because a record pre-pass straight into 26 624 fine partitions would write single records.
+// A workgroup takes batches of SPLIT_B records of its group: ranks them per fine partition (wave-aggregated: the lanes of a wave
+// that name the same partition are found with ballots and take their LDS counter once), reserves the batch's room in every
+// fine partition with ONE global atomic each, lays the batch out partition by partition in LDS and writes it out as runs
+// (SPLIT_B / fan = 64 .. 256 records on average).  The order of a fine partition's records depends on which batch reserved first:
+// the bucket sums do not (and every caller's result is canonical bytes).
+constexpr uint32_t SPLIT_B = 8192;  // records per batch: 8 per thread, 64 KB of stage
+constexpr uint32_t SPLIT_MAX_FAN = 128;  // 2^15-bucket groups cut into fine partitions of 2^8 buckets
+__device__ __forceinline__ uint32_t wave_bin_rank(uint32_t* ctr, uint32_t f, bool valid, int fan_log) {
+  uint64_t m = __ballot(valid);
+  for (int bit = 0; bit < fan_log; bit++) {
+    const bool one = ((f >> bit) & 1u) != 0;
+    const uint64_t bl = __ballot(valid && one);
+    m &= one ? bl : ~bl;
+  }
+  if (!valid) m = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int leader = m ? __ffsll((unsigned long long)m) - 1 : (int)lane;
+  uint32_t base = 0;
+  if (valid && (int)lane == leader) base = atomicAdd(&ctr[f], (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__global__ void __launch_bounds__(1024)
+k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a_bkt, const uint32_t* __restrict__ part_total,
+            uint32_t* __restrict__ cursor, uint32_t* __restrict__ b_entry, uint32_t* __restrict__ b_bkt, int fan_log, int fine_log) {
+  extern __shared__ uint32_t split_stage[];  // SPLIT_B entries, then SPLIT_B keys
+  __shared__ uint32_t cnt[SPLIT_MAX_FAN], base[SPLIT_MAX_FAN], gb[SPLIT_MAX_FAN];
+  uint32_t* const s_entry = split_stage;
+  uint32_t* const s_key = split_stage + SPLIT_B;
+  const uint32_t tid = threadIdx.x, q = blockIdx.y, fan = 1u << fan_log;
+  uint32_t pbase = 0;
+  for (uint32_t j = 0; j < q; j++) pbase += part_total[j];
+  const uint32_t ptot = part_total[q];
+  constexpr uint32_t PER = SPLIT_B / 1024;
+  for (uint32_t b0 = blockIdx.x * SPLIT_B; b0 < ptot; b0 += gridDim.x * SPLIT_B) {
+    if (tid < fan) cnt[tid] = 0;
+    __syncthreads();
+    uint32_t key[PER], ent[PER], rk[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t r = b0 + k * 1024 + tid;
+      key[k] = r < ptot ? a_bkt[pbase + r] : 0xffffffffu;
+      ent[k] = r < ptot ? a_entry[pbase + r] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) rk[k] = wave_bin_rank(cnt, key[k] >> fine_log, key[k] != 0xffffffffu, fan_log);
+    __syncthreads();
+    if (tid < 64) {  // one wave (two partitions per lane): exclusive prefix of the batch's counts, and the batch's room in every fine partition
+      const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
+      const uint32_t v0 = f0 < fan ? cnt[f0] : 0u, v1 = f1 < fan ? cnt[f1] : 0u;
+      uint32_t incl = v0 + v1;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)tid >= off) incl += t;
+      }
+      const uint32_t ex = incl - v0 - v1;
+      if (f0 < fan) {
+        base[f0] = ex;
+        gb[f0] = v0 ? atomicAdd(&cursor[(q << fan_log) + f0], v0) : 0u;
+      }
+      if (f1 < fan) {
+        base[f1] = ex + v0;
+        gb[f1] = v1 ? atomicAdd(&cursor[(q << fan_log) + f1], v1) : 0u;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++)
+      if (key[k] != 0xffffffffu) {
+        const uint32_t slot = base[key[k] >> fine_log] + rk[k];
+        s_entry[slot] = ent[k];
+        s_key[slot] = key[k];
+      }
+    __syncthreads();
+    const uint32_t total = ptot - b0 < SPLIT_B ? ptot - b0 : SPLIT_B;
+    for (uint32_t sl = tid; sl < total; sl += 1024) {
+      const uint32_t kk = s_key[sl], f = kk >> fine_log;
+      const uint32_t dst = gb[f] + (sl - base[f]);
+      b_entry[dst] = s_entry[sl];
+      b_bkt[dst] = kk & ((1u << fine_log) - 1u);
+    }
+    __syncthreads();
+  }
+}
+// fpart[2 NP + q] = fpart[q]: the cursors k_rec_split advances
+__global__ void __launch_bounds__(256)
+k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q < NP) fpart[2 * NP + q] = fpart[q];
 }
 
 __global__ void __launch_bounds__(1024)
@@ -884,10 +1050,11 @@ void MsmSort::release() {
   if (fpart) (void)hipFree(fpart);
   if (rec_entry) (void)hipFree(rec_entry);
   if (rec_bkt) (void)hipFree(rec_bkt);
+  if (rec_aux) (void)hipFree(rec_aux);
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
-  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = order_bins = fpart = nullptr;
+  count = begin = blockhist = sorted = perm = heavy = part_total = blkcnt = rec_entry = rec_bkt = rec_aux = order_bins = fpart = nullptr;
   cap_entries = cap_buckets = cap_hist = 0;
   has_shared = false;
 }
@@ -945,10 +1112,14 @@ hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * PART_MAX)) != hipSuccess) return e;
   if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2) * (256 + 1))) != hipSuccess) return e;  // row 0: offsets, rows 1..: per-block key counts
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * FPART_BLOCKS * FINE_MAX_PARTS)) != hipSuccess) return e;  // also 256 x 64 of the coarse form
-  if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 2 * FINE_MAX_PARTS)) != hipSuccess) return e;
+  static_assert(3 * FINE_BIG_PARTS >= 2 * FINE_MAX_PARTS, "fpart serves both fine-partition forms");
+  if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 3 * FINE_BIG_PARTS)) != hipSuccess) return e;  // bases, totals, cursors
   if (shared) {
     if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * ne)) != hipSuccess) return e;
     if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * ne)) != hipSuccess) return e;
+    // second record array of the two-level big windowed sort (its first level borrows sorted[] for the entries); only where
+    // such a plan can occur: from 2^21 entries on (a 2^17-term slice of a split 2^24-term MSM)
+    if (ne >= (1ull << 21) && (e = hipMalloc(&rec_aux, sizeof(uint32_t) * ne)) != hipSuccess) return e;
   }
   has_shared = shared;
   if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
@@ -980,6 +1151,16 @@ hipError_t msm_sort_enable_big_lds() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_write_staged<2048>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(uint32_t) * 2 * 1024 * 13));
+    if (e != hipSuccess) return e;
+  }
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_pass<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(uint32_t) * FINE_BIG_PARTS));
+    if (e != hipSuccess) return e;
+  }
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(uint32_t) * 2 * SPLIT_B));
     if (e != hipSuccess) return e;
   }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1086,6 +1267,38 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
   const int w_top_pos = plan.total_windows() - 1;
   // (the counting pass needs 42 registers per lane: beside an occupancy-capped accumulation -- nb_log 14 -- only two of its waves
   // fit a SIMD's free registers, so its workgroups are 512 threads there)
+  // Fine-partition form (see k_rec_split): groups of 2^15 buckets -> their 32 fine partitions -> k_fpart_sort.  The records of the
+  // first level go to (sorted, rec_aux), the second level's to (rec_entry, rec_bkt), the entries end in sorted[].
+  // buckets per fine partition: 2^10, or fewer (down to 2^8) while a fine partition would hold more than 32 768 records on average
+  int fine_log = FINE_LOG;
+  while (fine_log > 8 && (((uint64_t)nwin * n) >> (plan.c - 1 - fine_log)) / nwin > 32768) fine_log--;
+  {
+    const int fl = ZK_TUNE("ZKMI_BIG_FINE_LOG", 0);
+    if (fl >= 8 && fl <= FINE_LOG) fine_log = fl;
+  }
+  const uint32_t NPF = tot_b >> fine_log;
+  if (nb_log == 15 && NPF <= FINE_BIG_PARTS && rec_aux != nullptr && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0) {
+    const int fan_log = nb_log - fine_log;
+    hipError_t e = hipMemsetAsync(fpart + NPF, 0, sizeof(uint32_t) * NPF, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_part_pass<false, true, true>), dim3(nblk), dim3(1024), sizeof(uint32_t) * NPF, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
+                       nb_log, P, chunk, rc, blkcnt, sorted, rec_aux, plan.win_first, w_top_pos, fpart + NPF, fine_log);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
+    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NPF, fpart, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF);
+    hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P, chunk, rc, blkcnt,
+                       sorted, rec_aux, plan.win_first, w_top_pos);
+    // batches per group on average -> workgroups per group (at most 16: 3 328 workgroups at 13 windows)
+    uint64_t per_group = ((uint64_t)nwin * n / P + SPLIT_B - 1) / SPLIT_B;
+    const uint32_t nch2 = per_group > 16 ? 16u : (per_group ? (uint32_t)per_group : 1u);
+    hipLaunchKernelGGL(k_rec_split, dim3(nch2, P), dim3(1024), sizeof(uint32_t) * 2 * SPLIT_B, st, (const uint32_t*)sorted, (const uint32_t*)rec_aux,
+                       (const uint32_t*)part_total, fpart + 2 * NPF, rec_entry, rec_bkt, fan_log, fine_log);
+    hipLaunchKernelGGL(k_fpart_sort, dim3(NPF), dim3(1024), sizeof(uint32_t) * FINE_STAGE, st, rec_entry, rec_bkt, fpart, NPF, count, begin, sorted, 1, fine_log);
+    e = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
+    if (e != hipSuccess) return e;
+    if (prof) prof->end(PH_MSM_SORT, st);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(nb_log == 14 ? 512 : 1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
                      chunk, rc, blkcnt, rec_entry, rec_bkt, plan.win_first, w_top_pos);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
@@ -1167,7 +1380,7 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
       hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                          rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
     hipLaunchKernelGGL(k_fpart_sort, dim3(NP), dim3(1024), stage_on ? sizeof(uint32_t) * FINE_STAGE : 0, st, rec_entry, rec_bkt, fpart, NP,
-                       count, begin, sorted, stage_on ? 1 : 0);
+                       count, begin, sorted, stage_on ? 1 : 0, FINE_LOG);
     hipError_t e1 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e1 != hipSuccess) return e1;
     if (prof) prof->end(PH_MSM_SORT, st);
