@@ -34,6 +34,14 @@ wl[(kind >= 0.3) & (kind < 0.5), 0] = 1
 b = ctx.bases_g1_synthetic(n)
 h.update(ctx.msm_g1(sc.tobytes(), b))
 h.update(ctx.msm_g1(wl.tobytes(), b))
+# the same slices under the plan of a 2^24-term MSM (20-bit windows: the two-level record sort of msm_sort.hip run_windowed_big;
+# the witness-like slice puts 52 000 records into one fine partition: the round form of k_fpart_sort)
+for s_ in (sc, wl):
+    d_ = torch.from_numpy(s_).cuda()
+    torch.cuda.synchronize()
+    w_, nwin_, cb_ = ctx.msm_g1_windows_dev(d_.data_ptr(), n, b, 1 << 24)
+    assert (nwin_, cb_) == (13, 20)
+    h.update(w_)
 b.prepare()
 h.update(ctx.msm_g1(sc.tobytes(), b))
 h.update(ctx.msm_g1(wl.tobytes(), b))
