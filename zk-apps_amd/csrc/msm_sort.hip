@@ -121,6 +121,24 @@ k_bucket_pass_shared(const uint32_t* __restrict__ scalars, uint32_t n, int c, in
   }
 }
 
+// LDS counter updates of one wave, aggregated when all its active lanes name the SAME counter: a witness of bits sends
+// 630 000 records to one bucket, i.e. 64-way same-address ds_add conflicts on every wave-instruction of both passes (with
+// the round structure below: 3.7 ms of k_fpart_sort for a 2^20 bit witness, 0.15 ms for a dense one).  Returns the value
+// the lane's own atomicAdd(&ctr[idx], 1) would have returned (any order within the wave is as good as another).
+__device__ __forceinline__ uint32_t wave_counter_add(uint32_t* ctr, uint32_t idx, bool valid) {
+  const uint64_t mask = __ballot(valid);
+  if (mask == 0) return 0u;
+  const int leader = __ffsll((unsigned long long)mask) - 1;
+  const uint32_t idx0 = (uint32_t)__shfl((int)idx, leader);
+  if (__ballot(valid && idx != idx0) == 0) {  // wave-uniform
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&ctr[idx0], (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+  }
+  return valid ? atomicAdd(&ctr[idx], 1u) : 0u;
+}
+
 // ---- record pre-pass (shared mode with several partitions) -----------------------
 // Scanning every scalar's digits once per partition costs P x the digit extraction.  With
 // P > 1 the digits are extracted ONCE into (table index, local bucket) records grouped by
@@ -154,6 +172,28 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
   const int w_top = WIN ? w_top_pos - w0 : -1;
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  if (WIN && ppw == 1) {
+    // one group per window (c = 16): at digit w every lane of a wave names counter w -- one LDS atomic per wave instead of a
+    // 64-way same-address conflict (whole waves walk the scalars: the aggregated update needs every lane)
+    for (uint32_t i0 = beg; i0 < end; i0 += blockDim.x) {
+      const uint32_t i = i0 + threadIdx.x;
+      const bool in = i < end;
+      uint32_t k[9];
+      if (in) load_biased(scalars, i, rc, k);
+      for (int w = 0; w < ndigits; w++) {
+        bool neg = false;
+        const uint32_t d = in ? digit_of(k, w0 + w, c, neg) : 0u;
+        const uint32_t bkt = d - 1;
+        const uint32_t pos = wave_counter_add(cnt, (uint32_t)w, d != 0);
+        if (d == 0) continue;
+        if (FINE) atomicAdd(&fine_cnt[((uint32_t)w << fan_log) + (bkt >> fine_log)], 1u);
+        if (WRITE) {
+          rec_entry[pos] = i | (neg ? 0x80000000u : 0u);
+          rec_bkt[pos] = bkt;
+        }
+      }
+    }
+  } else
   for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
     uint32_t k[9];
     load_biased(scalars, i, rc, k);
@@ -449,24 +489,6 @@ k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restric
 // position falls into, a run that overshoots the stage's slack is written directly.
 constexpr uint32_t FINE_STAGE = 36864;   // entries the LDS stage holds (147 456 B)
 constexpr uint32_t FINE_ROUND = 32768;   // positions per round; FINE_STAGE - FINE_ROUND = slack for a straddling run
-// LDS counter updates of one wave, aggregated when all its active lanes name the SAME counter: a witness of bits sends
-// 630 000 records to one bucket, i.e. 64-way same-address ds_add conflicts on every wave-instruction of both passes (with
-// the round structure below: 3.7 ms of k_fpart_sort for a 2^20 bit witness, 0.15 ms for a dense one).  Returns the value
-// the lane's own atomicAdd(&ctr[idx], 1) would have returned (any order within the wave is as good as another).
-__device__ __forceinline__ uint32_t wave_counter_add(uint32_t* ctr, uint32_t idx, bool valid) {
-  const uint64_t mask = __ballot(valid);
-  if (mask == 0) return 0u;
-  const int leader = __ffsll((unsigned long long)mask) - 1;
-  const uint32_t idx0 = (uint32_t)__shfl((int)idx, leader);
-  if (__ballot(valid && idx != idx0) == 0) {  // wave-uniform
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&ctr[idx0], (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
-  }
-  return valid ? atomicAdd(&ctr[idx], 1u) : 0u;
-}
-
 constexpr uint32_t FSORT_U = 4;     // records in flight per thread in the round form of k_fpart_sort
 constexpr uint32_t FSORT_RPT = 36;  // records per thread of its register form: partitions of up to 36 864 records (= FINE_STAGE)
 // fine_log: log2 of the buckets per fine partition (<= FINE_LOG: one counter per thread); bucket ids are q << fine_log | local.
@@ -614,7 +636,7 @@ k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict_
 // (SPLIT_B / fan = 64 .. 256 records on average).  The order of a fine partition's records depends on which batch reserved first:
 // the bucket sums do not (and every caller's result is canonical bytes).
 constexpr uint32_t SPLIT_B = 8192;  // records per batch: 8 per thread, 64 KB of stage
-constexpr uint32_t SPLIT_MAX_FAN = 128;  // 2^15-bucket groups cut into fine partitions of 2^8 buckets
+constexpr uint32_t SPLIT_MAX_FAN = 256;  // 2^15-bucket groups cut into fine partitions of 2^7 buckets
 __device__ __forceinline__ uint32_t wave_bin_rank(uint32_t* ctr, uint32_t f, bool valid, int fan_log) {
   uint64_t m = __ballot(valid);
   for (int bit = 0; bit < fan_log; bit++) {
@@ -655,23 +677,29 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) rk[k] = wave_bin_rank(cnt, key[k] >> fine_log, key[k] != 0xffffffffu, fan_log);
     __syncthreads();
-    if (tid < 64) {  // one wave (two partitions per lane): exclusive prefix of the batch's counts, and the batch's room in every fine partition
-      const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
-      const uint32_t v0 = f0 < fan ? cnt[f0] : 0u, v1 = f1 < fan ? cnt[f1] : 0u;
-      uint32_t incl = v0 + v1;
+    if (tid < 64) {  // one wave (four partitions per lane): exclusive prefix of the batch's counts, and the batch's room in every fine partition
+      uint32_t v[4], sum = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t f = 4 * tid + j;
+        v[j] = f < fan ? cnt[f] : 0u;
+        sum += v[j];
+      }
+      uint32_t incl = sum;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_up(incl, off);
         if ((int)tid >= off) incl += t;
       }
-      const uint32_t ex = incl - v0 - v1;
-      if (f0 < fan) {
-        base[f0] = ex;
-        gb[f0] = v0 ? atomicAdd(&cursor[(q << fan_log) + f0], v0) : 0u;
-      }
-      if (f1 < fan) {
-        base[f1] = ex + v0;
-        gb[f1] = v1 ? atomicAdd(&cursor[(q << fan_log) + f1], v1) : 0u;
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t f = 4 * tid + j;
+        if (f < fan) {
+          base[f] = run;
+          gb[f] = v[j] ? atomicAdd(&cursor[(q << fan_log) + f], v[j]) : 0u;
+          run += v[j];
+        }
       }
     }
     __syncthreads();
@@ -980,6 +1008,11 @@ MsmPlan msm_make_plan_shared_batch(uint64_t n, uint32_t batch) {
 // windowed plans with more than 2^15 buckets per window: partitions per window and in total (run_windowed_big)
 static inline uint32_t big_parts_per_window(const MsmPlan& p) { return p.nb >> 15; }
 static inline bool plan_is_big(const MsmPlan& p) { return !p.shared && p.c > 16; }
+// 16-bit windows (2^15 buckets = one group per window) from 2^19 terms on take the same two-level record sort as the big plans
+// (A/B library: ZKMI_WIN_TWO_LEVEL = smallest log2(n) that does, 30 = never)
+static inline bool plan_two_level(const MsmPlan& p, uint64_t n) {
+  return !p.shared && p.c == 16 && n >= (1ull << ZK_TUNE("ZKMI_WIN_TWO_LEVEL", 19)) && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0;
+}
 
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
 
@@ -1078,7 +1111,7 @@ hipError_t MsmSort::reserve(uint64_t n, bool shared_too) {
   if (nbk < forced) nbk = forced;  // allow plan_override = 16 for any n
   if (16 * n > ne) ne = 16 * n;
   // (the record buffers serve the shared-bucket sorts and the partitioned windows of big windowed plans alike)
-  shared_too = shared_too || has_shared || plan_is_big(msm_make_plan(n));
+  shared_too = shared_too || has_shared || plan_is_big(msm_make_plan(n)) || plan_two_level(msm_make_plan(n), n);
   if (shared_too) {
     // shared-bucket plan for the same n (only the prover uses it)
     const MsmPlan sp = msm_make_plan_shared(n);
@@ -1188,7 +1221,8 @@ hipError_t MsmSort::run(const uint32_t* d_scalars, uint64_t n, hipStream_t st, P
     plan.win_first = win_first;
     plan.nwin = win_count;
   }
-  if (plan_is_big(plan)) return run_windowed_big(d_scalars, n, st, prof);
+  if (plan_is_big(plan) || (plan_two_level(plan, n) && rec_aux != nullptr && (uint64_t)plan.nwin * n <= cap_entries))
+    return run_windowed_big(d_scalars, n, st, prof);
   const uint32_t nb = plan.nb, nwin = (uint32_t)plan.nwin;
   const uint32_t tot_b = nwin * nb;
   const uint32_t nch = pick_chunks(plan);
@@ -1243,8 +1277,7 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
   const uint32_t P = nwin * (plan.nb >> nb_log);
   const uint32_t tot_b = nwin * plan.nb;
   const uint32_t nch = shared_chunks(P, n);
-  if (P > PART_MAX || (uint64_t)nwin * n > cap_entries || tot_b > cap_buckets || (uint64_t)tot_b * nch > cap_hist || !rec_entry)
-    return hipErrorInvalidValue;
+  if (P > PART_MAX || (uint64_t)nwin * n > cap_entries || tot_b > cap_buckets || !rec_entry) return hipErrorInvalidValue;
   RecodeConst rc;
   for (int j = 0; j < 9; j++) rc.m[j] = 0;
   for (uint32_t w = 0; w < (uint32_t)plan.total_windows(); w++) {  // (the recoding bias covers ALL digit positions)
@@ -1271,10 +1304,10 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
   // first level go to (sorted, rec_aux), the second level's to (rec_entry, rec_bkt), the entries end in sorted[].
   // buckets per fine partition: 2^10, or fewer (down to 2^8) while a fine partition would hold more than 32 768 records on average
   int fine_log = FINE_LOG;
-  while (fine_log > 8 && (((uint64_t)nwin * n) >> (plan.c - 1 - fine_log)) / nwin > 32768) fine_log--;
+  while (fine_log > 7 && (n >> (plan.c - 1 - fine_log)) > 32768) fine_log--;
   {
     const int fl = ZK_TUNE("ZKMI_BIG_FINE_LOG", 0);
-    if (fl >= 8 && fl <= FINE_LOG) fine_log = fl;
+    if (fl >= 7 && fl <= FINE_LOG) fine_log = fl;
   }
   const uint32_t NPF = tot_b >> fine_log;
   if (nb_log == 15 && NPF <= FINE_BIG_PARTS && rec_aux != nullptr && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0) {
@@ -1299,6 +1332,7 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
     if (prof) prof->end(PH_MSM_SORT, st);
     return hipGetLastError();
   }
+  if ((uint64_t)tot_b * nch > cap_hist) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_part_pass<false, true>), dim3(nblk), dim3(nb_log == 14 ? 512 : 1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
                      chunk, rc, blkcnt, rec_entry, rec_bkt, plan.win_first, w_top_pos);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
