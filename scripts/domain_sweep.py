@@ -13,7 +13,7 @@ import torch  # noqa: E402
 def main():
     lo = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     hi = int(sys.argv[2]) if len(sys.argv) > 2 else 21
-    z = bench.load_pkg().Zkmi()
+    z = bench.load_pkg().Zkmi(os.environ.get("ZKMI_LIB"))
     ctx = z.context(0)
     print(f"{'log_n':>5} {'proofs':>7} {'proofs/s':>10} {'ms/proof':>9} {'1-proof latency ms':>19}  verified")
     for lg in range(lo, hi + 1):

@@ -10,7 +10,8 @@ import torch
 import bench
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 14
-z = bench.load_pkg().Zkmi()
+import os
+z = bench.load_pkg().Zkmi(os.environ.get("ZKMI_LIB"))
 ctx = z.context(0)
 r1, wits = bench.relation_and_witness(z, "poseidon", lg, [1, 2])
 rng = bench.SplitMix64(3)

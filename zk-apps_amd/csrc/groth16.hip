@@ -1176,6 +1176,80 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
     // waited for, s * A + r * B1 as soon as the two G1 MSMs over z are in (the G2 MSM takes three times as long)
     AssemblyHead head;
     const AssemblyPre pre = assemble_pre(pk, r_bytes, s_bytes);
+    if (ctx->g1.host_spin && !merged && ZK_TUNE("ZKMI_SOLO_EVENT_ORDER", 1) != 0) {
+      // ONE proof by itself: the five results are taken in the order they arrive.  A small proof's G2 MSM lands first (one
+      // reduction chain against four) and B1 before A: B is assembled and compressed, r * B1 and s * A are multiplied out
+      // while the remaining reductions still run, and what is left behind the last result is three additions and one shared
+      // inversion.  (In the fixed order A, B1 | s A + r B1 | B2 | L | H | tail the host worked for 0.40 ms AFTER A had landed
+      // at 2^14: 0.19 ms of the joint doubling chain, 0.12 ms of combining and assembling a B2 that had been ready for
+      // 0.3 ms, 0.07 ms of three inversions.)
+      enum { RA = 0, RB1 = 1, RL = 2, RH = 3, RB2 = 4 };
+      hipEvent_t evs[5] = {ctx->g1.done[s0 + 0], ctx->g1.done[s0 + 1], ctx->g1.done[s0 + 2], ctx->g1.done[s0 + 3], ctx->g2.done[g2s]};
+      bool got[5] = {false, false, false, false, false};
+      G1XYZZ s_a = G1XYZZ::infinity(), r_b1 = G1XYZZ::infinity();
+      int left = 5;
+      bool polled_busy = false;
+      while (left) {
+        bool progress = false;
+        for (int i = 0; i < 5; i++) {
+          if (got[i]) continue;
+          const hipError_t q = hipEventQuery(evs[i]);
+          if (q == hipErrorNotReady) {
+            polled_busy = true;
+            continue;
+          }
+          if (q != hipSuccess) return ctx->hip_fail(q, "hipEventQuery(done[slot])");
+          got[i] = true;
+          left--;
+          progress = true;
+          switch (i) {
+            case RA:
+              ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
+              note_density();
+              head.g_a = pre.d_r;
+              head.g_a.madd(pk->ka);
+              head.g_a.add(acc_a[0]);
+              s_a = scalar_mul_w4(head.g_a, pre.sk);
+              break;
+            case RB1:
+              ZK_HIP(ctx, ctx->g1.finish_host(&acc_b1[0], s0 + 1));
+              r_b1 = scalar_mul_w4(acc_b1[0], pre.rk);
+              break;
+            case RL: ZK_HIP(ctx, ctx->g1.finish_host(&acc_l[0], s0 + 2)); break;
+            case RH: ZK_HIP(ctx, ctx->g1.finish_host(&acc_h[0], s0 + 3)); break;
+            case RB2:
+              ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
+              assemble_g2(pk, pre, acc_b2[0], head);
+              g2_compress(head.g2_b.to_affine(), out_proofs + 48);
+              break;
+          }
+          if (lat_debug) mark(i == RB2 ? 5 : i);
+          break;  // after the work, look at all pending results again
+        }
+        (void)progress;
+      }
+      if (polled_busy) (void)hipGetLastError();  // hipErrorNotReady is a status, not a failure (host_pool.hpp wait_event)
+      const uint32_t flags = pk->h_unsat[par];
+      pk->h_unsat[par] = 0;
+      if (flags & 2u) return ctx->fail(ZKMI_ERR_NON_CANONICAL, "witness element >= r");
+      if (flags) return ctx->fail(ZKMI_ERR_UNSATISFIED, "assignment does not satisfy the relation (or z[0] != 1)");
+      head.g_c = s_a;
+      head.g_c.add(r_b1);
+      head.g_c.add(pre.r_k1);
+      head.g_c.add(acc_l[0]);
+      head.g_c.add(acc_h[0]);
+      const G1XYZZ ac[2] = {head.g_a, head.g_c};
+      G1Affine aff[2];
+      batch_to_affine(ac, 2, aff);
+      g1_compress(aff[0], out_proofs);
+      g1_compress(aff[1], out_proofs + 144);
+      if (lat_debug) {
+        const long t_end = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "zkmi: finish (arrival order): A in + s A done %ld us, B1 + r B1 %ld, L %ld, H %ld, B2 + B compressed %ld, proof out %ld\n", tm[0], tm[1], tm[2],
+                tm[3], tm[5], t_end);
+      }
+      return ZKMI_OK;
+    }
     ZK_HIP(ctx, ctx->g1.finish_host(&acc_a[0], s0 + 0));
     note_density();
     if (merged_b1) acc_b1[0] = G1XYZZ::infinity();  // r * MSM(b1, z) comes in through the H slot: assemble_g1 multiplies the fixed part of B1 only
