@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every file under profiles/<round>/ in one command, on the GPU box, from the repo root:
 #
-#     bash scripts/profile.sh r04            # -> gpurun_out/prof_r04/{trace,pmc_*}/..., summaries in profiles/r04/
+#     bash scripts/profile.sh r05            # -> gpurun_out/prof_r05/{trace,pmc_*}/..., summaries in profiles/r05/
 # Run it LAST in a round, after the final commit that touches zk-apps_amd/csrc: the PMC summary is stamped with the digest
 # of those sources and bench.py compares it with the sources it runs (roofline.traffic_source.same_sources_as_this_run).
 #
@@ -9,7 +9,7 @@
 # collection are separate runs, and the counters are split over passes that fit the hardware slots
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: /opt/skills/guides/MI355X_MICROARCH.md, PMC slots).
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 OUT=gpurun_out/prof_$ROUND
 DST=profiles/$ROUND
 STEPS_TRACE=${STEPS_TRACE:-24}
