@@ -59,7 +59,7 @@ def test_ntt_full_size_all_modes_vs_cpp_oracle(ctx, lg):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "witness_like"])
-def test_msm_g1_2p20_vs_cpp_oracle(ctx, kind):
+def test_msm_g1_2p20_vs_cpp_oracle(ctx, zk, kind):
     """Row a8 at config 1's size: 2^20 terms, uniform scalars and the witness-like mix (heavy buckets: 20 % of all
     points share one bucket per window), against the C++ oracle's windowed Pippenger; and the same MSM over prepared
     bases (the prover's shared-bucket schedule)."""
@@ -71,6 +71,15 @@ def test_msm_g1_2p20_vs_cpp_oracle(ctx, kind):
     b = ctx.bases_g1_synthetic(n)
     want = ocpp.msm_g1(sc, b.read(0, n))
     assert ctx.msm_g1(sc, b) == want
+    # the same terms as ONE slice under the plan of a 2^24-term MSM (20-bit windows, the two-level sort of the big plans): the
+    # witness-like mix puts 210 000 records into one fine partition there too -- the oversized-partition kernels (k_big_*)
+    import torch
+
+    d = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    w, nwin, cb = ctx.msm_g1_windows_dev(d.data_ptr(), n, b, 1 << 24)
+    assert (nwin, cb) == (13, 20)
+    assert zk.msm_g1_combine(w, 1, nwin, cb) == want
     b.prepare()
     assert ctx.msm_g1(sc, b) == want
     b.free()

@@ -96,6 +96,7 @@ struct MsmSort {
   uint32_t* rec_entry = nullptr;  // records grouped by partition: table index | sign
   uint32_t* rec_bkt = nullptr;    //                               bucket id inside the partition
   uint32_t* rec_aux = nullptr;    // big windowed plans: bucket ids of the first-level records (msm_sort.hip k_rec_split)
+  uint32_t* big_ws = nullptr;     // ... and the list + chunk counters of oversized fine partitions (k_big_*)
   uint32_t* sorted = nullptr;     // nwin*n    point index | sign<<31
   uint64_t cap_entries = 0, cap_buckets = 0, cap_hist = 0;
   MsmPlan plan;

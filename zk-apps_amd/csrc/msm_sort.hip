@@ -458,7 +458,9 @@ k_fpart_scan_rows(uint32_t* __restrict__ blkcnt, uint32_t nblk, uint32_t NP, uin
 // It also leaves the sort's record count where the other sort paths leave their per-partition totals: part_total[0] = all
 // records, part_total[1 .. P) = 0 (the prover's k_entries_to_host sums the P words: the non-zero digits of the assignment)
 __global__ void __launch_bounds__(1024)
-k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restrict__ part_total, uint32_t P) {
+k_fpart_scan_base(uint32_t NP, uint32_t* __restrict__ fpart, uint32_t* __restrict__ part_total, uint32_t P,
+                  uint32_t* __restrict__ big_list = nullptr) {
+  if (big_list && threadIdx.x == 0) big_list[0] = 0;  // (k_fine_cursors, the next kernel of the stream, fills the list)
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (NP + 1023u) / 1024u;
@@ -499,7 +501,8 @@ constexpr uint32_t FSORT_RPT = 36;  // records per thread of its register form: 
 __global__ void __launch_bounds__(1024)
 k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
              uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged,
-             int fine_log) {
+             int fine_log, const uint32_t* __restrict__ bigflag = nullptr) {
+  if (bigflag && bigflag[blockIdx.x]) return;  // an oversized partition: sorted by the k_big_* kernels, 64 workgroups each
   static_assert(FINE_NB == 1024, "one counter per thread");
   static_assert(FSORT_RPT * 1024 <= FINE_STAGE, "the register form stages a whole partition");
   __shared__ uint32_t hist[FINE_NB];  // counts, then cursors (positions relative to the partition)
@@ -721,11 +724,125 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a
     __syncthreads();
   }
 }
-// fpart[2 NP + q] = fpart[q]: the cursors k_rec_split advances
+// Oversized fine partitions.  One workgroup per fine partition is the right grain while the digits are spread out; a witness of
+// bits and small values is not: a fifth of all scalars equal to one puts 13 M records of a 2^26-term MSM into ONE bucket, and
+// the workgroup owning it would walk them three times while 26 623 others finished in microseconds.  Partitions above
+// BIG_THR records (four times the largest mean the planner allows) are listed (at most BIG_MAX) and sorted by BIG_NCH
+// workgroups each in three small kernels -- per-chunk LDS histograms, a scan over chunks and buckets that also writes count[] /
+// begin[], and a scatter with LDS cursors (a heavy bucket's entries leave as whole runs: the lanes of a wave that name the same
+// bucket take consecutive positions); k_fpart_sort skips them.  With uniform digits the list is empty and the three launches
+// return at once.
+constexpr uint32_t BIG_THR = 131072, BIG_MAX = 32, BIG_NCH = 64;
+// fpart[2 NP + q] = fpart[q]: the cursors k_rec_split advances; fpart[3 NP + q] = 1 + list index of an oversized partition, or 0
 __global__ void __launch_bounds__(256)
-k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP) {
+k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP, uint32_t* __restrict__ big_list) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-  if (q < NP) fpart[2 * NP + q] = fpart[q];
+  if (q >= NP) return;
+  fpart[2 * NP + q] = fpart[q];
+  uint32_t flag = 0;
+  if (fpart[NP + q] > BIG_THR) {
+    const uint32_t j = atomicAdd(&big_list[0], 1u);
+    if (j < BIG_MAX) {
+      big_list[1 + j] = q;
+      flag = 1 + j;
+    }
+  }
+  fpart[3 * NP + q] = flag;
+}
+// chunk ch of listed partition j: records [lo, hi) of the partition (whole waves walk them: the aggregated counters need every lane)
+__device__ __forceinline__ bool big_slice(const uint32_t* fpart, uint32_t NP, const uint32_t* big_list, uint32_t& pbase, uint32_t& lo,
+                                          uint32_t& hi, uint32_t& steps) {
+  const uint32_t j = blockIdx.y, nbig = big_list[0] < BIG_MAX ? big_list[0] : BIG_MAX;
+  if (j >= nbig) return false;
+  const uint32_t q = big_list[1 + j];
+  pbase = fpart[q];
+  const uint32_t ptot = fpart[NP + q];
+  const uint32_t per = (((ptot + BIG_NCH - 1) / BIG_NCH) + 1023u) & ~1023u;
+  lo = blockIdx.x * per;
+  hi = lo + per < ptot ? lo + per : ptot;
+  steps = per / 1024;
+  return true;
+}
+__global__ void __launch_bounds__(1024)
+k_big_hist(const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __restrict__ big_list,
+           uint32_t* __restrict__ bighist) {
+  __shared__ uint32_t hist[FINE_NB];
+  uint32_t pbase, lo, hi, steps;
+  if (!big_slice(fpart, NP, big_list, pbase, lo, hi, steps)) return;
+  const uint32_t tid = threadIdx.x;
+  hist[tid] = 0;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < steps; k0 += 4) {
+    uint32_t b[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t r = lo + (k0 + k) * 1024 + tid;
+      b[k] = (k0 + k < steps && r < hi) ? rec_bkt[pbase + r] : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (k0 + k < steps) (void)wave_counter_add(hist, b[k] != 0xffffffffu ? b[k] : 0u, b[k] != 0xffffffffu);
+  }
+  __syncthreads();
+  bighist[((size_t)blockIdx.y * BIG_NCH + blockIdx.x) * FINE_NB + tid] = hist[tid];
+}
+// one workgroup per listed partition, thread = bucket: chunk counts -> absolute first positions per (chunk, bucket); count[] / begin[]
+__global__ void __launch_bounds__(1024)
+k_big_scan(const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __restrict__ big_list, uint32_t* __restrict__ bighist,
+           uint32_t* __restrict__ count, uint32_t* __restrict__ begin, int fine_log) {
+  __shared__ uint32_t part[1024];
+  const uint32_t j = blockIdx.x, nbig = big_list[0] < BIG_MAX ? big_list[0] : BIG_MAX, tid = threadIdx.x;
+  if (j >= nbig) return;
+  const uint32_t q = big_list[1 + j], pbase = fpart[q];
+  uint32_t* const row = bighist + (size_t)j * BIG_NCH * FINE_NB + tid;
+  uint32_t run = 0;
+  for (uint32_t ch = 0; ch < BIG_NCH; ch++) {
+    const uint32_t v = row[(size_t)ch * FINE_NB];
+    row[(size_t)ch * FINE_NB] = run;
+    run += v;
+  }
+  part[tid] = run;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t first = pbase + (tid ? part[tid - 1] : 0u);
+  if (tid < (1u << fine_log)) {
+    const size_t g = ((size_t)q << fine_log) + tid;
+    count[g] = run;
+    begin[g] = first;
+  }
+  for (uint32_t ch = 0; ch < BIG_NCH; ch++) row[(size_t)ch * FINE_NB] += first;
+}
+__global__ void __launch_bounds__(1024)
+k_big_scatter(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP,
+              const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ bighist, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cur[FINE_NB];
+  uint32_t pbase, lo, hi, steps;
+  if (!big_slice(fpart, NP, big_list, pbase, lo, hi, steps)) return;
+  const uint32_t tid = threadIdx.x;
+  cur[tid] = bighist[((size_t)blockIdx.y * BIG_NCH + blockIdx.x) * FINE_NB + tid];
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < steps; k0 += 4) {
+    uint32_t b[4], e[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t r = lo + (k0 + k) * 1024 + tid;
+      const bool in = k0 + k < steps && r < hi;
+      b[k] = in ? rec_bkt[pbase + r] : 0xffffffffu;
+      e[k] = in ? rec_entry[pbase + r] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (k0 + k < steps) {
+        const bool valid = b[k] != 0xffffffffu;
+        const uint32_t pos = wave_counter_add(cur, valid ? b[k] : 0u, valid);
+        if (valid) sorted[pos] = e[k];
+      }
+  }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -1084,6 +1201,8 @@ void MsmSort::release() {
   if (rec_entry) (void)hipFree(rec_entry);
   if (rec_bkt) (void)hipFree(rec_bkt);
   if (rec_aux) (void)hipFree(rec_aux);
+  if (big_ws) (void)hipFree(big_ws);
+  big_ws = nullptr;
   if (begin) (void)hipFree(begin);
   if (blockhist) (void)hipFree(blockhist);
   if (sorted) (void)hipFree(sorted);
@@ -1145,14 +1264,15 @@ hipError_t MsmSort::allocate(uint64_t ne, uint64_t nbk, uint64_t nh, bool shared
   if ((e = hipMalloc(&part_total, sizeof(uint32_t) * PART_MAX)) != hipSuccess) return e;
   if ((e = hipMalloc(&order_bins, sizeof(uint32_t) * (MSM_HEAVY + 2) * (256 + 1))) != hipSuccess) return e;  // row 0: offsets, rows 1..: per-block key counts
   if ((e = hipMalloc(&blkcnt, sizeof(uint32_t) * FPART_BLOCKS * FINE_MAX_PARTS)) != hipSuccess) return e;  // also 256 x 64 of the coarse form
-  static_assert(3 * FINE_BIG_PARTS >= 2 * FINE_MAX_PARTS, "fpart serves both fine-partition forms");
-  if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 3 * FINE_BIG_PARTS)) != hipSuccess) return e;  // bases, totals, cursors
+  static_assert(4 * FINE_BIG_PARTS >= 2 * FINE_MAX_PARTS, "fpart serves both fine-partition forms");
+  if ((e = hipMalloc(&fpart, sizeof(uint32_t) * 4 * FINE_BIG_PARTS)) != hipSuccess) return e;  // bases, totals, cursors, oversize flags
   if (shared) {
     if ((e = hipMalloc(&rec_entry, sizeof(uint32_t) * ne)) != hipSuccess) return e;
     if ((e = hipMalloc(&rec_bkt, sizeof(uint32_t) * ne)) != hipSuccess) return e;
     // second record array of the two-level big windowed sort (its first level borrows sorted[] for the entries); only where
     // such a plan can occur: from 2^21 entries on (a 2^17-term slice of a split 2^24-term MSM)
     if (ne >= (1ull << 21) && (e = hipMalloc(&rec_aux, sizeof(uint32_t) * ne)) != hipSuccess) return e;
+    if (rec_aux && (e = hipMalloc(&big_ws, sizeof(uint32_t) * (1 + BIG_MAX + (size_t)BIG_MAX * BIG_NCH * FINE_NB))) != hipSuccess) return e;
   }
   has_shared = shared;
   if ((e = hipMalloc(&heavy, sizeof(uint32_t) * (nbk + 1))) != hipSuccess) return e;  // [0] = list length
@@ -1310,15 +1430,15 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
     if (fl >= 7 && fl <= FINE_LOG) fine_log = fl;
   }
   const uint32_t NPF = tot_b >> fine_log;
-  if (nb_log == 15 && NPF <= FINE_BIG_PARTS && rec_aux != nullptr && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0) {
+  if (nb_log == 15 && NPF <= FINE_BIG_PARTS && rec_aux != nullptr && big_ws != nullptr && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0) {
     const int fan_log = nb_log - fine_log;
     hipError_t e = hipMemsetAsync(fpart + NPF, 0, sizeof(uint32_t) * NPF, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_part_pass<false, true, true>), dim3(nblk), dim3(1024), sizeof(uint32_t) * NPF, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
                        nb_log, P, chunk, rc, blkcnt, sorted, rec_aux, plan.win_first, w_top_pos, fpart + NPF, fine_log);
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
-    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NPF, fpart, (uint32_t*)nullptr, 0u);
-    hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF);
+    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NPF, fpart, (uint32_t*)nullptr, 0u, big_ws);
+    hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF, big_ws);
     hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P, chunk, rc, blkcnt,
                        sorted, rec_aux, plan.win_first, w_top_pos);
     // batches per group on average -> workgroups per group (at most 16: 3 328 workgroups at 13 windows)
@@ -1326,7 +1446,14 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
     const uint32_t nch2 = per_group > 16 ? 16u : (per_group ? (uint32_t)per_group : 1u);
     hipLaunchKernelGGL(k_rec_split, dim3(nch2, P), dim3(1024), sizeof(uint32_t) * 2 * SPLIT_B, st, (const uint32_t*)sorted, (const uint32_t*)rec_aux,
                        (const uint32_t*)part_total, fpart + 2 * NPF, rec_entry, rec_bkt, fan_log, fine_log);
-    hipLaunchKernelGGL(k_fpart_sort, dim3(NPF), dim3(1024), sizeof(uint32_t) * FINE_STAGE, st, rec_entry, rec_bkt, fpart, NPF, count, begin, sorted, 1, fine_log);
+    // (oversized partitions first: see k_fine_cursors; big_ws = the list, then BIG_MAX x BIG_NCH x 1024 chunk counters)
+    uint32_t* const bighist = big_ws + 1 + BIG_MAX;
+    hipLaunchKernelGGL(k_big_hist, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NPF, (const uint32_t*)big_ws, bighist);
+    hipLaunchKernelGGL(k_big_scan, dim3(BIG_MAX), dim3(1024), 0, st, (const uint32_t*)fpart, NPF, (const uint32_t*)big_ws, bighist, count, begin, fine_log);
+    hipLaunchKernelGGL(k_big_scatter, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint32_t*)rec_entry, (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NPF,
+                       (const uint32_t*)big_ws, (const uint32_t*)bighist, sorted);
+    hipLaunchKernelGGL(k_fpart_sort, dim3(NPF), dim3(1024), sizeof(uint32_t) * FINE_STAGE, st, rec_entry, rec_bkt, fpart, NPF, count, begin, sorted, 1, fine_log,
+                       (const uint32_t*)(fpart + 3 * NPF));
     e = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e != hipSuccess) return e;
     if (prof) prof->end(PH_MSM_SORT, st);
