@@ -153,11 +153,12 @@ constexpr int FINE_LOG = 10;        // buckets per fine partition (the fine-part
 // FINE (counting pass of the big windowed plans): also the records per FINE partition -- 2^fine_log consecutive buckets of a
 // group -- summed over all blocks into fine_tot[group * (nb >> fine_log) + fine] (zeroed by the caller; dynamic LDS: one
 // counter per fine partition)
-template <bool WRITE, bool WIN = false, bool FINE = false>
+// K: type of the stored bucket ids (uint16_t in the two-level sort: a record is 6 bytes instead of 8 through three passes)
+template <bool WRITE, bool WIN = false, bool FINE = false, class K = uint32_t>
 __global__ void __launch_bounds__(1024)
 k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P,
             uint32_t chunk, RecodeConst rc, uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry,
-            uint32_t* __restrict__ rec_bkt, int w0 = 0, int w_top_pos = -1, uint32_t* __restrict__ fine_tot = nullptr,
+            K* __restrict__ rec_bkt, int w0 = 0, int w_top_pos = -1, uint32_t* __restrict__ fine_tot = nullptr,
             int fine_log = FINE_LOG) {
   __shared__ uint32_t cnt[PART_MAX];
   extern __shared__ uint32_t fine_cnt[];
@@ -189,7 +190,7 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
         if (FINE) atomicAdd(&fine_cnt[((uint32_t)w << fan_log) + (bkt >> fine_log)], 1u);
         if (WRITE) {
           rec_entry[pos] = i | (neg ? 0x80000000u : 0u);
-          rec_bkt[pos] = bkt;
+          rec_bkt[pos] = (K)bkt;
         }
       }
     }
@@ -207,7 +208,7 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
       if (FINE) atomicAdd(&fine_cnt[(q << fan_log) + ((bkt & (nb - 1u)) >> fine_log)], 1u);
       if (WRITE) {
         rec_entry[pos] = (WIN ? i : (uint32_t)w * n + i) | (neg ? 0x80000000u : 0u);
-        rec_bkt[pos] = bkt & (nb - 1u);
+        rec_bkt[pos] = (K)(bkt & (nb - 1u));
       }
     }
   }
@@ -219,6 +220,102 @@ k_part_pass(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits
         const uint32_t v = fine_cnt[f];
         if (v) atomicAdd(&fine_tot[f], v);
       }
+  }
+}
+
+// The write pass of the WINDOWED record pre-pass with an LDS stage (big plans and the two-level 16-bit windows: up to 16
+// digits, P <= PART_MAX groups).  The direct form (k_part_pass<true, true>) lets every lane store its record halves wherever its
+// group's cursor points: WRITE_SIZE 12.7 GB for 7 GB of records at 2^26 terms.  Here a batch of 1 024 scalars (13 312 records
+// at c = 20) is ranked per group in LDS, laid out group by group in the stage and written out by consecutive lanes: a
+// group's records of the batch leave as one run (64 records on average at c = 20, 1 024 at c = 16).  Slots: the
+// (block, group) ranges k_part_scan assigned, as for the direct form.
+constexpr uint32_t WSTAGE_MAXD = 16;
+template <class K>
+__global__ void __launch_bounds__(1024)
+k_part_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, int ndigits, uint32_t nb, int nb_log, uint32_t P, uint32_t chunk,
+                    RecodeConst rc, const uint32_t* __restrict__ blkcnt, uint32_t* __restrict__ rec_entry, K* __restrict__ rec_bkt, int w0,
+                    int w_top_pos) {
+  __shared__ uint32_t cursor[PART_MAX];  // next global record slot of (this block, group)
+  __shared__ uint32_t bcnt[PART_MAX];    // records of the batch per group
+  __shared__ uint32_t bbase[PART_MAX];   // ... their first stage slot
+  __shared__ uint32_t gbase[PART_MAX];   // ... their first global slot
+  __shared__ uint32_t s_total;
+  extern __shared__ uint32_t wstage[];   // [1024 * ndigits] entries, then as many (group << 16 | bucket)
+  const uint32_t stage_n = 1024u * (uint32_t)ndigits, tid = threadIdx.x;
+  uint32_t* const s_entry = wstage;
+  uint32_t* const s_key = wstage + stage_n;
+  const uint32_t ppw = (1u << (c - 1)) >> nb_log;
+  const int w_top = w_top_pos - w0;
+  if (tid < PART_MAX) cursor[tid] = tid < P ? blkcnt[blockIdx.x * P + tid] : 0u;
+  const uint32_t beg = blockIdx.x * chunk;
+  const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  for (uint32_t i0 = beg; i0 < end; i0 += 1024) {
+    if (tid < PART_MAX) bcnt[tid] = 0;
+    __syncthreads();
+    const uint32_t i = i0 + tid;
+    const bool in = i < end;
+    uint32_t ent[WSTAGE_MAXD], key[WSTAGE_MAXD], rk[WSTAGE_MAXD];
+    uint32_t k[9];
+    if (in) load_biased(scalars, i, rc, k);
+#pragma unroll
+    for (int w = 0; w < (int)WSTAGE_MAXD; w++) {
+      key[w] = 0xffffffffu;
+      if (w < ndigits) {  // (uniform)
+        bool neg = false;
+        const uint32_t d = in ? digit_of(k, w0 + w, c, neg) : 0u;
+        const uint32_t bkt = d - 1;
+        const uint32_t q = (uint32_t)w * ppw + (w == w_top ? (i & (ppw - 1u)) : (bkt >> nb_log));
+        // one group per window: the wave's lanes name the same counter (aggregated update); 16 groups per window: plain atomics
+        const uint32_t r = ppw == 1 ? wave_counter_add(bcnt, (uint32_t)w, d != 0) : (d != 0 ? atomicAdd(&bcnt[q], 1u) : 0u);
+        if (d != 0) {
+          ent[w] = i | (neg ? 0x80000000u : 0u);
+          key[w] = (q << 16) | (bkt & (nb - 1u));
+          rk[w] = r;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // one wave, four groups per lane: stage and global bases of the batch's groups
+      uint32_t v[4], sum = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        v[j] = bcnt[4 * tid + j];
+        sum += v[j];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)tid >= off) incl += t;
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t q = 4 * tid + j;
+        bbase[q] = run;
+        gbase[q] = cursor[q];
+        cursor[q] += v[j];
+        run += v[j];
+      }
+      if (tid == 63) s_total = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < (int)WSTAGE_MAXD; w++)
+      if (key[w] != 0xffffffffu) {
+        const uint32_t slot = bbase[key[w] >> 16] + rk[w];
+        s_entry[slot] = ent[w];
+        s_key[slot] = key[w];
+      }
+    __syncthreads();
+    const uint32_t total = s_total;
+    for (uint32_t sl = tid; sl < total; sl += 1024) {
+      const uint32_t kk = s_key[sl], q = kk >> 16;
+      const uint32_t dst = gbase[q] + (sl - bbase[q]);
+      rec_entry[dst] = s_entry[sl];
+      rec_bkt[dst] = (K)(kk & 0xffffu);
+    }
+    __syncthreads();
   }
 }
 
@@ -498,8 +595,9 @@ constexpr uint32_t FSORT_RPT = 36;  // records per thread of its register form: 
 // flight together (72 per thread), and keeps them through histogram, scan and the scatter into the stage -- one pass over HBM
 // where the round form below reads the bucket ids once per pass and round with a handful of loads in flight (16 waves per CU
 // beside a 147 KB stage hide no latency: 58 G records/s at 131 072 records per partition, 75 G at 26 000).
+template <class K>
 __global__ void __launch_bounds__(1024)
-k_fpart_sort(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
+k_fpart_sort(const uint32_t* __restrict__ rec_entry, const K* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart,
              uint32_t NP, uint32_t* __restrict__ count, uint32_t* __restrict__ begin, uint32_t* __restrict__ sorted, int staged,
              int fine_log, const uint32_t* __restrict__ bigflag = nullptr) {
   if (bigflag && bigflag[blockIdx.x]) return;  // an oversized partition: sorted by the k_big_* kernels, 64 workgroups each
@@ -655,9 +753,10 @@ __device__ __forceinline__ uint32_t wave_bin_rank(uint32_t* ctr, uint32_t f, boo
   base = (uint32_t)__shfl((int)base, leader);
   return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+template <class K>
 __global__ void __launch_bounds__(1024)
-k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a_bkt, const uint32_t* __restrict__ part_total,
-            uint32_t* __restrict__ cursor, uint32_t* __restrict__ b_entry, uint32_t* __restrict__ b_bkt, int fan_log, int fine_log) {
+k_rec_split(const uint32_t* __restrict__ a_entry, const K* __restrict__ a_bkt, const uint32_t* __restrict__ part_total,
+            uint32_t* __restrict__ cursor, uint32_t* __restrict__ b_entry, K* __restrict__ b_bkt, int fan_log, int fine_log, int plain_rank) {
   extern __shared__ uint32_t split_stage[];  // SPLIT_B entries, then SPLIT_B keys
   __shared__ uint32_t cnt[SPLIT_MAX_FAN], base[SPLIT_MAX_FAN], gb[SPLIT_MAX_FAN];
   uint32_t* const s_entry = split_stage;
@@ -674,11 +773,13 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
       const uint32_t r = b0 + k * 1024 + tid;
-      key[k] = r < ptot ? a_bkt[pbase + r] : 0xffffffffu;
+      key[k] = r < ptot ? (uint32_t)a_bkt[pbase + r] : 0xffffffffu;
       ent[k] = r < ptot ? a_entry[pbase + r] : 0u;
     }
 #pragma unroll
-    for (uint32_t k = 0; k < PER; k++) rk[k] = wave_bin_rank(cnt, key[k] >> fine_log, key[k] != 0xffffffffu, fan_log);
+    for (uint32_t k = 0; k < PER; k++)
+      rk[k] = plain_rank ? (key[k] != 0xffffffffu ? atomicAdd(&cnt[key[k] >> fine_log], 1u) : 0u)
+                         : wave_bin_rank(cnt, key[k] >> fine_log, key[k] != 0xffffffffu, fan_log);
     __syncthreads();
     if (tid < 64) {  // one wave (four partitions per lane): exclusive prefix of the batch's counts, and the batch's room in every fine partition
       uint32_t v[4], sum = 0;
@@ -719,7 +820,7 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const uint32_t* __restrict__ a
       const uint32_t kk = s_key[sl], f = kk >> fine_log;
       const uint32_t dst = gb[f] + (sl - base[f]);
       b_entry[dst] = s_entry[sl];
-      b_bkt[dst] = kk & ((1u << fine_log) - 1u);
+      b_bkt[dst] = (K)(kk & ((1u << fine_log) - 1u));
     }
     __syncthreads();
   }
@@ -763,8 +864,9 @@ __device__ __forceinline__ bool big_slice(const uint32_t* fpart, uint32_t NP, co
   steps = per / 1024;
   return true;
 }
+template <class K>
 __global__ void __launch_bounds__(1024)
-k_big_hist(const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __restrict__ big_list,
+k_big_hist(const K* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __restrict__ big_list,
            uint32_t* __restrict__ bighist) {
   __shared__ uint32_t hist[FINE_NB];
   uint32_t pbase, lo, hi, steps;
@@ -777,7 +879,7 @@ k_big_hist(const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fp
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
       const uint32_t r = lo + (k0 + k) * 1024 + tid;
-      b[k] = (k0 + k < steps && r < hi) ? rec_bkt[pbase + r] : 0xffffffffu;
+      b[k] = (k0 + k < steps && r < hi) ? (uint32_t)rec_bkt[pbase + r] : 0xffffffffu;
     }
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++)
@@ -817,8 +919,9 @@ k_big_scan(const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __re
   }
   for (uint32_t ch = 0; ch < BIG_NCH; ch++) row[(size_t)ch * FINE_NB] += first;
 }
+template <class K>
 __global__ void __launch_bounds__(1024)
-k_big_scatter(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP,
+k_big_scatter(const uint32_t* __restrict__ rec_entry, const K* __restrict__ rec_bkt, const uint32_t* __restrict__ fpart, uint32_t NP,
               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ bighist, uint32_t* __restrict__ sorted) {
   __shared__ uint32_t cur[FINE_NB];
   uint32_t pbase, lo, hi, steps;
@@ -832,7 +935,7 @@ k_big_scatter(const uint32_t* __restrict__ rec_entry, const uint32_t* __restrict
     for (uint32_t k = 0; k < 4; k++) {
       const uint32_t r = lo + (k0 + k) * 1024 + tid;
       const bool in = k0 + k < steps && r < hi;
-      b[k] = in ? rec_bkt[pbase + r] : 0xffffffffu;
+      b[k] = in ? (uint32_t)rec_bkt[pbase + r] : 0xffffffffu;
       e[k] = in ? rec_entry[pbase + r] : 0u;
     }
 #pragma unroll
@@ -1307,16 +1410,26 @@ hipError_t msm_sort_enable_big_lds() {
     if (e != hipSuccess) return e;
   }
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_pass<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_pass<false, true, true, uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(uint32_t) * FINE_BIG_PARTS));
     if (e != hipSuccess) return e;
   }
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_split), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_write_staged<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(uint32_t) * 2 * 1024 * WSTAGE_MAXD));
+    if (e != hipSuccess) return e;
+  }
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_split<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(uint32_t) * 2 * SPLIT_B));
     if (e != hipSuccess) return e;
   }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(uint32_t) * FINE_STAGE));
+    if (e != hipSuccess) return e;
+  }
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_fpart_sort<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(sizeof(uint32_t) * FINE_STAGE));
 }
 
@@ -1434,26 +1547,33 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
     const int fan_log = nb_log - fine_log;
     hipError_t e = hipMemsetAsync(fpart + NPF, 0, sizeof(uint32_t) * NPF, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_part_pass<false, true, true>), dim3(nblk), dim3(1024), sizeof(uint32_t) * NPF, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
-                       nb_log, P, chunk, rc, blkcnt, sorted, rec_aux, plan.win_first, w_top_pos, fpart + NPF, fine_log);
+    // (bucket ids travel as 16-bit words through the three levels; rec_aux / rec_bkt are sized for 32-bit ones)
+    uint16_t* const key_a = reinterpret_cast<uint16_t*>(rec_aux);
+    uint16_t* const key_b = reinterpret_cast<uint16_t*>(rec_bkt);
+    hipLaunchKernelGGL((k_part_pass<false, true, true, uint16_t>), dim3(nblk), dim3(1024), sizeof(uint32_t) * NPF, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
+                       nb_log, P, chunk, rc, blkcnt, sorted, key_a, plan.win_first, w_top_pos, fpart + NPF, fine_log);
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
     hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NPF, fpart, (uint32_t*)nullptr, 0u, big_ws);
     hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF, big_ws);
-    hipLaunchKernelGGL((k_part_pass<true, true>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P, chunk, rc, blkcnt,
-                       sorted, rec_aux, plan.win_first, w_top_pos);
+    if (nwin <= WSTAGE_MAXD && ZK_TUNE("ZKMI_BIG_WSTAGE", 1) != 0)
+      hipLaunchKernelGGL(k_part_write_staged<uint16_t>, dim3(nblk), dim3(1024), sizeof(uint32_t) * 2 * 1024 * nwin, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
+                         nb_log, P, chunk, rc, (const uint32_t*)blkcnt, sorted, key_a, plan.win_first, w_top_pos);
+    else
+      hipLaunchKernelGGL((k_part_pass<true, true, false, uint16_t>), dim3(nblk), dim3(1024), 0, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb, nb_log, P,
+                         chunk, rc, blkcnt, sorted, key_a, plan.win_first, w_top_pos);
     // batches per group on average -> workgroups per group (at most 16: 3 328 workgroups at 13 windows)
     uint64_t per_group = ((uint64_t)nwin * n / P + SPLIT_B - 1) / SPLIT_B;
     const uint32_t nch2 = per_group > 16 ? 16u : (per_group ? (uint32_t)per_group : 1u);
-    hipLaunchKernelGGL(k_rec_split, dim3(nch2, P), dim3(1024), sizeof(uint32_t) * 2 * SPLIT_B, st, (const uint32_t*)sorted, (const uint32_t*)rec_aux,
-                       (const uint32_t*)part_total, fpart + 2 * NPF, rec_entry, rec_bkt, fan_log, fine_log);
+    hipLaunchKernelGGL(k_rec_split<uint16_t>, dim3(nch2, P), dim3(1024), sizeof(uint32_t) * 2 * SPLIT_B, st, (const uint32_t*)sorted, (const uint16_t*)key_a,
+                       (const uint32_t*)part_total, fpart + 2 * NPF, rec_entry, key_b, fan_log, fine_log, ZK_TUNE("ZKMI_SPLIT_PLAIN_RANK", 0));
     // (oversized partitions first: see k_fine_cursors; big_ws = the list, then BIG_MAX x BIG_NCH x 1024 chunk counters)
     uint32_t* const bighist = big_ws + 1 + BIG_MAX;
-    hipLaunchKernelGGL(k_big_hist, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NPF, (const uint32_t*)big_ws, bighist);
+    hipLaunchKernelGGL(k_big_hist<uint16_t>, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint16_t*)key_b, (const uint32_t*)fpart, NPF, (const uint32_t*)big_ws, bighist);
     hipLaunchKernelGGL(k_big_scan, dim3(BIG_MAX), dim3(1024), 0, st, (const uint32_t*)fpart, NPF, (const uint32_t*)big_ws, bighist, count, begin, fine_log);
-    hipLaunchKernelGGL(k_big_scatter, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint32_t*)rec_entry, (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NPF,
+    hipLaunchKernelGGL(k_big_scatter<uint16_t>, dim3(BIG_NCH, BIG_MAX), dim3(1024), 0, st, (const uint32_t*)rec_entry, (const uint16_t*)key_b, (const uint32_t*)fpart, NPF,
                        (const uint32_t*)big_ws, (const uint32_t*)bighist, sorted);
-    hipLaunchKernelGGL(k_fpart_sort, dim3(NPF), dim3(1024), sizeof(uint32_t) * FINE_STAGE, st, rec_entry, rec_bkt, fpart, NPF, count, begin, sorted, 1, fine_log,
-                       (const uint32_t*)(fpart + 3 * NPF));
+    hipLaunchKernelGGL(k_fpart_sort<uint16_t>, dim3(NPF), dim3(1024), sizeof(uint32_t) * FINE_STAGE, st, (const uint32_t*)rec_entry, (const uint16_t*)key_b,
+                       (const uint32_t*)fpart, NPF, count, begin, sorted, 1, fine_log, (const uint32_t*)(fpart + 3 * NPF));
     e = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e != hipSuccess) return e;
     if (prof) prof->end(PH_MSM_SORT, st);
@@ -1540,8 +1660,8 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     else
       hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                          rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
-    hipLaunchKernelGGL(k_fpart_sort, dim3(NP), dim3(1024), stage_on ? sizeof(uint32_t) * FINE_STAGE : 0, st, rec_entry, rec_bkt, fpart, NP,
-                       count, begin, sorted, stage_on ? 1 : 0, FINE_LOG);
+    hipLaunchKernelGGL(k_fpart_sort<uint32_t>, dim3(NP), dim3(1024), stage_on ? sizeof(uint32_t) * FINE_STAGE : 0, st, (const uint32_t*)rec_entry,
+                       (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NP, count, begin, sorted, stage_on ? 1 : 0, FINE_LOG, (const uint32_t*)nullptr);
     hipError_t e1 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e1 != hipSuccess) return e1;
     if (prof) prof->end(PH_MSM_SORT, st);
