@@ -249,6 +249,9 @@ k_part_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, int
   if (tid < PART_MAX) cursor[tid] = tid < P ? blkcnt[blockIdx.x * P + tid] : 0u;
   const uint32_t beg = blockIdx.x * chunk;
   const uint32_t end = (beg + chunk < n) ? beg + chunk : n;
+  // (the next batch's scalars are requested as soon as this batch's digits are extracted: the loads run under the staging and the write-out)
+  uint32_t nk[9];
+  if (beg + tid < end) load_biased(scalars, beg + tid, rc, nk);
   for (uint32_t i0 = beg; i0 < end; i0 += 1024) {
     if (tid < PART_MAX) bcnt[tid] = 0;
     __syncthreads();
@@ -256,7 +259,9 @@ k_part_write_staged(const uint32_t* __restrict__ scalars, uint32_t n, int c, int
     const bool in = i < end;
     uint32_t ent[WSTAGE_MAXD], key[WSTAGE_MAXD], rk[WSTAGE_MAXD];
     uint32_t k[9];
-    if (in) load_biased(scalars, i, rc, k);
+#pragma unroll
+    for (int j = 0; j < 9; j++) k[j] = nk[j];
+    if (i + 1024 < end) load_biased(scalars, i + 1024, rc, nk);
 #pragma unroll
     for (int w = 0; w < (int)WSTAGE_MAXD; w++) {
       key[w] = 0xffffffffu;
@@ -766,15 +771,25 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const K* __restrict__ a_bkt, c
   for (uint32_t j = 0; j < q; j++) pbase += part_total[j];
   const uint32_t ptot = part_total[q];
   constexpr uint32_t PER = SPLIT_B / 1024;
+  // (the next batch's records are requested as soon as this batch's sit in the stage: its loads run under the write-out)
+  uint32_t nkey[PER], nent[PER];
+  auto fetch = [&](uint32_t b0) {
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t r = b0 + k * 1024 + tid;
+      nkey[k] = r < ptot ? (uint32_t)a_bkt[pbase + r] : 0xffffffffu;
+      nent[k] = r < ptot ? a_entry[pbase + r] : 0u;
+    }
+  };
+  if (blockIdx.x * SPLIT_B < ptot) fetch(blockIdx.x * SPLIT_B);
   for (uint32_t b0 = blockIdx.x * SPLIT_B; b0 < ptot; b0 += gridDim.x * SPLIT_B) {
     if (tid < fan) cnt[tid] = 0;
     __syncthreads();
     uint32_t key[PER], ent[PER], rk[PER];
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
-      const uint32_t r = b0 + k * 1024 + tid;
-      key[k] = r < ptot ? (uint32_t)a_bkt[pbase + r] : 0xffffffffu;
-      ent[k] = r < ptot ? a_entry[pbase + r] : 0u;
+      key[k] = nkey[k];
+      ent[k] = nent[k];
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++)
@@ -814,6 +829,7 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const K* __restrict__ a_bkt, c
         s_entry[slot] = ent[k];
         s_key[slot] = key[k];
       }
+    if (b0 + gridDim.x * SPLIT_B < ptot) fetch(b0 + gridDim.x * SPLIT_B);
     __syncthreads();
     const uint32_t total = ptot - b0 < SPLIT_B ? ptot - b0 : SPLIT_B;
     for (uint32_t sl = tid; sl < total; sl += 1024) {
