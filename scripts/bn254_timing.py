@@ -8,7 +8,7 @@ import torch
 from zkmi_loader import load_pkg
 
 pkg = load_pkg()
-z = pkg.Zkmi()
+z = pkg.Zkmi(__import__("os").environ.get("ZKMI_LIB"))
 ctx = z.context(0)
 ctx.prof_enable(True)
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -323,6 +323,34 @@ def _closed_form_g1(tot, wtot):
     return ec.g1_to_bytes(ec.pt_add(ec.Fq, ec.g1_mul(tot), ec.g1_mul(wtot, q)))
 
 
+@pytest.mark.gpu
+def test_msm_g1_two_level_sort_of_16_bit_windows(ctx):
+    """16-bit windows from 2^21 terms on are sorted like the big plans (msm_sort.hip run_windowed_big with one group per
+    window: records -> fine partitions -> one workgroup per partition, oversized partitions by 64 workgroups).  An odd
+    size just above 2^21, uniform scalars and the witness-like mix (a fifth of the scalars equal to one: 420 000 records
+    in one bucket -- the k_big_* kernels), each against the closed form over the synthetic bases."""
+    import torch
+
+    n = (1 << 21) + 4097
+    raw, tot, wtot = _torch_scalars(n, 2121)
+    b = ctx.bases_g1_synthetic(n)
+    assert ctx.msm_g1_dev(raw.data_ptr(), n, b) == _closed_form_g1(tot, wtot)
+    g = torch.Generator(device="cuda").manual_seed(2122)
+    kind = torch.rand(n, device="cuda", generator=g)
+    raw[kind < 0.6] = 0
+    raw[(kind >= 0.4) & (kind < 0.6), 0] = 1
+    idx = torch.arange(n, dtype=torch.int64, device="cuda")
+    s0 = raw.to(torch.int64).sum(dim=0).cpu().tolist()
+    s1 = (raw.to(torch.int64) * idx[:, None]).sum(dim=0).cpu().tolist()
+    tot = sum(v << (8 * k) for k, v in enumerate(s0)) % R
+    wtot = sum(v << (8 * k) for k, v in enumerate(s1)) % R
+    torch.cuda.synchronize()
+    assert ctx.msm_g1_dev(raw.data_ptr(), n, b) == _closed_form_g1(tot, wtot)
+    b.free()
+    del raw, kind, idx
+    torch.cuda.empty_cache()
+
+
 def test_msm_g1_point_split_matches_full(ctx, zk):
     """BASELINE config 3 logic on one GPU: two point-slices -> per-window partials ->
     zkmi_msm_g1_combine == the unsplit MSM == the closed form."""
@@ -1288,7 +1316,7 @@ def test_c_example_proves_and_verifies(tmp_path):
 def test_c_bench_under_the_native_runtime_matches_the_python_path(ctx, zk, tmp_path):
     """examples/bench_prove.c in a fresh process WITHOUT Python or PyTorch: libzkmi.so bound to the /opt/rocm runtime it
     was built for (every other GPU test runs on the PyTorch wheel's bundled HIP runtime, which the binding preloads).
-    Short form of profiles/r04's run: 6 + 1 proofs at 2^14 from device-generated assignments, every proof verified by
+    Short form of profiles/r05's run: 6 + 1 proofs at 2^14 from device-generated assignments, every proof verified by
     pairing inside the program, 80 churn operations (setups 2^13..2^17, forced group sizes, batches, single and
     host-witness proofs, error path, MSMs, NTTs, second contexts); the dumped proof bytes must equal this process's
     proofs from the same seeds."""

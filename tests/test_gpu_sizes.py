@@ -72,7 +72,7 @@ def test_msm_g1_2p20_vs_cpp_oracle(ctx, zk, kind):
     want = ocpp.msm_g1(sc, b.read(0, n))
     assert ctx.msm_g1(sc, b) == want
     # the same terms as ONE slice under the plan of a 2^24-term MSM (20-bit windows, the two-level sort of the big plans): the
-    # witness-like mix puts 210 000 records into one fine partition there too -- the oversized-partition kernels (k_big_*)
+    # witness-like mix puts 210 000 records into one fine partition there -- the oversized-partition kernels (k_big_*)
     import torch
 
     d = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()

@@ -1244,10 +1244,11 @@ MsmPlan msm_make_plan_shared_batch(uint64_t n, uint32_t batch) {
 // windowed plans with more than 2^15 buckets per window: partitions per window and in total (run_windowed_big)
 static inline uint32_t big_parts_per_window(const MsmPlan& p) { return p.nb >> 15; }
 static inline bool plan_is_big(const MsmPlan& p) { return !p.shared && p.c > 16; }
-// 16-bit windows (2^15 buckets = one group per window) from 2^19 terms on take the same two-level record sort as the big plans
-// (A/B library: ZKMI_WIN_TWO_LEVEL = smallest log2(n) that does, 30 = never)
+// 16-bit windows (2^15 buckets = one group per window) from 2^21 terms on take the same two-level record sort as the big plans
+// (2^21: 0.87 -> 0.69 ms, 2^23: 4.1 -> 2.0; below that its fourteen short launches cost what they save -- 2^20: 0.45 ms either
+// way over BLS12-381 scalars, 0.62 against 0.52 over BN254 ones.  A/B library: ZKMI_WIN_TWO_LEVEL = smallest log2(n), 30 = never)
 static inline bool plan_two_level(const MsmPlan& p, uint64_t n) {
-  return !p.shared && p.c == 16 && n >= (1ull << ZK_TUNE("ZKMI_WIN_TWO_LEVEL", 19)) && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0;
+  return !p.shared && p.c == 16 && n >= (1ull << ZK_TUNE("ZKMI_WIN_TWO_LEVEL", 21)) && ZK_TUNE("ZKMI_BIG_SORT", 1) != 0;
 }
 
 static const uint64_t PLAN_STEPS[] = {1u << 8, 1u << 11, 1u << 14, 1u << 17, ~0ull};
