@@ -1113,7 +1113,7 @@ k_accum_heavy(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ 
 // for the pair instead of two each, and one tree sum / host combine instead of two -- and nothing else of the two MSMs
 // knows about the other: both accumulate into their own arrays with the ordinary kernels.
 template <class F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_segreduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ segsum, XYZZ<F>* __restrict__ segw,
             uint32_t total_segs, int seg, const XYZZ<F>* __restrict__ buckets2, const XYZZ<F>* __restrict__ buckets3) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1162,6 +1162,9 @@ static void plan_set_heavy(MsmPlan& p, uint64_t items) {
   // small proof's: nothing else fills the chip while its reduction runs -- 32 dependent additions per 16-bucket segment
   // (0.52 ms at 2^20 terms) and 23 per tree-sum job (0.36 ms).  8-bucket segments and sliced job lists: 16 + 13.
   if (!p.shared && buckets <= (1u << 19) && p.seg_log > 3) p.seg_log = 3;
+  // the partitioned big windows (13 x 2^19 buckets): 64-bucket segments -- the chains stay hidden behind 6 600 waves of them and
+  // the tree sums walk a quarter of the segments (reduction of a 2^26-term MSM 5.66 -> 5.0 ms)
+  if (!p.shared && p.c > 16) p.seg_log = 6;
   {
     const int seg_env = ZK_TUNE("ZKMI_SEG_LOG", 0);  // A/B library: segment length of big plans
     // (the segment arrays hold max(buckets / 16, 2^16) entries: msm_impl.hpp msm_max_segments)
