@@ -349,14 +349,15 @@ def _xyzz_host_bytes(pt, lam):
 @pytest.mark.parametrize("n_ranks", [1, 2, 8])
 def test_exchange_combine_at_the_real_slot_layout(zk, n_ranks):
     """What every rank computes behind ncclAllGather (csrc/comm.hip), at the slot geometry of BASELINE config 3 -- the plan of
-    2^26 terms: 13 windows of 20 bits, 16 partial sums per window, the partial top window spread over 16 partitions --
+    2^26 terms: 13 windows of 20 bits, 14 partial sums per window, the partial top window spread over 16 partitions --
     with up to 8 synthetic ranks, in both partitions (points / windows).  The slots hold known multiples of the
     generator in non-trivial XYZZ form (and some points at infinity); the expected scalar follows from the reduction's
     definition: window = job_0 + 2^seg_log * sum_j 2^j job_(1+j), the top window without its top_spread_log top bits."""
     plan_n = 1 << 26
     lay = zk.msm_exchange_layout(plan_n, n_ranks)
-    assert (lay["nwin"], lay["per_window"], lay["c"], lay["seg_log"], lay["top_spread_log"]) == (13, 16, 20, 4, 4)
-    assert lay["slot_pts_points"] == 13 * 16 and lay["point_bytes"] == 192
+    # (64-bucket segments since round 5: 2^19 / 64 = 2^13 segments per window -> 1 + 13 partial sums)
+    assert (lay["nwin"], lay["per_window"], lay["c"], lay["seg_log"], lay["top_spread_log"]) == (13, 14, 20, 6, 4)
+    assert lay["slot_pts_points"] == 13 * 14 and lay["point_bytes"] == 192
     nwin, per, c, seg_log = lay["nwin"], lay["per_window"], lay["c"], lay["seg_log"]
     rng = ec.SplitMix64(0x5A4B0003 + n_ranks)
     small = lambda: rng.fr() & ((1 << 48) - 1)
