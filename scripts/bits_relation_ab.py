@@ -19,7 +19,7 @@ R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 18
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-    z = bench.load_pkg().Zkmi()
+    z = bench.load_pkg().Zkmi(os.environ.get("ZKMI_LIB"))
     ctx = z.context(0)
     one = (1).to_bytes(32, "little")
     n_pub = 2

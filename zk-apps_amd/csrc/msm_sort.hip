@@ -852,14 +852,14 @@ k_rec_split(const uint32_t* __restrict__ a_entry, const K* __restrict__ a_bkt, c
 constexpr uint32_t BIG_THR = 131072, BIG_MAX = 32, BIG_NCH = 64;
 // fpart[2 NP + q] = fpart[q]: the cursors k_rec_split advances; fpart[3 NP + q] = 1 + list index of an oversized partition, or 0
 __global__ void __launch_bounds__(256)
-k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP, uint32_t* __restrict__ big_list) {
+k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP, uint32_t* __restrict__ big_list, uint32_t max_big) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= NP) return;
   fpart[2 * NP + q] = fpart[q];
   uint32_t flag = 0;
   if (fpart[NP + q] > BIG_THR) {
     const uint32_t j = atomicAdd(&big_list[0], 1u);
-    if (j < BIG_MAX) {
+    if (j < max_big) {  // (= the y extent of the k_big_* grids: at most BIG_MAX)
       big_list[1 + j] = q;
       flag = 1 + j;
     }
@@ -869,7 +869,7 @@ k_fine_cursors(uint32_t* __restrict__ fpart, uint32_t NP, uint32_t* __restrict__
 // chunk ch of listed partition j: records [lo, hi) of the partition (whole waves walk them: the aggregated counters need every lane)
 __device__ __forceinline__ bool big_slice(const uint32_t* fpart, uint32_t NP, const uint32_t* big_list, uint32_t& pbase, uint32_t& lo,
                                           uint32_t& hi, uint32_t& steps) {
-  const uint32_t j = blockIdx.y, nbig = big_list[0] < BIG_MAX ? big_list[0] : BIG_MAX;
+  const uint32_t j = blockIdx.y, nbig = big_list[0] < gridDim.y ? big_list[0] : gridDim.y;
   if (j >= nbig) return false;
   const uint32_t q = big_list[1 + j];
   pbase = fpart[q];
@@ -909,7 +909,7 @@ __global__ void __launch_bounds__(1024)
 k_big_scan(const uint32_t* __restrict__ fpart, uint32_t NP, const uint32_t* __restrict__ big_list, uint32_t* __restrict__ bighist,
            uint32_t* __restrict__ count, uint32_t* __restrict__ begin, int fine_log) {
   __shared__ uint32_t part[1024];
-  const uint32_t j = blockIdx.x, nbig = big_list[0] < BIG_MAX ? big_list[0] : BIG_MAX, tid = threadIdx.x;
+  const uint32_t j = blockIdx.x, nbig = big_list[0] < gridDim.x ? big_list[0] : gridDim.x, tid = threadIdx.x;
   if (j >= nbig) return;
   const uint32_t q = big_list[1 + j], pbase = fpart[q];
   uint32_t* const row = bighist + (size_t)j * BIG_NCH * FINE_NB + tid;
@@ -1574,7 +1574,7 @@ hipError_t MsmSort::run_windowed_big(const uint32_t* d_scalars, uint64_t n, hipS
                        nb_log, P, chunk, rc, blkcnt, sorted, key_a, plan.win_first, w_top_pos, fpart + NPF, fine_log);
     hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(PART_MAX), 0, st, blkcnt, nblk, P, part_total);
     hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NPF, fpart, (uint32_t*)nullptr, 0u, big_ws);
-    hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF, big_ws);
+    hipLaunchKernelGGL(k_fine_cursors, dim3((NPF + 255) / 256), dim3(256), 0, st, fpart, NPF, big_ws, BIG_MAX);
     if (nwin <= WSTAGE_MAXD && ZK_TUNE("ZKMI_BIG_WSTAGE", 1) != 0)
       hipLaunchKernelGGL(k_part_write_staged<uint16_t>, dim3(nblk), dim3(1024), sizeof(uint32_t) * 2 * 1024 * nwin, st, d_scalars, (uint32_t)n, plan.c, (int)nwin, nb,
                          nb_log, P, chunk, rc, (const uint32_t*)blkcnt, sorted, key_a, plan.win_first, w_top_pos);
@@ -1668,7 +1668,13 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     hipLaunchKernelGGL(k_fpart_pass<false>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                        rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
     hipLaunchKernelGGL(k_fpart_scan_rows, dim3(NP), dim3(64), 0, st, blkcnt, nblk, NP, fpart);
-    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart, part_total, P);
+    // Oversized fine partitions (a witness of bits: 630 000 records in one bucket) stay with the round form of k_fpart_sort HERE:
+    // the k_big_* kernels (A/B library: ZKMI_SORT_BIG=1, a grid of BIG_PROVER x 64 workgroups) are four more launches per sort in
+    // the proof pipeline, where an empty launch still has to be placed -- measured 57.3 / 57.6 against 57.9 / 58.0 proofs/s at 2^20
+    // for 174 / 167 against 163 / 166 on the bits relation (profiles/r05/experiments/prover_sort_big_partitions_ab.txt).
+    constexpr uint32_t BIG_PROVER = 4;
+    const bool big_on = big_ws != nullptr && ZK_TUNE("ZKMI_SORT_BIG", 0) != 0;
+    hipLaunchKernelGGL(k_fpart_scan_base, dim3(1), dim3(1024), 0, st, NP, fpart, part_total, P, big_on ? big_ws : (uint32_t*)nullptr);
     const bool stage_on = ZK_TUNE("ZKMI_SORT_STAGE", 1) != 0;
     const size_t stage_bytes = sizeof(uint32_t) * 2 * 1024 * (size_t)plan.ndigits;
     if (stage_on && NP <= 512 && plan.ndigits <= (int)FPASS_MAXD)
@@ -1680,8 +1686,18 @@ hipError_t MsmSort::run_shared(const uint32_t* d_scalars, uint64_t n, hipStream_
     else
       hipLaunchKernelGGL(k_fpart_pass<true>, dim3(nblk), dim3(1024), lds_np, st, d_scalars, (uint32_t)n, plan.c, plan.ndigits, NP, chunk_a,
                          rc, blkcnt, (const uint32_t*)fpart, rec_entry, rec_bkt);
+    if (big_on) {
+      uint32_t* const bighist = big_ws + 1 + BIG_MAX;
+      hipLaunchKernelGGL(k_fine_cursors, dim3((NP + 255) / 256), dim3(256), 0, st, fpart, NP, big_ws, BIG_PROVER);
+      hipLaunchKernelGGL(k_big_hist<uint32_t>, dim3(BIG_NCH, BIG_PROVER), dim3(1024), 0, st, (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NP, (const uint32_t*)big_ws,
+                         bighist);
+      hipLaunchKernelGGL(k_big_scan, dim3(BIG_PROVER), dim3(1024), 0, st, (const uint32_t*)fpart, NP, (const uint32_t*)big_ws, bighist, count, begin, FINE_LOG);
+      hipLaunchKernelGGL(k_big_scatter<uint32_t>, dim3(BIG_NCH, BIG_PROVER), dim3(1024), 0, st, (const uint32_t*)rec_entry, (const uint32_t*)rec_bkt, (const uint32_t*)fpart,
+                         NP, (const uint32_t*)big_ws, (const uint32_t*)bighist, sorted);
+    }
     hipLaunchKernelGGL(k_fpart_sort<uint32_t>, dim3(NP), dim3(1024), stage_on ? sizeof(uint32_t) * FINE_STAGE : 0, st, (const uint32_t*)rec_entry,
-                       (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NP, count, begin, sorted, stage_on ? 1 : 0, FINE_LOG, (const uint32_t*)nullptr);
+                       (const uint32_t*)rec_bkt, (const uint32_t*)fpart, NP, count, begin, sorted, stage_on ? 1 : 0, FINE_LOG,
+                       big_on ? (const uint32_t*)(fpart + 3 * NP) : (const uint32_t*)nullptr);
     hipError_t e1 = bucket_order(count, perm, heavy, order_bins, tot_b, plan.heavy_thr, plan.heavy_shift, st);
     if (e1 != hipSuccess) return e1;
     if (prof) prof->end(PH_MSM_SORT, st);
