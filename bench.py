@@ -560,7 +560,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 20 (proofs) / 3 (msm26)")
+    ap.add_argument("--steps", type=int, default=None, help="default 48 (proofs: a timed region of ~0.85 s; the ring of three proofs fills and drains once per run) / 3 (msm26)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["proofs", "msm26"], default="proofs",
                     help="proofs = BASELINE configs[1]/[2] (headline); msm26 = configs[3], one 2^26-point G1 MSM split over the ranks")
@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--msm-pmc-summary", default="profiles/r05/pmc_summary_msm26_steps1.json")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.workload == "proofs" else 3
+        args.steps = 48 if args.workload == "proofs" else 3
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
