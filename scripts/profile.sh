@@ -12,7 +12,7 @@ set -u
 ROUND=${1:-r05}
 OUT=gpurun_out/prof_$ROUND
 DST=profiles/$ROUND
-STEPS_TRACE=${STEPS_TRACE:-24}
+STEPS_TRACE=${STEPS_TRACE:-48}
 STEPS_PMC=${STEPS_PMC:-3}
 mkdir -p "$OUT" "$DST"
 export TMPDIR=/tmp
