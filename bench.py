@@ -102,12 +102,17 @@ def resident_witnesses(z, ctx, relation, log_n, seeds):
     return r1, bufs
 
 
-def source_revision():
+def source_revision(z=None):
     """What was measured: the last commit that touched the kernels / C ABI ('+dirty' when the tree differs from it) where
     a git checkout is present, and always a digest of those sources themselves (the GPU box receives a snapshot without
     .git) -- the same digest scripts/pmc_summary.py stamps into the PMC summary, so a profile that is older than the
     library shows."""
     out = {"git": None, "csrc_sha256_16": csrc_digest()}
+    if z is not None:
+        # the digest compiled INTO the library that ran (zkmi_version()) against the files on this box: a stale .so beside
+        # fresh sources reads false here
+        out["library_src_sha256_16"] = z.src_digest()
+        out["library_matches_sources"] = out["library_src_sha256_16"] == out["csrc_sha256_16"]
     try:
         h = subprocess.run(["git", "log", "-1", "--format=%h", "--", "zk-apps_amd/csrc", "include"], cwd=ROOT, capture_output=True,
                            text=True, timeout=10).stdout.strip()
@@ -120,16 +125,14 @@ def source_revision():
 
 
 def csrc_digest():
-    """sha256 (16 hex digits) over the kernel / C-ABI sources, file names included, in sorted order"""
-    h = hashlib.sha256()
-    for d in ("zk-apps_amd/csrc", "include"):
-        base = os.path.join(ROOT, d)
-        for name in sorted(os.listdir(base)):
-            path = os.path.join(base, name)
-            if os.path.isfile(path) and name.endswith((".hip", ".hpp", ".h", "Makefile")):
-                h.update(name.encode() + b"\0")
-                h.update(open(path, "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 (16 hex digits) over the kernel / C-ABI sources (scripts/src_digest.py: the one definition, also compiled
+    into the library by the Makefile and returned by zkmi_version())"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import src_digest
+    finally:
+        sys.path.pop(0)
+    return src_digest.csrc_digest(ROOT)
 
 
 def cpu_kernel_twins(z, ctx, log_n):
@@ -534,7 +537,10 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
         "frac_of_hbm_peak": 128.0 * n / sec / 1e9 / (HBM_PEAK_GBS * world),
         "phase_ms_per_msm": {k: v[0] / args.steps for k, v in phases.items()},
         "roofline": {"kernel": "k_accum_g1_nc (rank 0's share: %d points)" % m, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     # HIP-event time of the accumulation phase per MSM (one launch in the product; the A/B library's pipelined
+                     # form brackets two launches per MSM: `launches_per_msm`)
+                     "avg_ms_per_msm": avg_ms, "launches": launches,
                      "launches_per_msm": launches / max(1, args.steps),
                      "algorithmic_bytes_per_launch": 128 * m,
                      "limiter": "VALU integer issue (384-bit Montgomery products), see DESIGN.md 4.1"},
@@ -550,7 +556,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
             rate = pmc_traffic.valu / (avg_ms * 1e-3)
             out["roofline_valu"] = {"kernel": pmc_traffic.name, "bound": "valu", "achieved": rate / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
                                     "unit": "G wave-instr/s", "frac": rate / VALU_ISSUE_PEAK, "wave_insts_per_launch": pmc_traffic.valu}
-    out["source_revision"] = source_revision()
+    out["source_revision"] = source_revision(z)
     bases.free()
     if not ok:
         print("bench.py: MSM result differs from the closed form", file=sys.stderr)
@@ -741,7 +747,7 @@ def main():
         "phase_ms_per_proof": {k: v[0] / args.steps for k, v in phases.items()},
         "roofline": roofline,
         "hip_versions": dict(zip(("build", "runtime"), z.hip_versions())),
-        "source_revision": source_revision(),
+        "source_revision": source_revision(z),
         # the host side (rank 0): CPUs the process is granted / ranks on the node / threads its assembly pool uses
         # (csrc/host_pool.hpp), CPU seconds per proof inside the timed region and the CPUs that keeps busy
         "host": dict(z.host_info(), host_cpu_s_per_proof=timed_region.cpu_s / max(1, args.steps),

@@ -53,7 +53,18 @@ typedef struct zkmi_r1cs zkmi_r1cs;
 typedef struct zkmi_pk zkmi_pk;
 
 /* ---- library / context -------------------------------------------------- */
+/* "zkmi 0.1 (gfx950) src:<16 hex digits>": the digits are the sha256 digest of the sources the binary was built from
+ * (scripts/src_digest.py; bench.py and smoke() compare it with the files beside the library: `library_matches_sources`). */
 const char* zkmi_version(void);
+/* Where the host-side numbers of zkmi_host_info came from, e.g. "cpus=16 (cgroup2 /sys/fs/cgroup/cpu.max) ranks=8
+ * (LOCAL_WORLD_SIZE) threads=2": the CPU grant is min(logical CPUs, affinity mask, the smallest cgroup quota between the
+ * process's own cgroup and the root); the ranks sharing it come from LOCAL_WORLD_SIZE (torchrun), OMPI_COMM_WORLD_LOCAL_SIZE,
+ * SLURM_NTASKS_PER_NODE or MPI_LOCALNRANKS. */
+const char* zkmi_host_info_string(void);
+/* Fingerprint of the library's internal struct layouts (sizes and member offsets of the context, the MSM workspaces and the
+ * handle types): two builds of this source tree may only share objects (a context made by one, bases made by the other --
+ * what the test suite does with the testing library) when their fingerprints are equal.  out_n = values written / needed. */
+int32_t zkmi_abi_layout_probe(uint64_t* out, uint32_t cap, uint32_t* out_n);
 /* HIP_VERSION the library was built with / hipRuntimeGetVersion of the runtime it is bound to (diagnostics) */
 int32_t zkmi_hip_versions(int32_t* out_build, int32_t* out_runtime);
 /* The prover's host side: proof assembly (row a10: O(1) scalar multiplications, compression) runs on one persistent pool
@@ -164,11 +175,21 @@ int32_t zkmi_msm_g1_window_range_dev(zkmi_ctx* ctx, const void* d_scalars, uint6
                                      uint32_t* out_nwin_total, uint32_t* out_window_bits);
 int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n,
                                            const zkmi_bases_g1* bases, uint8_t out_affine[96]);
+/* The 2-D split: n_ranks = P x window_groups; rank k = g * window_groups + q holds the points of group g (d_scalars / bases
+ * are its slice of n points, as in the point split; plan_n = the size of the whole MSM) and computes only the windows of
+ * range q of window_groups (range q: windows [q nwin / Q, (q + 1) nwin / Q)).  Per rank: 1 / n_ranks of the bucket
+ * insertions like both 1-D splits, 1 / P of the points resident, 1 / Q of the buckets to reduce -- the share of a rank's
+ * time that the point split leaves unscaled.  window_groups = 1 is the point split, = n_ranks the window split (over a
+ * slice that is then the whole input).  window_groups must divide the communicator's size (else ZKMI_ERR_BAD_ARG, before
+ * anything is launched).  The full result on every rank. */
+int32_t zkmi_msm_g1_split2d_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                      uint64_t plan_n, uint32_t window_groups, uint8_t out_affine[96]);
 
 /* What every rank computes AFTER the all-gather, on caller-supplied slots (host arithmetic; no GPU, no RCCL): partials =
  * n_ranks slots of XYZZ points in the form the reductions leave in HBM (4 x 48-byte LE Montgomery coordinates x, y, zz, zzz;
  * all-zero zz = infinity).  window_split = 0: rank k's slot holds the partial sums of ALL windows over its points (the
- * point split); 1: the partial sums of its windows [k nwin / R, (k + 1) nwin / R).  zkmi_msm_exchange_layout reports the
+ * point split); 1: the partial sums of its windows [k nwin / R, (k + 1) nwin / R); Q >= 2 (Q divides n_ranks): the 2-D split
+ * with Q window ranges -- rank k's slot holds the partial sums of window range k mod Q over its point group's points.  zkmi_msm_exchange_layout reports the
  * slot geometry for a plan of plan_n terms: out[0] windows, [1] partial sums per window, [2] points per slot (point
  * split), [3] points per slot (window split over n_ranks), [4] bytes per point, [5] window bits, [6] log2 of the
  * reduction's segment length, [7] log2 of the partitions the partial top window is spread over. */

@@ -40,6 +40,10 @@ int32_t zkmi_selftest_fq28(uint64_t seed, uint32_t iters, uint32_t* out_mismatch
 int32_t zkmi_selftest_assembly(uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
 int32_t zkmi_selftest_host_pool(uint32_t callers, uint32_t jobs, uint32_t* out_mismatches);
 int32_t zkmi_selftest_poseidon(int32_t field, uint64_t seed, uint32_t iters, uint32_t* out_mismatches);
+/* Device self-test of the quad-split complete addition (csrc/quad.hpp: one coordinate of an XYZZ point per lane of a quad)
+ * against curve.hpp's one-lane addition on the device and the 32-bit-limb host arithmetic: n pairs with every special case
+ * (o = a, o = -a, either at infinity, equal points in different representations), and 16-point sums over the quads of a wave. */
+int32_t zkmi_selftest_quad_add(zkmi_ctx* ctx, uint64_t seed, uint32_t n, uint32_t* out_mismatches);
 /* Test hook for the bucket set two MSMs share (the prover's L and H queries): sum_i a_i P_i + sum_i b_i P_i
  * with the first MSM's accumulation left unreduced and the second one's reduction taking both bucket arrays (prepared
  * bases run the shared-bucket schedule, others the windowed one).  Scalars in HBM. */

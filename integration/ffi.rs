@@ -155,6 +155,8 @@ extern "C" {
                                         w_first: u32, w_count: u32, out_windows_affine: *mut u8, out_nwin_total: *mut u32, out_window_bits: *mut u32) -> i32;
     pub fn zkmi_msm_g1_window_split_allgather(ctx: *mut zkmi_ctx, comm: *mut zkmi_comm, d_scalars: *const core::ffi::c_void, n: u64,
                                               bases: *const zkmi_bases_g1, out_affine: *mut u8) -> i32;
+    pub fn zkmi_msm_g1_split2d_allgather(ctx: *mut zkmi_ctx, comm: *mut zkmi_comm, d_scalars: *const core::ffi::c_void, n: u64,
+                                         bases: *const zkmi_bases_g1, plan_n: u64, window_groups: u32, out_affine: *mut u8) -> i32;
     pub fn zkmi_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn zkmi_comm_init(ctx: *mut zkmi_ctx, n_ranks: u32, rank: u32, id: *const u8, out: *mut *mut zkmi_comm) -> i32;
     pub fn zkmi_comm_from_nccl(ctx: *mut zkmi_ctx, nccl_comm: *mut core::ffi::c_void, n_ranks: u32, rank: u32, out: *mut *mut zkmi_comm) -> i32;

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--proofs", type=int, default=64)
     ap.add_argument("--msm-log-n", type=int, default=26)
+    ap.add_argument("--window-groups", type=int, default=0,
+                    help="config 3 also as a 2-D split: ranks = point groups x this many window ranges (0 = 2 where the world size is even)")
     ap.add_argument("--one-gpu", action="store_true", help="TEST MODE: all ranks share GPU 0 (gloo + tests/fake_rccl), see the docstring")
     args = ap.parse_args()
 
@@ -181,6 +183,43 @@ def main():
             dist.all_reduce(okw, op=dist.ReduceOp.MIN)
             bases_all.free()
             del raw_all
+        # the 2-D split (zkmi_msm_g1_split2d_allgather): world = P point groups x Q window ranges; rank g Q + q holds point
+        # group g's slice -- generated here from the same per-rank seeds as the 1-D slices it is made of -- and reduces only
+        # the windows of range q
+        ok2 = None
+        Q = args.window_groups or (2 if world % 2 == 0 else 1)
+        if world % Q == 0 and Q > 1:
+            P = world // Q
+            gidx, qidx = rank // Q, rank % Q
+            ga, gb = par.shard_units(n, gidx, P)
+            parts = []
+            for k in range(world):  # the 1-D slices [a_k, b_k) that overlap this group's points, same generators as above
+                ak, bk = par.shard_units(n, k, world)
+                lo_, hi_ = max(ak, ga), min(bk, gb)
+                if lo_ >= hi_:
+                    continue
+                gk = torch.Generator(device="cuda").manual_seed(1000 + k)
+                t = torch.randint(0, 256, (bk - ak, 32), dtype=torch.uint8, device="cuda", generator=gk)
+                t[:, 31] &= 0x3F
+                parts.append(t[lo_ - ak : hi_ - ak])
+            raw_g = torch.cat(parts).contiguous()
+            bases_g = ctx.bases_g1_synthetic_range(ga, gb - ga)
+            ctx.msm_g1_split2d_allgather(comm, raw_g.data_ptr(), gb - ga, bases_g, n, Q)  # untimed
+            barrier()
+            t0 = time.perf_counter()
+            got_2d = ctx.msm_g1_split2d_allgather(comm, raw_g.data_ptr(), gb - ga, bases_g, n, Q)
+            barrier()
+            dt2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ddev)
+            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+            ok2 = torch.tensor([1 if got_2d == want else 0], dtype=torch.int32, device=ddev)
+            dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+            bases_g.free()
+            del raw_g, parts
+            if rank == 0:
+                print(json.dumps({"config": 3, "workload": "the same MSM as a 2-D split: %d point groups x %d window ranges (zkmi_msm_g1_split2d_allgather)" % (P, Q),
+                                  "matches_closed_form_on_every_rank": bool(ok2.item()), "seconds": float(dt2.item()),
+                                  "algorithmic_GBps": 128.0 * n / float(dt2.item()) / 1e9, **gpus}), flush=True)
+            assert ok2.item() == 1
         comm.free()
         if rank == 0 and okw is not None:
             print(json.dumps({"config": 3, "workload": "the same MSM with its WINDOWS split over the ranks (zkmi_msm_g1_window_split_allgather)",

@@ -1,8 +1,10 @@
 """CPU suite, part 2: the product's host logic through the C ABI (no compute
 kernels are launched; the library must load and export every declared symbol
 without a GPU)."""
+import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -391,6 +393,29 @@ def test_exchange_combine_at_the_real_slot_layout(zk, n_ranks):
         slots += mine
     got = zk.msm_g1_combine_partials(b"".join(slots), n_ranks, plan_n, window_split=True)
     assert got == ec.g1_to_bytes(ec.g1_mul(total % ec.R))
+    # --- 2-D split (round 6): rank k = g Q + q holds window range q of Q over point group g; a window's value is the sum
+    # over the point groups.  Every Q that divides the rank count (Q = 1 is the point split's arithmetic in window-range
+    # slots, Q = n_ranks the window split's).
+    for Q in [q for q in (2, 4, 8) if n_ranks % q == 0 and q <= n_ranks]:
+        firstq = lambda q: q * nwin // Q
+        max_wq = max(firstq(q + 1) - firstq(q) for q in range(Q))
+        assert zk.msm_exchange_layout(plan_n, Q)["slot_pts_windows"] == per * max_wq
+        total, slots = 0, []
+        for k in range(n_ranks):
+            q = k % Q
+            mine = []
+            for w in range(firstq(q), firstq(q + 1)):
+                jobs = [small() if (k + w + j) % 6 else 0 for j in range(per)]
+                total += window_value(w, jobs) << (c * w)
+                mine += [_xyzz_host_bytes(ec.g1_mul(v) if v else None, 2 + rng.fr() % ec.P) for v in jobs]
+            mine += [_xyzz_host_bytes(ec.g1_mul(54321), 1)] * (per * max_wq - len(mine))
+            slots += mine
+        got = zk.msm_g1_combine_partials(b"".join(slots), n_ranks, plan_n, window_split=Q)
+        assert got == ec.g1_to_bytes(ec.g1_mul(total % ec.R)), Q
+    # a window-range count that does not divide the ranks is refused
+    if n_ranks == 8:
+        with pytest.raises(Exception):
+            zk.msm_g1_combine_partials(bytes(192 * per * 13 * 8), 8, plan_n, window_split=3)
 
 
 def test_rccl_not_found_is_an_error_code_not_a_crash(tmp_path):
@@ -413,6 +438,16 @@ def test_rccl_not_found_is_an_error_code_not_a_crash(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "code -9" in out.stdout and "plan 16" in out.stdout, out.stdout
+    # the product does not dlopen whatever the environment names: a relative path, and a world-writable
+    # file, are refused with the same error code -- and never fall back to another RCCL
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    loose = tmp_path / "libloose.so"
+    loose.write_bytes(open(fake, "rb").read() if os.path.exists(fake) else b"\x7fELF")
+    os.chmod(loose, 0o777)
+    for bad in ("tests/fake_rccl/libfake_rccl.so", str(loose)):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, ZKMI_RCCL_LIB=bad, ZKMI_DEBUG="1"), capture_output=True,
+                             text=True, timeout=120, cwd=ROOT)
+        assert out.returncode == 0 and "code -9" in out.stdout and "ZKMI_RCCL_LIB refused" in out.stderr, (bad, out.stdout, out.stderr)
 
 
 # ------------------------------------------------ mocked_zk mirror (row a12)
@@ -920,3 +955,61 @@ def test_c_example_builds_against_the_header_and_fails_loudly_without_gpu(tmp_pa
         pytest.skip("GPU present: covered by the GPU test")
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 2 and "no CPU fallback" in p.stderr
+
+
+def test_library_carries_the_digest_of_its_sources(zk):
+    """zkmi_version() returns the digest of the sources the binary was BUILT from (Makefile: src_digest.o); it must equal the
+    digest of the files beside it -- the .so files are git-ignored and travel prebuilt, and bench.py / smoke() print the same
+    comparison as `library_matches_sources`.  Both libraries."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import src_digest
+    finally:
+        sys.path.pop(0)
+    want = src_digest.csrc_digest(ROOT)
+    assert re.fullmatch(r"zkmi 0\.1 \(gfx950\) src:[0-9a-f]{16}", zk.version()), zk.version()
+    assert zk.src_digest() == want, "libzkmi.so is stale: run __graft_entry__.build()"
+    zk.tlib.zkmi_version.restype = C.c_char_p
+    assert zk.tlib.zkmi_version().decode() == "zkmi 0.1 (gfx950) src:%s exp" % want
+    import bench
+
+    assert bench.csrc_digest() == want
+    rev = bench.source_revision(zk)
+    assert rev["library_matches_sources"] is True and rev["library_src_sha256_16"] == want
+
+
+def test_struct_layouts_agree_between_product_and_testing_library(zk):
+    """Tests and bench.py create inputs in libzkmi_exp.so on a context made by libzkmi.so (Zkmi.tlib): both export a
+    fingerprint of the struct layouts involved, the binding refuses to pair them when they differ."""
+    a, b = zk.abi_layout(zk.lib), zk.abi_layout(zk.tlib)
+    assert a == b and len(a) >= 20 and a[0] > 1000  # (sizeof(zkmi_ctx) first)
+    n = C.c_uint32(0)
+    assert zk.lib.zkmi_abi_layout_probe((C.c_uint64 * 2)(), C.c_uint32(2), C.byref(n)) == -1 and n.value == len(a)
+
+
+def test_kernel_register_budgets():
+    """The allocations the design stands on, read from the code objects inside the built library (scripts/kernel_resources.py;
+    no GPU needed): the accumulation kernels and the quad-split reduction kernels are one-wave workgroups of at most 168
+    VGPRs -- three waves per SIMD, each placed in the slot another one frees -- and the hot ones have
+    no scratch.  k_accum_g1_nc's zero-spill allocation at exactly 168 is, by msm_impl.hpp's own comment, a draw of the register
+    allocator that an edit nearby can lose: this test is what notices."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import kernel_resources as kr
+    finally:
+        sys.path.pop(0)
+    ks = {kr.short_name(n): v for n, v in kr.kernels(os.path.join(ROOT, "zk-apps_amd", "libzkmi.so")).items()}
+    assert len(ks) > 100
+    # kernel: (max VGPRs + AGPRs, max scratch bytes per lane)
+    budgets = {
+        "k_accum_g1_nc<Fq28,3,1,0,0>": (168, 0), "k_accum_g1_nc<Fq28,3,1,1,0>": (168, 0),
+        "k_accum_g1_nc<BnFq28,3,1,0,0>": (168, 0), "k_accum_g2_nc<Fq2,2,1>": (256, 0),
+        "k_accum_heavy_nc<Fq28,3>": (168, 96), "k_accum_heavy_nc_g2<Fq2,2>": (256, 0),
+        "k_segreduce_q<Fq28>": (168, 0), "k_treesum_q<Fq28>": (168, 0), "k_treesum_final_q<Fq28>": (168, 0),
+        "k_accum_redo_q<Fq28>": (168, 0), "k_heavy_q<Fq28>": (168, 64),
+        "k_segreduce_q<BnFq28>": (168, 0), "k_treesum_q<BnFq28>": (168, 0), "k_heavy_q<BnFq28>": (168, 0),
+    }
+    for name, (regs, scratch) in budgets.items():
+        assert name in ks, (name, sorted(k for k in ks if k.startswith(name.split("<")[0])))
+        k = ks[name]
+        assert k["vgpr"] + k["agpr"] <= regs and k["scratch"] <= scratch and not k["dynamic_stack"], (name, k)

@@ -1617,6 +1617,8 @@ def test_multigpu_script_ranks_sharing_one_gpu(world):
     assert next(o for w, o in by.items() if "zkmi_msm_g1_allgather_combine" in w)["matches_closed_form_and_python_path_on_every_rank"]
     assert next(o for w, o in by.items() if "WINDOWS split" in w)["matches_closed_form_on_every_rank"]
     assert next(o for w, o in by.items() if "prepared bases" in w)["matches_closed_form_on_every_rank"]
+    # round 6: the 2-D split (point groups x 2 window ranges) on the same slices
+    assert next(o for w, o in by.items() if "2-D split" in w)["matches_closed_form_on_every_rank"]
 
 
 def test_exchange_under_the_big_window_plan_with_ranks_sharing_one_gpu():
@@ -1625,6 +1627,18 @@ def test_exchange_under_the_big_window_plan_with_ranks_sharing_one_gpu():
     out = _run_multigpu(4, ["--one-gpu", "--config", "3", "--msm-log-n", "24"])
     assert all(o.get("matches_closed_form_on_every_rank", o.get("matches_closed_form_and_python_path_on_every_rank")) for o in out)
     assert all(o["ranks"] == 4 for o in out) and len(out) >= 3
+
+
+@pytest.mark.parametrize("window_groups", [2, 4])
+def test_2d_split_under_the_big_window_plan_at_world_8(window_groups):
+    """BASELINE configs[3] at its rank count: 8 ranks as 4 point groups x 2 window ranges and as 2 x 4
+    (zkmi_msm_g1_split2d_allgather), 2^24 points under their own plan -- the partitioned 20-bit windows, 13 windows, so the
+    ranges own 6 + 7 resp. 3 + 3 + 3 + 4 windows and the spread top window sits in the last range -- over the all-gather
+    double; every rank must reach the closed form.  (Ranks share GPU 0: nothing here says anything about RCCL or xGMI.)"""
+    out = _run_multigpu(8, ["--one-gpu", "--config", "3", "--msm-log-n", "24", "--window-groups", str(window_groups)])
+    two_d = [o for o in out if "2-D split" in o.get("workload", "")]
+    assert len(two_d) == 1 and two_d[0]["matches_closed_form_on_every_rank"] and two_d[0]["ranks"] == 8
+    assert "%d point groups x %d window ranges" % (8 // window_groups, window_groups) in two_d[0]["workload"]
 
 
 def test_arkworks_key_layout_load_and_write(ctx, zk):
@@ -2106,3 +2120,16 @@ def test_bn254_kzg_open_many_matches_oracle(ctx, pkg):
     kk = (sum(q) + 0xC0FFEE * sum(i * x for i, x in enumerate(q))) % bn.R
     assert pf == bn.g1_to_bytes(bn.pt_mul(bn.G1, kk))
     b.free()
+
+
+def test_quad_split_addition_selftest(ctx, zk):
+    """csrc/quad.hpp -- the complete XYZZ addition with one coordinate per lane of a quad (the segment sums, tree sums, redo
+    pass and heavy-bucket sums of the G1 MSM run on it: csrc/msm_quad.hpp) -- against curve.hpp's one-lane addition on the
+    device and the host's 32-bit-limb arithmetic: 4 096 pairs with every special case (o = a and o = -a in the same and in
+    another representation, either operand at infinity, both), and 16-point sums over the quads of a wave from XYZZ and
+    from affine sources (signs, entries at infinity, a doubling and a cancellation inside the tree)."""
+    import ctypes as C
+
+    bad = C.c_uint32(99)
+    assert zk.tlib.zkmi_selftest_quad_add(ctx.h, C.c_uint64(0xA11CE), C.c_uint32(4096), C.byref(bad)) == 0
+    assert bad.value == 0

@@ -176,7 +176,27 @@ class Zkmi:
                 if not os.path.exists(path):
                     raise ZkmiError(-4, f"{path} (testing library) not built; run __graft_entry__.build()")
                 self._tlib = C.CDLL(path)
+                # objects cross between the two libraries (a product context drives testing-library code and back): refuse
+                # to pair builds whose struct layouts differ instead of corrupting memory silently
+                mine, theirs = self.abi_layout(self.lib), self.abi_layout(self._tlib)
+                if mine != theirs:
+                    self._tlib = None
+                    raise ZkmiError(-1, f"libzkmi.so and libzkmi_exp.so disagree on struct layouts: {mine} vs {theirs}; rebuild both")
         return self._tlib
+
+    @staticmethod
+    def abi_layout(lib):
+        """zkmi_abi_layout_probe of `lib` as a tuple."""
+        out, n = (C.c_uint64 * 64)(), C.c_uint32(0)
+        rc = lib.zkmi_abi_layout_probe(out, C.c_uint32(64), C.byref(n))
+        if rc != 0:
+            raise ZkmiError(rc, "zkmi_abi_layout_probe")
+        return tuple(out[: n.value])
+
+    def src_digest(self):
+        """The source digest compiled into the loaded library (zkmi_version(): 'src:<digest>')."""
+        v = self.version()
+        return v.split("src:", 1)[1].split()[0] if "src:" in v else None
 
     def hip_versions(self):
         """(HIP_VERSION of the build, version of the HIP runtime this process bound the library to)."""
@@ -291,9 +311,14 @@ class Zkmi:
     def msm_g1_combine_partials(self, partials, n_ranks, plan_n, window_split=False):
         """zkmi_msm_g1_combine_partials: the host combination behind the all-gather, on caller-supplied slots."""
         out = (C.c_uint8 * 96)()
+        # window_split: False / 0 = point split, True / 1 = window split, Q >= 2 = the 2-D split with Q window ranges
         self._chk(self.lib.zkmi_msm_g1_combine_partials(_buf(partials), C.c_uint32(n_ranks), C.c_uint64(plan_n),
-                                                        C.c_int32(1 if window_split else 0), out))
+                                                        C.c_int32(int(window_split)), out))
         return bytes(out)
+
+    def host_info_string(self):
+        self.lib.zkmi_host_info_string.restype = C.c_char_p
+        return self.lib.zkmi_host_info_string().decode()
 
     def msm_g1_multi(self, ctxs, dptrs, counts, bases):
         """One MSM split by points over several contexts (one per GPU) of this process."""
@@ -832,6 +857,14 @@ class Context:
         """BASELINE configs[3] as worded: windows split over the ranks of `comm`, RCCL all-gather, the full result (collective)"""
         out = (C.c_uint8 * 96)()
         self._chk(self.lib.zkmi_msm_g1_window_split_allgather(self.h, comm.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, out))
+        return bytes(out)
+
+    def msm_g1_split2d_allgather(self, comm, dptr, n, bases, plan_n, window_groups):
+        """The 2-D split: rank k = g * window_groups + q holds point group g's slice (dptr / n / bases) and computes window
+        range q of the plan of plan_n terms; RCCL all-gather, the full result on every rank (collective)"""
+        out = (C.c_uint8 * 96)()
+        self._chk(self.lib.zkmi_msm_g1_split2d_allgather(self.h, comm.h, C.c_void_p(dptr), C.c_uint64(n), bases.h, C.c_uint64(plan_n),
+                                                         C.c_uint32(window_groups), out))
         return bytes(out)
 
     def msm_g1_windows_dev(self, dptr, n, bases, plan_n):

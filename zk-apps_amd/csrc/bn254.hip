@@ -369,6 +369,8 @@ int32_t msm_dev(zkmi_ctx* ctx, const void* d_scalars, uint64_t n, const zkmi_bn_
 
 }  // namespace
 
+uint64_t zkmi_layout_bn_bases() { return sizeof(zkmi_bn_bases); }  // capi.hip zkmi_abi_layout_probe
+
 extern "C" {
 
 int32_t zkmi_bn254_bases_load(zkmi_ctx* ctx, const uint8_t* affine, uint64_t n, int32_t check, zkmi_bn_bases** out) {

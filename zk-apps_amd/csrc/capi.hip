@@ -82,9 +82,47 @@ static int32_t bases_prepare(zkmi_ctx* ctx, B* b) {
 }
 
 
+// sizeof of the handle types other translation units define (groth16.hip, r1cs.hip, bn254.hip)
+uint64_t zkmi_layout_pk();
+uint64_t zkmi_layout_r1cs();
+uint64_t zkmi_layout_bn_bases();
+
 extern "C" {
 
-const char* zkmi_version(void) { return "zkmi 0.1 (gfx950)"; }
+// "zkmi 0.1 (gfx950) src:<digest>[ exp]": the digest of the sources this binary was built from (Makefile: src_digest.o)
+extern const char zkmi_src_digest_str[];
+const char* zkmi_version(void) {
+  static const std::string v = std::string("zkmi 0.1 (gfx950) src:") + zkmi_src_digest_str +
+#ifdef ZKMI_EXPERIMENTS
+                               " exp";
+#else
+                               "";
+#endif
+  return v.c_str();
+}
+
+// Sizes and member offsets of every struct that crosses between the product library and the A/B + testing library (tests
+// create inputs in libzkmi_exp.so on a context made by libzkmi.so: zk-apps_amd/binding.py Zkmi.tlib compares the two
+// fingerprints and refuses to pair libraries whose layouts differ -- a conditional member would otherwise corrupt memory
+// silently).
+int32_t zkmi_abi_layout_probe(uint64_t* out, uint32_t cap, uint32_t* out_n) {
+  if (!out || !out_n) return ZKMI_ERR_BAD_ARG;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winvalid-offsetof"
+  const uint64_t v[] = {
+      sizeof(zkmi_ctx), offsetof(zkmi_ctx, prof), offsetof(zkmi_ctx, domains), offsetof(zkmi_ctx, sort), offsetof(zkmi_ctx, sort_rz),
+      offsetof(zkmi_ctx, g1), offsetof(zkmi_ctx, g2), offsetof(zkmi_ctx, g1_bn), offsetof(zkmi_ctx, d_tmp), offsetof(zkmi_ctx, d_pos),
+      sizeof(zkmi_bases_g1), sizeof(zkmi_bases_g2), sizeof(MsmPlan), sizeof(MsmSort), offsetof(MsmSort, plan), offsetof(MsmSort, readers),
+      sizeof(MsmEngine<Fq28>), sizeof(MsmEngine<Fq2_28>), sizeof(MsmEngine<BnFq28>), offsetof(MsmEngine<Fq28>, slot_plan),
+      offsetof(MsmEngine<Fq28>, cap_buckets), sizeof(PhaseTimer), sizeof(NttDomain), zkmi_layout_r1cs(), zkmi_layout_pk(),
+      zkmi_layout_bn_bases(), sizeof(XYZZ<Fq28>), sizeof(Affine<Fq2_28>)};
+#pragma clang diagnostic pop
+  const uint32_t n = (uint32_t)(sizeof(v) / sizeof(v[0]));
+  *out_n = n;
+  if (cap < n) return ZKMI_ERR_BAD_ARG;
+  for (uint32_t i = 0; i < n; i++) out[i] = v[i];
+  return ZKMI_OK;
+}
 
 // HIP version the library was compiled against and the one of the runtime it is bound to in this process (a Python
 // process that also holds PyTorch-ROCm shares the wheel's runtime: zk-apps_amd/binding.py)
@@ -107,6 +145,13 @@ int32_t zkmi_host_info(uint32_t out[4]) {
   out[2] = zkmi::host_cpu_budget();
   out[3] = zkmi::HostPool::instance().workers();
   return ZKMI_OK;
+}
+const char* zkmi_host_info_string(void) {
+  static thread_local std::string s;
+  const zkmi::HostGrant& g = zkmi::host_grant();
+  s = "cpus=" + std::to_string(g.cpus) + " (" + g.cpu_source + ") ranks=" + std::to_string(g.ranks) + " (" + g.rank_source +
+      ") threads=" + std::to_string(zkmi::host_cpu_budget());
+  return s.c_str();
 }
 // threads per process for proof assembly from now on (0 = back to the library's choice); a host that runs several
 // contexts, or shares its CPUs with other work, knows better than the cgroup files

@@ -11,8 +11,12 @@
 // process (the host's own: a communicator handed to zkmi_comm_from_nccl must belong to the library whose ncclAllGather is
 // called on it) or else from librccl.so.1.  A host without RCCL can load the library and use everything but this file.
 #include <dlfcn.h>
+#include <errno.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -51,9 +55,25 @@ const Rccl& rccl() {
     // ZKMI_RCCL_LIB names the library file to use and nothing else is tried (a deployment whose RCCL lives outside the
     // loader's search path; the test-suite points it at a missing file -- ZKMI_ERR_RCCL -- and at an in-process all-gather
     // double that lets several ranks share one GPU, which RCCL itself refuses)
+    // The variable puts a file into the prover's address space, so the product only takes what an administrator of this
+    // account could have put there: an ABSOLUTE path to a regular file owned by root or by the effective user and not
+    // writable by others (sshd's StrictModes rule); anything else is refused with ZKMI_ERR_RCCL -- never a silent fallback.
     void* h = nullptr;
     const char* forced = getenv("ZKMI_RCCL_LIB");
     if (forced && *forced) {
+      struct stat sb;
+      if (forced[0] != '/') {
+        x.why = std::string("ZKMI_RCCL_LIB refused: not an absolute path: ") + forced;
+        return x;
+      }
+      if (stat(forced, &sb) != 0) {
+        x.why = std::string("RCCL not found: ZKMI_RCCL_LIB=") + forced + ": " + strerror(errno);
+        return x;
+      }
+      if (!S_ISREG(sb.st_mode) || (sb.st_uid != 0 && sb.st_uid != geteuid()) || (sb.st_mode & S_IWOTH)) {
+        x.why = std::string("ZKMI_RCCL_LIB refused: ") + forced + " must be a regular file owned by root or the effective user and not world-writable";
+        return x;
+      }
       h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     } else {
       h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
@@ -141,6 +161,20 @@ static G1XYZZ combine_window_slots(const MsmPlan& pl, const G1XYZZ* all, uint64_
   return msm_combine_windows<Fq>(win.data(), pl.nwin, pl.c);
 }
 
+// The combination of a 2-D split: R = P x Q ranks, rank k = g Q + q holds point group g (its slice of the points) and window
+// range q of Q (split_sub_plan(pl, q, Q)); its slot holds the partials of those windows over those points.  A window's sum is
+// the sum over the P point groups of the rank (g, range of the window)'s value.
+static G1XYZZ combine_2d_slots(const MsmPlan& pl, const G1XYZZ* all, uint64_t slot_pts, uint32_t R, uint32_t Q) {
+  std::vector<G1XYZZ> win((size_t)pl.nwin, G1XYZZ::infinity()), tmp((size_t)pl.nwin);
+  for (uint32_t k = 0; k < R; k++) {
+    const MsmPlan q = split_sub_plan(pl, k % Q, Q);
+    if (q.nwin <= 0) continue;
+    MsmEngine<Fq28>::windows_from_partials(q, all + slot_pts * k, tmp.data());
+    for (int w = 0; w < q.nwin; w++) win[(size_t)q.win_first + w].add(tmp[w]);
+  }
+  return msm_combine_windows<Fq>(win.data(), pl.nwin, pl.c);
+}
+
 static int32_t rccl_fail(zkmi_ctx* ctx, int code, const char* where) {
   const Rccl& r = rccl();
   const std::string msg = std::string(where) + ": " + (r.error_string ? r.error_string(code) : "RCCL error");
@@ -153,7 +187,10 @@ extern "C" {
 int32_t zkmi_comm_unique_id(uint8_t out_id[128]) {
   if (!out_id) return ZKMI_ERR_BAD_ARG;
   const Rccl& r = rccl();
-  if (!r.ok) return ZKMI_ERR_RCCL;
+  if (!r.ok) {
+    if (zkmi::debug_level()) fprintf(stderr, "zkmi: %s\n", r.why.c_str());  // (no context to carry the reason)
+    return ZKMI_ERR_RCCL;
+  }
   nccl_unique_id id;
   if (r.get_unique_id(&id) != 0) return ZKMI_ERR_RCCL;
   memcpy(out_id, id.internal, 128);
@@ -318,10 +355,65 @@ int32_t zkmi_msm_g1_window_split_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const
   return ZKMI_OK;
 }
 
+// The 2-D split as a collective (BASELINE configs[3] at 8 ranks: 4 point groups x 2 window ranges, or 2 x 4): rank
+// k = g Q + q of R = P Q holds the n points of group g -- d_scalars / bases are ITS SLICE, as in the point split -- and sorts,
+// accumulates and reduces only the windows of range q of the plan of plan_n terms: per rank 1 / R of the insertions like
+// both 1-D splits, 1 / P of the points resident (the window split: all of them) and 1 / Q of the buckets to reduce (the
+// point split: all of them -- the part of a rank's time that does not shrink with the slice).
+// Exchange: the same all-gather of equal-sized slots, (partials per window) x (most windows any range owns) points each.
+int32_t zkmi_msm_g1_split2d_allgather(zkmi_ctx* ctx, zkmi_comm* comm, const void* d_scalars, uint64_t n, const zkmi_bases_g1* bases,
+                                      uint64_t plan_n, uint32_t window_groups, uint8_t out_affine[96]) {
+  ZK_ENTER(ctx);
+  if (!comm || comm->ctx != ctx || !bases || !out_affine || n > bases->n || n > MSM_MAX_TERMS || plan_n > MSM_MAX_TERMS || (n && !d_scalars) ||
+      window_groups == 0 || comm->n_ranks % window_groups != 0)
+    return ZKMI_ERR_BAD_ARG;
+  const Rccl& r = rccl();
+  if (!r.ok) return ctx->fail(ZKMI_ERR_RCCL, r.why);
+  if (plan_n < n) plan_n = n;
+  const MsmPlan pl = msm_make_plan(plan_n);  // one window width on every rank
+  const uint32_t R = comm->n_ranks, Q = window_groups, nwin = (uint32_t)pl.nwin;
+  const uint32_t qi = comm->rank % Q;
+  const uint32_t w0 = split_first_window(qi, nwin, Q), w1 = split_first_window(qi + 1, nwin, Q);
+  const int per_window = MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin;
+  const uint64_t slot_pts = (uint64_t)per_window * split_max_windows(pl, Q);
+  const uint64_t slot_bytes = sizeof(G1XYZZ) * slot_pts;
+  // (as in the 1-D collectives: nothing between the first launch and the all-gather can fail on this rank alone)
+  if (slot_pts > (uint64_t)MsmEngine<Fq28>::SLOT_PTS) return ctx->fail(ZKMI_ERR_BAD_ARG, "plan has more partial sums than a slot holds");
+  ZK_HIP(ctx, ctx->sort.reserve(plan_n));
+  ZK_HIP(ctx, ctx->g1.reserve(plan_n));
+  ZK_HIP(ctx, comm_reserve(comm, slot_bytes * R));
+  std::vector<G1XYZZ> all(slot_pts * R);
+  if (w1 > w0 && n) {
+    ctx->sort.plan_override = pl.c;
+    ctx->sort.win_first = (int)w0;
+    ctx->sort.win_count = (int)(w1 - w0);
+    const hipError_t e = ctx->sort.run(static_cast<const uint32_t*>(d_scalars), n, ctx->stream, ctx->timer());
+    ctx->sort.plan_override = 0;
+    ctx->sort.win_first = ctx->sort.win_count = 0;
+    if (e != hipSuccess) return ctx->hip_fail(e, "sort");
+    ZK_HIP(ctx, ctx->g1.run_device(ctx->sort, bases->d28, ctx->stream, ctx->stream_aux, ctx->timer(), PH_MSM_ACCUM_G1, PH_MSM_REDUCE_G1));
+  } else {
+    // nothing to add on this rank (more window ranges than windows, or an empty slice): its slot must still read as sums
+    ZK_HIP(ctx, hipMemsetAsync(ctx->g1.partial, 0, (size_t)slot_bytes, ctx->stream_aux));
+  }
+  const int rc = r.all_gather(ctx->g1.partial, comm->d_gather, (size_t)slot_bytes, /* ncclUint8 */ 1, comm->comm, ctx->stream_aux);
+  if (rc != 0) {
+    (void)ctx->drain();
+    return rccl_fail(ctx, rc, "ncclAllGather");
+  }
+  ZK_HIP(ctx, hipMemcpyAsync(all.data(), comm->d_gather, slot_bytes * R, hipMemcpyDeviceToHost, ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const G1XYZZ res = combine_2d_slots(pl, all.data(), slot_pts, R, Q);
+  g1_to_wire(res.to_affine(), out_affine);
+  return ZKMI_OK;
+}
+
 // The two host combinations above on caller-supplied slots (no GPU, no RCCL): what every rank computes after the all-gather.
 // partials = n_ranks slots of XYZZ points in the library's host form (4 x 48-byte Montgomery coordinates, the bytes the
 // reductions leave in HBM).  window_split = 0: point split, a slot = partials_per_msm(plan of plan_n) points;
-// window_split = 1: a slot = (partials per window) x (most windows any rank owns) points.
+// window_split = 1: a slot = (partials per window) x (most windows any rank owns) points; window_split = Q >= 2: the 2-D
+// split with Q window ranges (Q divides n_ranks), a slot = (partials per window) x (most windows any RANGE owns) points.
 int32_t zkmi_msm_g1_combine_partials(const uint8_t* partials, uint32_t n_ranks, uint64_t plan_n, int32_t window_split,
                                      uint8_t out_affine[96]) {
   if (!partials || !out_affine || n_ranks == 0 || n_ranks > 4096 || plan_n == 0 || plan_n > MSM_MAX_TERMS) return ZKMI_ERR_BAD_ARG;
@@ -333,11 +425,18 @@ int32_t zkmi_msm_g1_combine_partials(const uint8_t* partials, uint32_t n_ranks, 
     all.resize(pts * n_ranks);
     memcpy(all.data(), partials, sizeof(G1XYZZ) * all.size());
     res = combine_rank_partials(pl, all.data(), n_ranks);
-  } else {
+  } else if (window_split == 1 || (uint32_t)window_split == n_ranks) {
     const uint64_t slot_pts = (uint64_t)(MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin) * split_max_windows(pl, n_ranks);
     all.resize(slot_pts * n_ranks);
     memcpy(all.data(), partials, sizeof(G1XYZZ) * all.size());
     res = combine_window_slots(pl, all.data(), slot_pts, n_ranks);
+  } else {
+    const uint32_t Q = (uint32_t)window_split;
+    if (window_split < 0 || n_ranks % Q != 0) return ZKMI_ERR_BAD_ARG;
+    const uint64_t slot_pts = (uint64_t)(MsmEngine<Fq28>::partials_per_msm(pl) / pl.nwin) * split_max_windows(pl, Q);
+    all.resize(slot_pts * n_ranks);
+    memcpy(all.data(), partials, sizeof(G1XYZZ) * all.size());
+    res = combine_2d_slots(pl, all.data(), slot_pts, n_ranks, Q);
   }
   g1_to_wire(res.to_affine(), out_affine);
   return ZKMI_OK;

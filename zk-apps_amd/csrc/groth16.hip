@@ -551,6 +551,8 @@ static hipError_t fixed_base_batch(zkmi_ctx* ctx, const Affine<F>* d_table, cons
   return hipStreamSynchronize(ctx->stream);
 }
 
+uint64_t zkmi_layout_pk() { return sizeof(zkmi_pk); }  // capi.hip zkmi_abi_layout_probe
+
 extern "C" {
 
 int32_t zkmi_groth16_setup(zkmi_ctx* ctx, const zkmi_r1cs* r, const uint8_t toxic[160], zkmi_pk** out_pk,
@@ -1187,6 +1189,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
       hipEvent_t evs[5] = {ctx->g1.done[s0 + 0], ctx->g1.done[s0 + 1], ctx->g1.done[s0 + 2], ctx->g1.done[s0 + 3], ctx->g2.done[g2s]};
       bool got[5] = {false, false, false, false, false};
       G1XYZZ s_a = G1XYZZ::infinity(), r_b1 = G1XYZZ::infinity();
+      uint8_t b_bytes[96];  // compressed B: copied out behind the witness checks only (a rejected witness leaves nothing in out_proofs)
       int left = 5;
       bool polled_busy = false;
       while (left) {
@@ -1220,7 +1223,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
             case RB2:
               ZK_HIP(ctx, ctx->g2.finish_host(&acc_b2[0], g2s));
               assemble_g2(pk, pre, acc_b2[0], head);
-              g2_compress(head.g2_b.to_affine(), out_proofs + 48);
+              g2_compress(head.g2_b.to_affine(), b_bytes);
               break;
           }
           if (lat_debug) mark(i == RB2 ? 5 : i);
@@ -1242,6 +1245,7 @@ static int32_t prove_finish(zkmi_ctx* ctx, const zkmi_pk* pk, const uint8_t* r_b
       G1Affine aff[2];
       batch_to_affine(ac, 2, aff);
       g1_compress(aff[0], out_proofs);
+      memcpy(out_proofs + 48, b_bytes, 96);
       g1_compress(aff[1], out_proofs + 144);
       if (lat_debug) {
         const long t_end = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();

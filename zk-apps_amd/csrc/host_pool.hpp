@@ -13,6 +13,7 @@
 //   * wait_event(): a short poll, then sleeping polls -- a rank's driving thread costs ~3 % of a CPU while it waits for the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -25,20 +26,37 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 #include "tune.hpp"
 
 namespace zkmi {
 
-// CPUs' worth of time the process may use: logical CPUs, cut down by the affinity mask and the cgroup quota (v2, then v1)
-inline unsigned host_cpus_granted() {
+// Where the two numbers below came from (zkmi_host_info_string: "cpus=16 (cgroup2 /sys/fs/cgroup/cpu.max) ranks=8 (LOCAL_WORLD_SIZE)")
+struct HostGrant {
+  unsigned cpus = 1;
+  char cpu_source[160] = "logical CPUs";
+  unsigned ranks = 1;
+  char rank_source[48] = "single process";
+};
+
+// CPUs' worth of time the process may use: logical CPUs, cut down by the affinity mask and by the SMALLEST CPU quota on the
+// path from the process's own cgroup up to the root (cgroup v2: cpu.max; v1: cpu.cfs_quota_us / cpu.cfs_period_us).  The
+// process's cgroup is read from /proc/self/cgroup: inside a cgroup namespace that path is "/" and the walk is the one file
+// the namespace root shows; without a namespace (or under a nested / hybrid hierarchy) the quota sits further down and the
+// namespace-root file alone would miss it.
+inline HostGrant host_grant_probe() {
+  HostGrant g;
   long n = (long)std::thread::hardware_concurrency();
   if (n < 1) n = 1;
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) {
     const long a = CPU_COUNT(&set);
-    if (a >= 1 && a < n) n = a;
+    if (a >= 1 && a < n) {
+      n = a;
+      snprintf(g.cpu_source, sizeof(g.cpu_source), "affinity mask");
+    }
   }
   auto quota = [](const char* path, const char* path_period) -> double {
     FILE* f = fopen(path, "r");
@@ -49,29 +67,102 @@ inline unsigned host_cpus_granted() {
     if (got < 1 || !strcmp(a, "max") || atof(a) <= 0) return 0;
     double period = got >= 2 ? atof(b) : 0;
     if (period <= 0 && path_period) {
-      FILE* g = fopen(path_period, "r");
-      if (g) {
-        if (fscanf(g, "%63s", b) == 1) period = atof(b);
-        fclose(g);
+      FILE* h = fopen(path_period, "r");
+      if (h) {
+        if (fscanf(h, "%63s", b) == 1) period = atof(b);
+        fclose(h);
       }
     }
     return period > 0 ? atof(a) / period : 0;
   };
-  double q = quota("/sys/fs/cgroup/cpu.max", nullptr);
-  if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
-  if (q > 0) {
-    const long c = (long)(q + 0.999);
-    if (c >= 1 && c < n) n = c;
+  double best = 0;
+  char best_src[160] = "";
+  auto consider = [&](double q, const char* kind, const char* path) {
+    if (q > 0 && (best <= 0 || q < best)) {
+      best = q;
+      snprintf(best_src, sizeof(best_src), "%s %s", kind, path);
+    }
+  };
+  // every directory from `rel` (a cgroup path, "/a/b") up to the mount point `mnt`
+  auto walk = [&](const char* mnt, const char* rel, bool v2) {
+    char dir[512];
+    snprintf(dir, sizeof(dir), "%s%s", mnt, rel);
+    for (;;) {
+      size_t len = strlen(dir);
+      while (len > 1 && dir[len - 1] == '/') dir[--len] = 0;
+      char f1[600], f2[600];
+      if (v2) {
+        snprintf(f1, sizeof(f1), "%s/cpu.max", dir);
+        consider(quota(f1, nullptr), "cgroup2", f1);
+      } else {
+        snprintf(f1, sizeof(f1), "%s/cpu.cfs_quota_us", dir);
+        snprintf(f2, sizeof(f2), "%s/cpu.cfs_period_us", dir);
+        consider(quota(f1, f2), "cgroup1", f1);
+      }
+      if (strlen(dir) <= strlen(mnt)) break;
+      char* slash = strrchr(dir, '/');
+      if (!slash || slash == dir) break;
+      *slash = 0;
+      if (strlen(dir) < strlen(mnt)) break;
+    }
+  };
+  bool walked = false;
+  if (FILE* f = fopen("/proc/self/cgroup", "r")) {
+    char line[600];
+    while (fgets(line, sizeof(line), f)) {
+      // "<id>:<controllers>:<path>"
+      char* c1 = strchr(line, ':');
+      char* c2 = c1 ? strchr(c1 + 1, ':') : nullptr;
+      if (!c2) continue;
+      *c2 = 0;
+      char* path = c2 + 1;
+      path[strcspn(path, "\n")] = 0;
+      if (path[0] != '/' || strstr(path, "..")) continue;
+      const char* ctl = c1 + 1;
+      if (!*ctl) {  // v2 (unified): "0::/path"
+        walk("/sys/fs/cgroup", path, true);
+        walked = true;
+      } else if (strstr(ctl, "cpu") && !strstr(ctl, "cpuset")) {  // v1: "4:cpu,cpuacct:/path"
+        char mnt[256];
+        snprintf(mnt, sizeof(mnt), "/sys/fs/cgroup/%s", ctl);
+        walk(mnt, path, false);
+        walk("/sys/fs/cgroup/cpu", path, false);
+        walked = true;
+      }
+    }
+    fclose(f);
   }
-  return (unsigned)n;
+  if (!walked) {  // no /proc: the files the namespace root shows
+    consider(quota("/sys/fs/cgroup/cpu.max", nullptr), "cgroup2", "/sys/fs/cgroup/cpu.max");
+    consider(quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"), "cgroup1", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us");
+  }
+  if (best > 0) {
+    const long c = (long)(best + 0.999);
+    if (c >= 1 && c < n) {
+      n = c;
+      snprintf(g.cpu_source, sizeof(g.cpu_source), "%s", best_src);
+    }
+  }
+  g.cpus = (unsigned)n;
+  // processes of this job on this node (they share the grant): torchrun / torch.distributed.run export LOCAL_WORLD_SIZE,
+  // Open MPI OMPI_COMM_WORLD_LOCAL_SIZE, Slurm SLURM_NTASKS_PER_NODE, MPICH / Intel MPI MPI_LOCALNRANKS
+  for (const char* name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "MPI_LOCALNRANKS"}) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    if (v >= 1 && v <= 1024) {
+      g.ranks = (unsigned)v;
+      snprintf(g.rank_source, sizeof(g.rank_source), "%s", name);
+      break;
+    }
+  }
+  return g;
 }
-
-// processes of this job on this node (they share the grant): torchrun / torch.distributed.run export LOCAL_WORLD_SIZE
-inline unsigned host_local_ranks() {
-  const char* e = getenv("LOCAL_WORLD_SIZE");
-  const int v = e ? atoi(e) : 0;
-  return (unsigned)(v >= 1 && v <= 1024 ? v : 1);
+inline const HostGrant& host_grant() {
+  static const HostGrant g = host_grant_probe();
+  return g;
 }
+inline unsigned host_cpus_granted() { return host_grant().cpus; }
+inline unsigned host_local_ranks() { return host_grant().ranks; }
 
 constexpr unsigned HOST_THREADS_MAX = 64;
 inline std::atomic<unsigned>& host_threads_override() {
@@ -174,7 +265,21 @@ class HostPool {
       }
     }
   }
-  HostPool() = default;
+  // fork(): the child has none of the workers (only the forking thread survives), but it has their std::thread objects --
+  // ~HostPool would join() threads that do not exist and never return from exit().  The child forgets them (the objects
+  // are leaked on purpose: destroying a joinable std::thread terminates) and starts from an empty pool; the locks are
+  // re-made because a worker may have held them at the instant of the fork.  A fork in the MIDDLE of run() is the
+  // caller's own problem only as far as its job goes: the owner drains its own indices.
+  static void atfork_child() {
+    HostPool& p = instance();
+    new (&p.mu_) std::mutex();
+    new (&p.cv_) std::condition_variable();
+    (void)new std::vector<std::thread>(std::move(p.threads_));
+    new (&p.threads_) std::vector<std::thread>();
+    p.queue_.clear();
+    p.stop_ = false;
+  }
+  HostPool() { (void)pthread_atfork(nullptr, nullptr, &HostPool::atfork_child); }
   ~HostPool() {
     {
       std::lock_guard<std::mutex> g(mu_);

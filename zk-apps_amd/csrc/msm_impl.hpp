@@ -42,7 +42,8 @@ namespace zkmi {
 // segment arrays: 16-bucket segments for big plans, down to 1-bucket segments for plans of <= 2^16 buckets
 static inline uint64_t msm_max_segments(uint64_t buckets) { return (buckets / 16 > (1u << 16) ? buckets / 16 : (1u << 16)) + 1; }
 constexpr int MSM_TREE_T = 128;  // k_treesum block: 128 x XYZZ<Fq2> = 56 KiB LDS
-constexpr uint32_t MSM_STAGE_PTS = 4096;  // k_treesum slices of one slot (small plans only)
+constexpr uint32_t MSM_STAGE_PTS = 16384;  // slices of one slot's tree-sum job lists (k_treesum_q; the one-lane k_treesum uses the first MSM_STAGE_PTS_1)
+constexpr uint32_t MSM_STAGE_PTS_1 = 4096;
 constexpr uint32_t MSM_HEAVY = 256;  // load-ordering key range; the heavy threshold itself is plan.heavy_thr
 
 template <class T>
@@ -1482,6 +1483,10 @@ k_accum_redo_g2_split(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* 
   }
 }
 
+}  // namespace zkmi
+#include "msm_quad.hpp"
+namespace zkmi {
+
 template <class F>
 __global__ void __launch_bounds__(256)
 k_bases_convert(const Affine<typename HostFieldOf<F>::type>* __restrict__ in, Affine<F>* __restrict__ out,
@@ -1662,6 +1667,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   const int accum_mode_g2 = ZK_TUNE("ZKMI_ACCUM_G2", 2);
   const int mode = std::is_same<F, Fq2_28>::value ? accum_mode_g2 : accum_mode;
   const bool nocall = mode == 2 || mode == 3;
+  // The reduction-side kernels with every complete addition split over a lane quad (msm_quad.hpp; G1 and BN254 G1): bit 0 =
+  // segment sums, 1 = tree sums, 2 = redo pass, 3 = the summing of heavy-bucket partials.  One-wave workgroups at the
+  // accumulation kernels' register count: placed beside them.  (A/B library: ZKMI_QUAD = mask; 0 = the one-lane kernels.)
+  // The partitioned big windows keep the one-lane segment and tree sums: their reduction has the chip to itself.
+  const int quad_mask = std::is_same<F, Fq2_28>::value ? 0 : ZK_TUNE("ZKMI_QUAD", 15);
+  const bool quad_reduce_ok = pl.shared || pl.c <= 16;
 #ifdef ZKMI_EXPERIMENTS
   const int accum_block = ZK_TUNE("ZKMI_ACCUM_BLOCK", 64) == 256 ? 256 : 64;
   const int accum_rounds = ZK_TUNE("ZKMI_ACCUM_ROUNDS", 0);
@@ -1723,6 +1734,10 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
                            d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, MSM_HEAVY_CAP, 0xffffffffu,
                            (const uint32_t*)nullptr, pool_nc);
+    } else if (nc && (quad_mask & 8)) {
+      // both modes of the plan in one-wave workgroups of quads: nothing of 300 registers has to find a SIMD beside the accumulation
+      hipLaunchKernelGGL(k_heavy_q<F>, dim3(1024), dim3(64), 0, heavy_stream[m], d_bases[m], sort.begin, sort.count, sort.heavy,
+                         sort.sorted, bk_of(m), hp, tk, hplan, pool_nc);
     } else {
       hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, into_of(m) ? 1u : 0u, 0u,
@@ -1869,7 +1884,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     if (nchunk > MSM_TREE_T) nchunk = MSM_TREE_T;
     // (fewer, longer slices -- at most 16, 8 or 4 -- measured the same group rates and single-proof latencies within noise:
     // profiles/r05/experiments/tree_slices_ab.txt)
-    if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS) nchunk = 1;
+    if ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS_1) nchunk = 1;
   } else if (!pl.shared && tot_b <= (1u << 19) && segs_per_win > per_block) {
     // one windowed MSM of up to 2^19 buckets: as many slices as the stage holds (16 windows x 13 jobs: 16), see plan_set_heavy
     // (... and as the chip holds at once: 3 328 workgroups of 9 dependent additions each, in three rounds, took longer than 208 of 23)
@@ -1879,7 +1894,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     // partitioned big windows: 2^(c-5) segments per (window, job) list on ONE workgroup are a chain of 2^(c-12) dependent
     // additions (5 ms at c = 20); sliced, as many slices as the stage holds (16 at 13 windows x 16 jobs)
     nchunk = MSM_TREE_T;
-    while (nchunk > 1 && ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS || nchunk * per_block > segs_per_win)) nchunk >>= 1;
+    while (nchunk > 1 && ((uint64_t)njobs * pl.nwin * nchunk > MSM_STAGE_PTS_1 || nchunk * per_block > segs_per_win)) nchunk >>= 1;
   }
   for (int m = 0; m < nm; m++) {
     const MsmSort& sort = *sorts[m];
@@ -1906,6 +1921,9 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       if constexpr (std::is_same<F, Fq2_28>::value)
         hipLaunchKernelGGL(k_accum_redo_g2_split<0>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 32, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk,
                            redo, redo + cap_buckets + 1);
+      else if (quad_mask & 4)
+        hipLaunchKernelGGL(k_accum_redo_q<F>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
+                           redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
       else
         hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 64, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
                            redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
@@ -1933,6 +1951,8 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       }
       if (!pl.shared && pl.c > 16)
         hipLaunchKernelGGL(k_segreduce_w2<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
+      else if (quad_mask & 1)
+        hipLaunchKernelGGL(k_segreduce_q<F>, dim3((tot_segs + MSM_NQ - 1) / MSM_NQ), dim3(64), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
       else
         hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
     }
@@ -1958,6 +1978,14 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
           hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                              ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
       }
+    } else if ((quad_mask & 2) && quad_reduce_ok) {
+      // one wave (16 quads) per slice of a job list; as many slices as make the two levels equally deep (a quad walks
+      // len / (16 slices) segments, the final sum slices / 16), within the stage
+      uint32_t nq = 1;
+      while ((uint64_t)nq * nq * 4 <= segs_per_win) nq <<= 1;  // ~ sqrt(segs_per_win), rounded to a power of two
+      while (nq > 1 && ((uint64_t)njobs * pl.nwin * nq > MSM_STAGE_PTS || nq * MSM_NQ > segs_per_win)) nq >>= 1;
+      hipLaunchKernelGGL(k_treesum_q<F>, dim3(njobs, pl.nwin, nq), dim3(64), 0, st_reduce, ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
+      if (nq > 1) hipLaunchKernelGGL(k_treesum_final_q<F>, dim3(njobs, pl.nwin), dim3(64), 0, st_reduce, stg, nq, dp, hp_out);
     } else {
       hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                          ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);

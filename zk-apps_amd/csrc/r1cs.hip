@@ -220,6 +220,8 @@ bool r1cs_satisfied(const zkmi_r1cs& r, const std::vector<Fr>& z) {
 
 using namespace zkmi;
 
+uint64_t zkmi_layout_r1cs() { return sizeof(zkmi_r1cs); }  // capi.hip zkmi_abi_layout_probe
+
 extern "C" {
 
 int32_t zkmi_r1cs_create(uint32_t n_vars, uint32_t n_pub, uint32_t n_constraints, const uint32_t* a_rowptr,
