@@ -723,6 +723,49 @@ def test_create_note_relation_matches_oracle(zk):
     r1.free()
 
 
+def test_oracle_side_witness_solver_reproduces_both_relations(zk):
+    """oracle/relation_witness.py: loaded values by the reference's load order with oracle/poseidon.py hashes + a generic
+    solver over the exported matrices (products, is_zero pairs, range-check bits).  The solved assignment satisfies the
+    oracle's evaluator and equals the product generator's bytes for deposit, withdraw (2^13) and the creation relation (2^12);
+    a loaded hash that is off by one makes the solver raise (the constraint system computes the oracle's Poseidon)."""
+    from oracle import bls12_381 as ec
+    from oracle import relation_witness as rw
+
+    height = 10
+    for op_kind in (0, 1):
+        r1 = zk.update_note_r1cs(13, op_kind)
+        rng = ec.SplitMix64(0xA11 + op_kind)
+        tok = [rng.fr(), rng.fr()]
+        bal, amount, slot = [900, 40], 25, 1 - op_kind
+        new_note, old_note = (rng.fr(), rng.fr(), rng.fr()), (rng.fr(), rng.fr(), rng.fr())
+        user = rng.fr()
+        shape = [rng.next() & 1 for _ in range(height)]
+        path = [rng.fr() for _ in range(height)]
+        acct = (tok[0], bal[0], tok[1], bal[1])
+        loaded = rw.update_note_loaded(op_kind, amount, tok[slot], user, new_note, old_note, shape, path, user, acct)
+        orc = _oracle_r1cs(r1)
+        z_int = rw.solve(r1.n_vars, orc.A, orc.B, orc.C, loaded)
+        assert orc.is_satisfied(z_int)
+        inp = zk.note_update(amount, tok[slot], user, new_note, old_note, shape, path, user, acct)
+        w, pub, rc = zk.update_note_witness(13, op_kind, inp)
+        assert rc == 0 and w == b"".join(v.to_bytes(32, "little") for v in z_int)
+        bad = list(loaded)
+        bad[5] = (bad[5] + 1) % ec.R  # merkle_root
+        with pytest.raises(ValueError):
+            rw.solve(r1.n_vars, orc.A, orc.B, orc.C, bad)
+        r1.free()
+    r1 = zk.create_note_r1cs(12)
+    rng = ec.SplitMix64(0xC4EA7E)
+    tok, note = (rng.fr(), rng.fr()), (rng.fr(), rng.fr(), rng.fr())
+    pubs, acc_hash = rw.create_note_loaded(tok, note)
+    orc = _oracle_r1cs(r1)
+    z_int = rw.solve(r1.n_vars, orc.A, orc.B, orc.C, pubs + [note[0], note[1], note[2], acc_hash])
+    assert orc.is_satisfied(z_int)
+    w, pub = zk.create_note_witness(12, zk.note_create(tok, note))
+    assert w == b"".join(v.to_bytes(32, "little") for v in z_int) and pub == pubs[1:]
+    r1.free()
+
+
 def test_verifier_rejects_non_canonical_and_small_order_points(zk, pkg):
     """zkmi_groth16_verify is a validating verifier (as arkworks' deserialisation and the zcash format are):
     one encoding of infinity, and every proof point must lie in the r-order subgroup."""

@@ -151,6 +151,90 @@ def test_msm_g2_2p22_vs_cpp_oracle(ctx):
     b.free()
 
 
+def _proof_bytes_against_the_oracle(ctx, zk, r1, wit, publics, seed):
+    """vk + 192 proof bytes of the product (its setup, its GPU prover: single and batch entry points) against the C++
+    oracle's own setup + prover from the same toxic waste, witness, r and s; the proof must verify under the oracle's key."""
+    import torch
+    from oracle import cpp as ocpp
+
+    ocpp.build()
+    rng = ec.SplitMix64(seed)
+    toxic = frs([rng.fr() for _ in range(5)])
+    pk, vk = ctx.groth16_setup(r1, toxic)
+    mats = [r1.export(m) for m in range(3)]
+    ovk, okey = ocpp.groth16_setup(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, toxic)
+    assert vk == ovk
+    r_, s_ = ec.fr_to_bytes(rng.fr()), ec.fr_to_bytes(rng.fr())
+    want = ocpp.groth16_prove(r1.n_vars, r1.n_pub, r1.n_constraints, r1.log_n, mats, okey, wit, r_, s_)
+    d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert ctx.groth16_prove_dev(pk, d.data_ptr(), r_, s_) == want
+    assert ctx.groth16_prove_batch_dev(pk, [d.data_ptr()] * 3, [r_] * 3, [s_] * 3) == [want] * 3
+    assert zk.groth16_verify(ovk, frs(publics), want) is True
+    bad = list(publics)
+    bad[0] = (bad[0] + 1) % R
+    assert zk.groth16_verify(ovk, frs(bad), want) is False
+    pk.free()
+    return want
+
+
+@pytest.mark.parametrize("which", ["deposit", "withdraw", "creation"])
+def test_proof_bytes_vs_cpp_oracle_at_the_relations_own_sizes(ctx, zk, which):
+    """BASELINE configs[0] is the DEPOSIT relation at 2^14 (mocked_zk/src/ops.rs:6-25: Deposit / Withdraw); the byte-parity
+    tests of the big sizes all prove withdraw.  Here: deposit and withdraw at 2^14 and the creation relation (what
+    ZkProof::verify_creation stands for, relations.rs:127-136) at 2^12, each against the oracle's own setup + prover."""
+    from test_cpu_host import _note_update_case
+    from oracle import poseidon as ps
+
+    if which == "creation":
+        lg = 12
+        r1 = zk.create_note_r1cs(lg)
+        rng = ec.SplitMix64(777)
+        tok, note = (rng.fr(), rng.fr()), (rng.fr(), rng.fr(), rng.fr())
+        wit, publics = zk.create_note_witness(lg, zk.note_create(tok, note))
+        assert publics[0] == ps.note_hash(note[0], note[1], note[2], ps.hash_fix_len([tok[0], 0, tok[1], 0]))
+    else:
+        lg, op_kind = 14, 0 if which == "deposit" else 1
+        r1 = zk.update_note_r1cs(lg, op_kind)
+        inp, publics = _note_update_case(zk, 9100 + op_kind, op_kind, slot=op_kind)
+        wit, pub, rc = zk.update_note_witness(lg, op_kind, inp)
+        assert rc == 0 and pub == publics
+    _proof_bytes_against_the_oracle(ctx, zk, r1, wit, publics, 0x5A4B0100 + lg + len(which))
+    r1.free()
+
+
+@pytest.mark.parametrize("op_kind", [0, 1])
+def test_update_note_proof_from_an_oracle_side_witness(ctx, zk, op_kind):
+    """Relation AND prover on inputs the product did not produce (2^13, the relation's real size): the loaded values come
+    from oracle/relation_witness.py (UpdateNoteInput::new's order, update_note.rs:47-88, every hash by oracle/poseidon.py), the
+    remaining variables from its generic solver over the exported matrices -- which raises if the constraint system does not
+    compute the oracle's hashes; the assignment must satisfy the oracle's R1CS evaluator, equal the product generator's
+    bytes (the solution is unique), and the GPU proof over it must equal the oracle prover's bytes."""
+    from oracle import relation_witness as rw
+    from test_cpu_host import _oracle_r1cs
+
+    lg, height = 13, 10
+    r1 = zk.update_note_r1cs(lg, op_kind)
+    rng = ec.SplitMix64(0xB0B + op_kind)
+    tok = [rng.fr(), rng.fr()]
+    bal, amount, slot = [5000, 123], 321, op_kind
+    new_note, old_note = (rng.fr(), rng.fr(), rng.fr()), (rng.fr(), rng.fr(), rng.fr())
+    user = rng.fr()
+    shape = [rng.next() & 1 for _ in range(height)]
+    path = [rng.fr() for _ in range(height)]
+    loaded = rw.update_note_loaded(op_kind, amount, tok[slot], user, new_note, old_note, shape, path, user, (tok[0], bal[0], tok[1], bal[1]))
+    orc = _oracle_r1cs(r1)
+    z_int = rw.solve(r1.n_vars, orc.A, orc.B, orc.C, loaded)
+    assert orc.is_satisfied(z_int)
+    wit = b"".join(v.to_bytes(32, "little") for v in z_int)
+    # the product's generator on the same instance: the same bytes
+    inp = zk.note_update(amount, tok[slot], user, new_note, old_note, shape, path, user, (tok[0], bal[0], tok[1], bal[1]))
+    w_prod, pub, rc = zk.update_note_witness(lg, op_kind, inp)
+    assert rc == 0 and w_prod == wit and pub == loaded[1:7]
+    _proof_bytes_against_the_oracle(ctx, zk, r1, wit, loaded[1:7], 0x5A4B0200 + op_kind)
+    r1.free()
+
+
 @pytest.mark.parametrize("lg", [18, 20, 22])
 def test_proof_bytes_vs_cpp_oracle_over_the_oracle_side_key(ctx, zk, lg):
     """Rows a7 + a10 at the headline size (2^20) and at BASELINE config 4's (2^22: "G2 MSM + pairing ... full Groth16 proof",

@@ -1671,7 +1671,10 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   // segment sums, 1 = tree sums, 2 = redo pass, 3 = the summing of heavy-bucket partials.  One-wave workgroups at the
   // accumulation kernels' register count: placed beside them.  (A/B library: ZKMI_QUAD = mask; 0 = the one-lane kernels.)
   // The partitioned big windows keep the one-lane segment and tree sums: their reduction has the chip to itself.
-  const int quad_mask = std::is_same<F, Fq2_28>::value ? 0 : ZK_TUNE("ZKMI_QUAD", 15);
+  // Two contexts: ONE MSM or ONE proof by itself (host_spin: the latency path -- a chain of 4 products per dependent addition
+  // instead of 14) and the batch prover's pipeline (throughput: the quad form issues 16 products for the 14 of the formula
+  // plus its exchanges, 1.37 x the instructions of the one-lane addition).
+  const int quad_mask = std::is_same<F, Fq2_28>::value ? 0 : host_spin ? ZK_TUNE("ZKMI_QUAD", 15) : ZK_TUNE("ZKMI_QUAD_BATCH", 12);
   const bool quad_reduce_ok = pl.shared || pl.c <= 16;
 #ifdef ZKMI_EXPERIMENTS
   const int accum_block = ZK_TUNE("ZKMI_ACCUM_BLOCK", 64) == 256 ? 256 : 64;
