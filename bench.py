@@ -343,6 +343,95 @@ def secondary_measurements(z, ctx, log_n):
             "scalars resident, median of 5, wall clock", **out}
 
 
+def ntt_alone(z, ctx, log_n, pmc_path):
+    """BASELINE configs[1] names a 2^20 NTT beside the MSM: one Fr transform of 2^log_n resident elements alone on the chip,
+    forward and coset-inverse (the two shapes the prover runs), through the C ABI (zkmi_ntt_dev: canonical 32-byte elements
+    in place).  Algorithmic bytes 2 x 32 N; wall clock around a synchronised call, median of 9."""
+    _need_torch()
+    N = 1 << log_n
+    g = torch.Generator(device="cuda").manual_seed(0x5A4B0007)
+    x = torch.randint(0, 256, (N, 32), dtype=torch.uint8, device="cuda", generator=g)
+    x[:, 31] &= 0x3F
+    out = {"n": N, "what": "zkmi_ntt_dev in place over resident canonical elements (conversion to limb form, the two passes, "
+           "conversion back), alone on the chip, median of 9, wall clock around ctx.sync()"}
+    for name, kw in (("forward", {}), ("coset_inverse", {"inverse": True, "coset": True})):
+        ctx.ntt_dev(x.data_ptr(), log_n, **kw)
+        ctx.sync()
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            ctx.ntt_dev(x.data_ptr(), log_n, **kw)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        out[name] = {"ms": 1e3 * t, "GBps": 64.0 * N / t / 1e9, "frac_of_hbm_peak": 64.0 * N / t / 1e9 / HBM_PEAK_GBS}
+    # the pass kernel's own figures from the PMC summary (alone on the chip: scripts/pmc_summary.py), when it has them
+    try:
+        rows = json.loads(open(os.path.join(ROOT, pmc_path)).read()) if pmc_path != "none" else []
+    except (OSError, ValueError):
+        rows = []
+    for r in rows:
+        if r.get("kernel", "").startswith("k_ntt_pass") and "1024" in r["kernel"] and r.get("alone_ns_avg_per_dispatch") and log_n == 20:
+            ms = r["alone_ns_avg_per_dispatch"] / 1e6
+            out["pass_kernel"] = {"kernel": r["kernel"], "alone_ms_per_launch": ms,
+                                  "valu_frac_of_issue_peak": r.get("SQ_INSTS_VALU_avg_per_dispatch", 0) / (ms * 1e-3) / VALU_ISSUE_PEAK,
+                                  "note": "one of the two passes of a transform, from the committed PMC summary (SQ_INSTS_VALU / duration alone)"}
+            break
+    return out
+
+
+def config4_block(z, ctx, relation, steps=6):
+    """BASELINE configs[4]: full Groth16 proofs at 2^22 (G2 MSM of 2^22 - 1 terms, pairing check) on one GPU -- the batch
+    rate over `steps` proofs and the G2 MSM alone (zkmi_msm_g2_dev over the key-sized synthetic bases): 224 n algorithmic
+    bytes."""
+    _need_torch()
+    lg = 22
+    t0 = time.time()
+    r1, d_wits = resident_witnesses(z, ctx, relation, lg, [0x5A4B4000, 0x5A4B4001])
+    rng = SplitMix64(0x5A4B0044)
+    pk, vk = ctx.groth16_setup(r1, b"".join(rng.fr_bytes() for _ in range(5)))
+    setup_s = time.time() - t0
+    rs = [(rng.fr_bytes(), rng.fr_bytes()) for _ in range(steps)]
+    ptrs = [d_wits[i % 2].data_ptr() for i in range(steps)]
+    ctx.groth16_prove_batch_dev(pk, ptrs[:2], [a for a, _ in rs[:2]], [b for _, b in rs[:2]])
+    ctx.sync()
+    t0 = time.perf_counter()
+    proofs = ctx.groth16_prove_batch_dev(pk, ptrs, [a for a, _ in rs], [b for _, b in rs])
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    pub = bytes(d_wits[(steps - 1) % 2][32 : 32 * r1.n_pub].cpu().numpy().tobytes())
+    ok = z.groth16_verify(vk, pub, proofs[-1])
+    lat = []
+    for i in range(3):
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.groth16_prove_dev(pk, ptrs[i % 2], rs[i][0], rs[i][1])
+        lat.append(time.perf_counter() - t0)
+    pk.free()
+    r1.free()
+    del d_wits
+    torch.cuda.empty_cache()
+    n = (1 << lg) - 1
+    g = torch.Generator(device="cuda").manual_seed(0x5A4B0045)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    sc[:, 31] &= 0x3F
+    b = ctx.bases_g2_synthetic(n)
+    ctx.msm_g2_dev(sc.data_ptr(), n, b)
+    ts = []
+    for _ in range(3):
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.msm_g2_dev(sc.data_ptr(), n, b)
+        ts.append(time.perf_counter() - t0)
+    b.free()
+    tg = sorted(ts)[1]
+    return {"log_n": lg, "proofs": steps, "proofs_per_s": steps / dt, "ms_per_proof": 1e3 * dt / steps,
+            "single_proof_latency_ms": 1e3 * sorted(lat)[1], "verified_by_pairing": bool(ok), "setup_seconds": setup_s,
+            "algorithmic_GBps_whole_proof": 1184.0 * (1 << lg) * steps / dt / 1e9,
+            "msm_g2_alone": {"n": n, "ms": 1e3 * tg, "GBps": 224.0 * n / tg / 1e9, "frac_of_hbm_peak": 224.0 * n / tg / 1e9 / HBM_PEAK_GBS,
+                             "what": "zkmi_msm_g2_dev end to end over plain bases (windowed schedule), uniform scalars, median of 3"}}
+
+
 def small_domain_rate(z, ctx, relation, log_n=14, count=512):
     """BASELINE config 0's size (2^14, the relation's natural size): `count` independent proofs through the same batch
     entry point, which at this size moves groups of 64 proofs through one sort / one accumulation launch per query."""
@@ -424,10 +513,13 @@ def timed_region(ctx, use_dist, fn):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=timed_region.reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return res, elapsed
+
+
+timed_region.reduce_device = "cuda"  # "cpu" under --shared-gpu-dry-run (gloo)
 
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -452,6 +544,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     sums = torch.stack([raw.to(torch.int64).sum(dim=0), (raw.to(torch.int64) * idx[:, None]).sum(dim=0)]).contiguous()
     del idx
     if use_dist:
+        sums = sums.to(timed_region.reduce_device)  # (gloo under --shared-gpu-dry-run)
         allsums = [torch.empty_like(sums) for _ in range(world)]
         dist.all_gather(allsums, sums)
     else:
@@ -483,6 +576,8 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     def one():
         if args.split == "windows":
             return ctx.msm_g1_window_split_allgather(comm, raw.data_ptr(), n, bases)
+        if args.split == "2d":
+            return ctx.msm_g1_split2d_allgather(comm, raw.data_ptr(), m, bases, n, args.window_groups)
         return ctx.msm_g1_allgather_combine(comm, raw.data_ptr(), m, bases, n)
 
     # the exchange behind the C ABI: zkmi_comm (RCCL; torch.distributed only carries rank 0's 128-byte id), partial sums
@@ -506,7 +601,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     want = z.g1_add(z.g1_mul(G, (tot % R_MOD).to_bytes(32, "little")), z.g1_mul(Q, (wtot % R_MOD).to_bytes(32, "little")))
     ok = got == want
     if use_dist:
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=timed_region.reduce_device)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
     comm.free()
@@ -563,6 +658,15 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     return out, 0 if ok else 1
 
 
+def mark_dry_run(out, world):
+    """--shared-gpu-dry-run: the line must not be mistaken for a scaling point -- all ranks shared ONE GPU."""
+    out["dry_run_shared_gpu"] = True
+    out["metric"] = "DRY_RUN_%d_ranks_sharing_one_gpu__%s" % (world, out["metric"])
+    out["physical_gpus"] = 1
+    out["note_dry_run"] = ("all %d ranks ran on device 0 over gloo + the shared-memory all-gather double (tests/fake_rccl): the value exercises the "
+                           "multi-rank code path of bench.py and says nothing about scaling, RCCL or xGMI" % world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -572,7 +676,8 @@ def main():
                     help="proofs = BASELINE configs[1]/[2] (headline); msm26 = configs[3], one 2^26-point G1 MSM split over the ranks")
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--msm-log-n", type=int, default=26)
-    ap.add_argument("--split", choices=["points", "windows"], default="points",
+    ap.add_argument("--window-groups", type=int, default=2, help="msm26 --split 2d: window ranges Q (ranks = point groups x Q)")
+    ap.add_argument("--split", choices=["points", "windows", "2d"], default="points",
                     help="msm26: how the MSM is cut over the ranks -- by POINTS (SURVEY.md 8e's preferred partition, 1/N of the scalars and "
                          "bases per rank; default) or by WINDOWS (BASELINE configs[3] as worded: every rank holds all points)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
@@ -581,6 +686,11 @@ def main():
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
     ap.add_argument("--pmc-summary", default="profiles/r05/pmc_summary_bench_steps3.json")
     ap.add_argument("--msm-pmc-summary", default="profiles/r05/pmc_summary_msm26_steps1.json")
+    ap.add_argument("--shared-gpu-dry-run", action="store_true",
+                    help="TEST MODE for boxes with ONE GPU: the N ranks of --gpus N all use device 0 (RCCL refuses that, so the process group "
+                         "is gloo and the library's exchange runs over the all-gather double tests/fake_rccl).  Exercises the real spawn, "
+                         "rank-0-only emit, max-over-ranks timing and the world-size refusal; the line is marked dry_run_shared_gpu and its "
+                         "metric name says so -- it is NOT a scaling point")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 48 if args.workload == "proofs" else 3
@@ -608,11 +718,24 @@ def main():
               % (args.gpus, world), file=sys.stderr)
         return 2
     _need_torch()
+    dry = args.shared_gpu_dry_run
+    if dry:
+        # every rank on device 0; the library's zkmi_comm exchange over the shared-memory double (absolute path, our own file:
+        # csrc/comm.hip accepts nothing else from the environment)
+        local_rank = 0
+        fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+        if not os.path.exists(fake):
+            print("bench.py --shared-gpu-dry-run: %s not built (make -C tests/fake_rccl)" % fake, file=sys.stderr)
+            return 2
+        os.environ["ZKMI_RCCL_LIB"] = fake
     torch.cuda.set_device(local_rank)
     # launched by torch.distributed.run (any world size, also 1): RCCL process group, used only for the
     # barriers around the timed region and the max-over-ranks of the elapsed time -- no data-path collective
     use_dist = launched and "MASTER_ADDR" in os.environ
-    if use_dist:
+    timed_region.reduce_device = "cpu" if dry else "cuda"
+    if use_dist and dry:
+        dist.init_process_group("gloo")
+    elif use_dist:
         # RCCL prints a version banner on STDOUT when its first communicator comes up (at the first collective): bring it
         # up here with fd 1 pointed at stderr, so that stdout carries nothing but rank 0's one JSON line
         with stdout_to_stderr():
@@ -626,6 +749,8 @@ def main():
     ctx = z.context(local_rank)
     if args.workload == "msm26":
         out, rc = run_msm26(args, pkg, z, ctx, rank, world, use_dist)
+        if dry:
+            mark_dry_run(out, world)
         if rank == 0:
             emit(out)
         ctx.close()

@@ -196,7 +196,7 @@ def test_proof_bytes_vs_cpp_oracle_at_the_relations_own_sizes(ctx, zk, which):
     else:
         lg, op_kind = 14, 0 if which == "deposit" else 1
         r1 = zk.update_note_r1cs(lg, op_kind)
-        inp, publics = _note_update_case(zk, 9100 + op_kind, op_kind, slot=op_kind)
+        inp, publics = _note_update_case(zk, 9100 + op_kind, op_kind, slot=1 - op_kind)  # (withdraw from the 1 000 balance)
         wit, pub, rc = zk.update_note_witness(lg, op_kind, inp)
         assert rc == 0 and pub == publics
     _proof_bytes_against_the_oracle(ctx, zk, r1, wit, publics, 0x5A4B0100 + lg + len(which))
@@ -419,7 +419,8 @@ VARIANTS = [
     {"ZKMI_HEAVY_NC": "0"}, {"ZKMI_HEAVY_NC": "0", "ZKMI_HEAVY_ON": "0"}, {"ZKMI_HOST_WAIT": "0"},
     {"ZKMI_BIG_SORT": "0"}, {"ZKMI_BIG_FINE_LOG": "8"}, {"ZKMI_BIG_FINE_LOG": "9"}, {"ZKMI_WIN_TWO_LEVEL": "30", "ZKMI_SOLO_EVENT_ORDER": "0"}, {"ZKMI_WIN_TWO_LEVEL": "17"}, {"ZKMI_BIG_WSTAGE": "0", "ZKMI_SPLIT_PLAIN_RANK": "1"}, {"ZKMI_SORT_BIG": "1"},
     {"ZKMI_SOLO_FUSE_H": "0", "ZKMI_SOLO_G2_EARLY": "0"}, {"ZKMI_SOLO_MAX_LOG": "12", "ZKMI_G2_TREE_SPLIT": "0"}, {"ZKMI_SPREAD": "0"}, {"ZKMI_SOLO_SPLIT": "0"}, {"ZKMI_FORCE_MULTI": "1"}, {"ZKMI_FORCE_MULTI": "1", "ZKMI_SOLO_SPLIT": "0"},
-    {"ZKMI_QUAD": "0"}, {"ZKMI_QUAD": "5"}, {"ZKMI_QUAD": "10"}, {"ZKMI_QUAD": "15", "ZKMI_HEAVY_NC": "0"},
+    {"ZKMI_QUAD": "0", "ZKMI_QUAD_BATCH": "0", "ZKMI_QUAD_G2": "0", "ZKMI_QUAD_G2_BATCH": "0"}, {"ZKMI_QUAD": "5", "ZKMI_QUAD_BATCH": "10", "ZKMI_QUAD_G2": "10", "ZKMI_QUAD_G2_BATCH": "5"},
+    {"ZKMI_QUAD": "10", "ZKMI_QUAD_BATCH": "5", "ZKMI_QUAD_G2": "5", "ZKMI_QUAD_G2_BATCH": "10"}, {"ZKMI_QUAD_BATCH": "15", "ZKMI_QUAD_G2_BATCH": "15", "ZKMI_HEAVY_NC": "0"},
 ]
 EXP_LIB = os.path.join(ROOT, "zk-apps_amd", "libzkmi_exp.so")
 

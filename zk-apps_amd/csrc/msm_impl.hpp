@@ -1674,7 +1674,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   // Two contexts: ONE MSM or ONE proof by itself (host_spin: the latency path -- a chain of 4 products per dependent addition
   // instead of 14) and the batch prover's pipeline (throughput: the quad form issues 16 products for the 14 of the formula
   // plus its exchanges, 1.37 x the instructions of the one-lane addition).
-  const int quad_mask = std::is_same<F, Fq2_28>::value ? 0 : host_spin ? ZK_TUNE("ZKMI_QUAD", 15) : ZK_TUNE("ZKMI_QUAD_BATCH", 12);
+  // G2 (the octet form, 8 lanes per point): ZKMI_QUAD_G2 / ZKMI_QUAD_G2_BATCH.
+  constexpr bool g2_engine = std::is_same<F, Fq2_28>::value;
+  const int quad_mask = g2_engine ? (host_spin ? ZK_TUNE("ZKMI_QUAD_G2", 15) : ZK_TUNE("ZKMI_QUAD_G2_BATCH", 12))
+                                  : (host_spin ? ZK_TUNE("ZKMI_QUAD", 15) : ZK_TUNE("ZKMI_QUAD_BATCH", 12));
+  using QPT = typename std::conditional<g2_engine, XYZZQ<Fq28, 0, true>, XYZZQ<F, 0, false>>::type;
+  constexpr uint32_t QPW = g2_engine ? 8u : 16u;  // points per wave of the quad / octet kernels
   const bool quad_reduce_ok = pl.shared || pl.c <= 16;
 #ifdef ZKMI_EXPERIMENTS
   const int accum_block = ZK_TUNE("ZKMI_ACCUM_BLOCK", 64) == 256 ? 256 : 64;
@@ -1729,7 +1734,11 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         hipLaunchKernelGGL((k_accum_heavy_nc<F, 3>), dim3(6144), dim3(64), 0, heavy_stream[m], d_bases[m], sort.sorted, hplan, pool_nc);
     }
     const uint32_t* const plan_arg = nc ? hplan : nullptr;
-    if constexpr (std::is_same<F, Fq2_28>::value) {
+    if (nc && (quad_mask & 8)) {
+      // both modes of the plan in one-wave workgroups of quads / octets: nothing of 300 registers has to find a SIMD beside the accumulation
+      hipLaunchKernelGGL(k_heavy_q<QPT>, dim3(1024), dim3(64), 0, heavy_stream[m], d_bases[m], sort.begin, sort.count, sort.heavy,
+                         sort.sorted, bk_of(m), hp, tk, hplan, pool_nc);
+    } else if constexpr (std::is_same<F, Fq2_28>::value) {
       hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, 0u,
                          wide_tail ? MSM_HEAVY_CAP : 0xffffffffu, plan_arg, pool_nc);
@@ -1737,10 +1746,6 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         hipLaunchKernelGGL(k_accum_heavy_g2_split<0>, dim3(1, 4096), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, heavy_stream[m],
                            d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, MSM_HEAVY_CAP, 0xffffffffu,
                            (const uint32_t*)nullptr, pool_nc);
-    } else if (nc && (quad_mask & 8)) {
-      // both modes of the plan in one-wave workgroups of quads: nothing of 300 registers has to find a SIMD beside the accumulation
-      hipLaunchKernelGGL(k_heavy_q<F>, dim3(1024), dim3(64), 0, heavy_stream[m], d_bases[m], sort.begin, sort.count, sort.heavy,
-                         sort.sorted, bk_of(m), hp, tk, hplan, pool_nc);
     } else {
       hipLaunchKernelGGL(k_accum_heavy<F>, dim3(MSM_HSPLIT, 8), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, heavy_stream[m],
                          d_bases[m], sort.begin, sort.count, sort.heavy, sort.sorted, bk_of(m), hp, tk, into_of(m) ? 1u : 0u, 0u,
@@ -1921,12 +1926,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       // after the accumulation (it writes the list), in front of the reduction (it reads the buckets);
       // heavy buckets are never listed, so the heavy kernels may still be running
       uint32_t* const redo = redo_of(m);
-      if constexpr (std::is_same<F, Fq2_28>::value)
+      if (quad_mask & 4)
+        hipLaunchKernelGGL(k_accum_redo_q<QPT>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
+                           redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
+      else if constexpr (std::is_same<F, Fq2_28>::value)
         hipLaunchKernelGGL(k_accum_redo_g2_split<0>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 32, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk,
                            redo, redo + cap_buckets + 1);
-      else if (quad_mask & 4)
-        hipLaunchKernelGGL(k_accum_redo_q<F>, dim3(64), dim3(64), 0, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
-                           redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
       else
         hipLaunchKernelGGL(k_accum_redo<F>, dim3(64), dim3(64), sizeof(XYZZ<F>) * 64, st_reduce, d_bases[m], sort.begin, sort.count, sort.sorted, bk, redo,
                            redo + cap_buckets + 1, into_of(m) ? 1u : 0u);
@@ -1939,8 +1944,12 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     XYZZ<F>* const ssum = segsum + (size_t)slot * seg_cap;
     XYZZ<F>* const sw = segw + (size_t)slot * seg_cap;
     if constexpr (is_g2) {
-      hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
-                         tot_segs, seg);
+      if ((quad_mask & 1) && quad_reduce_ok)
+        hipLaunchKernelGGL(k_segreduce_q<QPT>, dim3((tot_segs + QPW - 1) / QPW), dim3(64), 0, st_reduce, bk, ssum, sw, tot_segs, seg,
+                           (const XYZZ<F>*)nullptr, (const XYZZ<F>*)nullptr);
+      else
+        hipLaunchKernelGGL(k_segreduce_g2_split<0>, dim3((2 * tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw,
+                           tot_segs, seg);
     } else {
       const XYZZ<F>*bk2 = nullptr, *bk3 = nullptr;
       if (second_of(m)) {
@@ -1955,14 +1964,22 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
       if (!pl.shared && pl.c > 16)
         hipLaunchKernelGGL(k_segreduce_w2<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
       else if (quad_mask & 1)
-        hipLaunchKernelGGL(k_segreduce_q<F>, dim3((tot_segs + MSM_NQ - 1) / MSM_NQ), dim3(64), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
+        hipLaunchKernelGGL(k_segreduce_q<QPT>, dim3((tot_segs + QPW - 1) / QPW), dim3(64), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
       else
         hipLaunchKernelGGL(k_segreduce<F>, dim3((tot_segs + T - 1) / T), dim3(T), 0, st_reduce, bk, ssum, sw, tot_segs, seg, bk2, bk3);
     }
     XYZZ<HF>* dp = partial + (size_t)slot * SLOT_PTS;
     XYZZ<HF>* const hp_out = h_partial + (size_t)slot * SLOT_PTS;  // pinned host slot, written by the tree-sum kernels themselves
     XYZZ<F>* const stg = tree_stage + (size_t)slot * MSM_STAGE_PTS;
-    if constexpr (is_g2) {
+    if ((quad_mask & 2) && quad_reduce_ok) {
+      // one wave (16 quads / 8 octets) per slice of a job list; as many slices as make the two levels equally deep (a point
+      // walks len / (PER_WAVE slices) segments, the final sum slices / PER_WAVE), within the stage
+      uint32_t nq = 1;
+      while ((uint64_t)nq * nq * 4 <= segs_per_win) nq <<= 1;  // ~ sqrt(segs_per_win), rounded to a power of two
+      while (nq > 1 && ((uint64_t)njobs * pl.nwin * nq > MSM_STAGE_PTS || nq * QPW > segs_per_win)) nq >>= 1;
+      hipLaunchKernelGGL(k_treesum_q<QPT>, dim3(njobs, pl.nwin, nq), dim3(64), 0, st_reduce, ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
+      if (nq > 1) hipLaunchKernelGGL(k_treesum_final_q<QPT>, dim3(njobs, pl.nwin), dim3(64), 0, st_reduce, stg, nq, dp, hp_out);
+    } else if constexpr (is_g2) {
       if (nchunk > 1) {
         hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T / 2, st_reduce,
                            ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
@@ -1981,14 +1998,6 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
           hipLaunchKernelGGL(k_treesum_g2_split<0>, dim3(njobs, pl.nwin, 1), dim3(2 * MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                              ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
       }
-    } else if ((quad_mask & 2) && quad_reduce_ok) {
-      // one wave (16 quads) per slice of a job list; as many slices as make the two levels equally deep (a quad walks
-      // len / (16 slices) segments, the final sum slices / 16), within the stage
-      uint32_t nq = 1;
-      while ((uint64_t)nq * nq * 4 <= segs_per_win) nq <<= 1;  // ~ sqrt(segs_per_win), rounded to a power of two
-      while (nq > 1 && ((uint64_t)njobs * pl.nwin * nq > MSM_STAGE_PTS || nq * MSM_NQ > segs_per_win)) nq >>= 1;
-      hipLaunchKernelGGL(k_treesum_q<F>, dim3(njobs, pl.nwin, nq), dim3(64), 0, st_reduce, ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);
-      if (nq > 1) hipLaunchKernelGGL(k_treesum_final_q<F>, dim3(njobs, pl.nwin), dim3(64), 0, st_reduce, stg, nq, dp, hp_out);
     } else {
       hipLaunchKernelGGL(k_treesum<F>, dim3(njobs, pl.nwin, nchunk), dim3(MSM_TREE_T), sizeof(XYZZ<F>) * MSM_TREE_T, st_reduce,
                          ssum, sw, segs_per_win, dp, plain_job, stg, hp_out);

@@ -27,6 +27,7 @@
 #pragma once
 #include "curve.hpp"
 #include "field28.hpp"
+#include <type_traits>
 
 #if defined(__HIPCC__)
 namespace zkmi {
@@ -71,9 +72,21 @@ __device__ __forceinline__ void dpp_fence(F& a) {
 
 // one coordinate of an XYZZ point per lane of a quad
 // (XCH = 1: the exchanges as ds_bpermute moves instead of DPP -- the self-test's cross-check of the DPP selectors)
-template <class F, int XCH = 0>
+//
+// EXT2 = true: G2.  A point takes an OCTET of lanes: lanes 0-3 hold the c0 components of X, Y, ZZ, ZZZ and lanes 4-7 the c1
+// components (Fq2 = Fq[u] / (u^2 + 1)); `v` is still ONE base-field value per lane.  The exchanges between coordinates are
+// the same quad_perm moves (they act inside each quad, i.e. on one component); a field product becomes the lane's component
+// of the Fq2 product, which needs the other component of both operands from lane ^ 4: two bank-masked DPP row shifts per limb
+// (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3).  Operands of an Fq2 lane product must be normalised (a column
+// sums two partial products: no spare bit), so the differences that the G1 form leaves lazy are carried here.
+template <class F, int XCH = 0, bool EXT2 = false>
 struct XYZZQ {
   F v;
+  static constexpr int LANES = EXT2 ? 8 : 4;          // lanes per point
+  static constexpr int PER_WAVE = 64 / LANES;         // points per wave
+  using Elem = typename std::conditional<EXT2, Fq2T<F>, F>::type;  // a coordinate in memory
+  using Point = XYZZ<Elem>;
+  using APoint = Affine<Elem>;
   template <int CTRL>
   __device__ __forceinline__ static F get(const F& a) {
     if constexpr (XCH == 0) {
@@ -96,50 +109,129 @@ struct XYZZQ {
       return __shfl(f ? 1 : 0, (lane & ~3) | ((CTRL >> (2 * k)) & 3)) != 0;
     }
   }
+  // the value lane ^ 4 holds (the other Fq2 component of the same coordinate); EXT2 only
+  __device__ __forceinline__ static int other_word(int x) {
+    if constexpr (XCH == 0) {
+      const int t = __builtin_amdgcn_update_dpp(x, x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);  // lanes 0-3, 8-11 <- lane + 4
+      return __builtin_amdgcn_update_dpp(t, x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);          // lanes 4-7, 12-15 <- lane - 4
+    } else {
+      return __shfl(x, (int)((threadIdx.x & 63u) ^ 4u));
+    }
+  }
+  __device__ __forceinline__ static F other(const F& a) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) r.l[i] = other_word(a.l[i]);
+    return r;
+  }
   __device__ __forceinline__ static uint32_t q() { return threadIdx.x & 3u; }
+  __device__ __forceinline__ static uint32_t comp() { return EXT2 ? (threadIdx.x >> 2) & 1u : 0u; }
+  // index of this lane's value among the base-field values of a point / affine point in memory
+  __device__ __forceinline__ static uint32_t slot() { return EXT2 ? 2u * q() + comp() : q(); }
+  __device__ __forceinline__ static uint32_t aslot() { return EXT2 ? 2u * (q() & 1u) + comp() : (q() & 1u); }
+
+  // ---- the field operations of the formulas: base field, or this lane's component of Fq2 ----
+  __device__ __forceinline__ static F fmul(const F& a, const F& b) {
+    if constexpr (!EXT2) {
+      return F::mul_inline(a, b);
+    } else {
+      // c0 = a0 b0 - a1 b1 (comp 0: own * own - other * other); c1 = a0 b1 + a1 b0 (comp 1: own * other + other * own):
+      // a.v * X + other(a) * Y with X = comp ? other(b) : b, Y = comp ? b : -other(b); one reduction (field28.hpp Fq2P)
+      constexpr int NL = F::NL;
+      const bool c1 = comp() != 0u;
+      int64_t T[2 * NL];
+#pragma unroll
+      for (int i = 0; i < 2 * NL; i++) T[i] = 0;
+      const F pb = other(b);
+      {
+        const F X = quad_sel(c1, pb, b);
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+#pragma unroll
+          for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.l[i] * X.l[j];
+      }
+      {
+        const F pa = other(a);
+        F Y;
+#pragma unroll
+        for (int i = 0; i < NL; i++) Y.l[i] = c1 ? b.l[i] : -pb.l[i];
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+#pragma unroll
+          for (int j = 0; j < NL; j++) T[i + j] += (int64_t)pa.l[i] * Y.l[j];
+      }
+      return F::reduce(T);
+    }
+  }
+  // a - b / 2 a as operands of a product: lazy in the base field, carried for Fq2 lane products
+  __device__ __forceinline__ static F fsub(const F& a, const F& b) {
+    if constexpr (EXT2) return a - b;
+    else return a.sub_lazy(b);
+  }
+  __device__ __forceinline__ static F fdbl(const F& a) {
+    if constexpr (EXT2) return a.dbl();
+    else return a.add_lazy(a);
+  }
+  // the element this lane holds a component of is zero (a product: exact, field28.hpp is_zero)
+  // (the exchange is executed by ALL lanes, never behind a short-circuit: a lane that skipped it would be a disabled DPP
+  // source for its partner -- the c1 component of ZZ = 1 is zero, so "mine && other" diverged inside every octet of an
+  // affine point: round-6 self-test)
+  __device__ __forceinline__ static bool fzero(const F& a) { return both(a.is_zero()); }
+  __device__ __forceinline__ static bool both(bool f) {  // f on both components
+    if constexpr (EXT2) {
+      const int o = other_word(f ? 1 : 0);
+      return f & (o != 0);
+    } else {
+      return f;
+    }
+  }
+  __device__ __forceinline__ static bool either(bool f) {
+    if constexpr (EXT2) {
+      const int o = other_word(f ? 1 : 0);
+      return f | (o != 0);
+    } else {
+      return f;
+    }
+  }
+  __device__ __forceinline__ static F fone() { return comp() ? F::zero() : F::one(); }
+
   __device__ __forceinline__ static XYZZQ infinity() { return {F::zero()}; }
-  // ZZ = 0 (lane 2), known to all four lanes
-  __device__ __forceinline__ bool is_inf() const { return flag<QP_B2>(v.is_zero()); }
-  // memory form: XYZZ<F> = x | y | zz | zzz, lane q reads / writes coordinate q (a quad moves one contiguous point)
-  __device__ __forceinline__ static XYZZQ load(const XYZZ<F>* p) {
-    XYZZQ r;
-    const F* s = reinterpret_cast<const F*>(p) + q();
+  // ZZ = 0 (lane 2 of each quad), known to all lanes of the point
+  __device__ __forceinline__ bool is_inf() const { return flag<QP_B2>(fzero(v)); }
+  // memory form: x | y | zz | zzz (Fq2: c0 | c1 inside each); the lanes of a point move one contiguous point
+  __device__ __forceinline__ static F load_f(const F* s) {
+    F r;
     constexpr int W = sizeof(F) / 8;
     const uint2* s2 = reinterpret_cast<const uint2*>(s);
 #pragma unroll
     for (int i = 0; i < W; i++) {
       const uint2 w = s2[i];
-      r.v.l[2 * i] = (int32_t)w.x;
-      r.v.l[2 * i + 1] = (int32_t)w.y;
+      r.l[2 * i] = (int32_t)w.x;
+      r.l[2 * i + 1] = (int32_t)w.y;
     }
     return r;
   }
-  __device__ __forceinline__ void store(XYZZ<F>* p) const {
-    F* d = reinterpret_cast<F*>(p) + q();
+  __device__ __forceinline__ static XYZZQ load(const Point* p) { return {load_f(reinterpret_cast<const F*>(p) + slot())}; }
+  __device__ __forceinline__ void store(Point* p) const {
+    F* d = reinterpret_cast<F*>(p) + slot();
     constexpr int W = sizeof(F) / 8;
     uint2* d2 = reinterpret_cast<uint2*>(d);
 #pragma unroll
     for (int i = 0; i < W; i++) d2[i] = make_uint2((uint32_t)v.l[2 * i], (uint32_t)v.l[2 * i + 1]);
   }
   // an affine table entry (+- by the digit's sign) as an XYZZ point: (x, +-y, 1, 1), or infinity for the all-zero entry
-  __device__ __forceinline__ static XYZZQ from_affine(const Affine<F>* p, bool negate) {
+  __device__ __forceinline__ static XYZZQ from_affine(const APoint* p, bool negate) {
     const uint32_t k = q();
     XYZZQ r;
-    const F* s = reinterpret_cast<const F*>(p) + (k & 1u);
-    constexpr int W = sizeof(F) / 8;
-    const uint2* s2 = reinterpret_cast<const uint2*>(s);
+    r.v = load_f(reinterpret_cast<const F*>(p) + aslot());  // lanes 2 and 3 load x and y once more
     uint32_t any = 0;
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-      const uint2 w = s2[i];
-      r.v.l[2 * i] = (int32_t)w.x;
-      r.v.l[2 * i + 1] = (int32_t)w.y;
-      any |= w.x | w.y;
-    }
-    // lanes 2 and 3 loaded x and y once more: the OR over the quad of what lanes 0 and 1 hold decides infinity
-    const bool fin = flag<QP_B0>(any != 0) || flag<QP_B1>(any != 0);
+    for (int i = 0; i < F::NL; i++) any |= (uint32_t)r.v.l[i];
+    // the OR over what lanes 0 and 1 (of every component) hold decides infinity
+    const bool f0 = flag<QP_B0>(any != 0), f1 = flag<QP_B1>(any != 0);
+    const bool fin = either(f0 | f1);
     if (negate && k == 1u) r.v = r.v.neg();
-    if (k >= 2u) r.v = fin ? F::one() : F::zero();
+    if (k >= 2u) r.v = fone();
     if (!fin) r.v = F::zero();
     return r;
   }
@@ -148,8 +240,8 @@ struct XYZZQ {
   __device__ __forceinline__ void dbl_nonzero() {
     const uint32_t k = q();
     // round 1   lane 0: X^2    lane 1: V = (2 Y)^2
-    const F a1 = quad_sel(k == 1u, v.add_lazy(v), v);
-    const F m1 = F::mul_inline(a1, a1);
+    const F a1 = quad_sel(k == 1u, fdbl(v), v);
+    const F m1 = fmul(a1, a1);
     // M = 3 X^2 (carried: it is squared below), on lanes 0 and 3
     F m = get<QP_B0>(m1);
 #pragma unroll
@@ -159,7 +251,7 @@ struct XYZZQ {
     // round 2   lane 0: S = X V    1: W = (2 Y) V    2: ZZ3 = ZZ V    3: M^2
     const F a2 = quad_sel(k == 3u, m, a1);
     const F b2 = quad_sel(k == 3u, m, vv);
-    const F m2 = F::mul_inline(a2, b2);
+    const F m2 = fmul(a2, b2);
     // X3 = M^2 - 2 S on lane 0
     const F msq = get<QP_3103>(m2);
     F x3;
@@ -169,8 +261,8 @@ struct XYZZQ {
     const F w = get<QP_B1>(m2);
     // round 3   lane 0: M (S - X3)    1: W Y    3: ZZZ3 = W ZZZ
     const F a3 = quad_sel(k == 0u, m, v);
-    const F b3 = quad_sel(k == 0u, m2.sub_lazy(x3), w);
-    const F m3 = F::mul_inline(a3, b3);
+    const F b3 = quad_sel(k == 0u, fsub(m2, x3), w);
+    const F m3 = fmul(a3, b3);
     // Y3 = M (S - X3) - W Y on lane 1
     const F t0 = get<QP_0023>(m3);
     F y3 = t0 - m3;
@@ -178,28 +270,28 @@ struct XYZZQ {
   }
 
   // this += o, complete (either may be infinity, o = +-this)
-  // (DBG: the self-test's view of the intermediate values -- dbg[6 * 4] per quad, coordinate-major like a point)
+  // (DBG: the self-test's view of the intermediate values -- dbg[6 * LANES] per point, slot-major like a point)
   template <bool DBG = false>
   __device__ __forceinline__ void add(const XYZZQ& o, F* dbg = nullptr) {
     const uint32_t k = q();
-    if (o.is_inf()) return;  // quad-uniform
+    if (o.is_inf()) return;  // uniform over the lanes of the point
     if (is_inf()) {
       v = o.v;
       return;
     }
-    const F m1 = F::mul_inline(v, get<QP_ROT2>(o.v));
-    const F d = get<QP_ROT2>(m1).sub_lazy(m1);
+    const F m1 = fmul(v, get<QP_ROT2>(o.v));
+    const F d = fsub(get<QP_ROT2>(m1), m1);
     const bool low = k < 2u;
-    const F m2 = F::mul_inline(quad_sel(low, d, v), quad_sel(low, d, o.v));
-    const bool z = m2.is_zero();
+    const F m2 = fmul(quad_sel(low, d, v), quad_sel(low, d, o.v));
+    const bool z = fzero(m2);
     if (flag<QP_B0>(z)) {  // P = 0: the same x
       if (flag<QP_B1>(z)) dbl_nonzero();  // R = 0: o = this
-      else v = F::zero();                      // o = -this
+      else v = F::zero();                 // o = -this
       return;
     }
     const F pp = get<QP_B0>(m2);
     const F u1 = get<QP_0023>(m1);
-    const F m3 = F::mul_inline(quad_sel(k == 0u, d, quad_sel(k == 1u, u1, m2)), pp);
+    const F m3 = fmul(quad_sel(k == 0u, d, quad_sel(k == 1u, u1, m2)), pp);
     // X3 = RR - PPP - 2 Q on lanes 0 and 1 (lane 0: RR, Q from lane 1; lane 1: PPP from lane 0)
     const F s2 = get<QP_SWAP>(m2), s3 = get<QP_SWAP>(m3);
     const bool l0 = k == 0u;
@@ -212,8 +304,8 @@ struct XYZZQ {
     const F s1_or_p = get<QP_0110>(quad_sel(k == 0u, d, m1));  // lane 2: S1 (lane 1's m1); lane 3: P (lane 0's d)
     const F ppp = get<QP_B0>(m3);
     const F a4 = quad_sel(k == 1u, d, quad_sel(k == 2u, s1_or_p, m3));
-    const F b4 = quad_sel(k == 1u, m3.sub_lazy(x3), quad_sel(k == 2u, ppp, s1_or_p));
-    const F m4 = F::mul_inline(a4, b4);
+    const F b4 = quad_sel(k == 1u, fsub(m3, x3), quad_sel(k == 2u, ppp, s1_or_p));
+    const F m4 = fmul(a4, b4);
     // (own - dpp(own)): the fence keeps the DPP move from being folded into the subtraction.  Folded, the compiler emits
     // v_subrev_u32_dpp vD, vM, vM quad_perm:[0,2,2,3] -- and on gfx950 that instruction returned dpp(vM) - vM, the NEGATED
     // difference (self-test of round 6, limb by limb: profiles/r06/experiments/quad_add_subrev_dpp.txt); every other
@@ -222,22 +314,22 @@ struct XYZZQ {
     dpp_fence(sub);
     const F y3 = m4 - sub;
     if constexpr (DBG) {
-      dbg[0 * 4 + k] = m1;
-      dbg[1 * 4 + k] = d;
-      dbg[2 * 4 + k] = m2;
-      dbg[3 * 4 + k] = m3;
-      dbg[4 * 4 + k] = x3;
-      dbg[5 * 4 + k] = m4;
+      dbg[0 * LANES + slot()] = m1;
+      dbg[1 * LANES + slot()] = d;
+      dbg[2 * LANES + slot()] = m2;
+      dbg[3 * LANES + slot()] = m3;
+      dbg[4 * LANES + slot()] = x3;
+      dbg[5 * LANES + slot()] = m4;
     }
     v = quad_sel(k == 0u, x3, quad_sel(k == 1u, y3, quad_sel(k == 2u, m3, m4)));
   }
 };
 
-// the quads of a wave summed into quad 0 (quad-uniform control flow; ds_bpermute moves, no LDS allocation)
-template <class F, int XCH>
-__device__ __forceinline__ XYZZQ<F, XCH> wave_quad_sum(XYZZQ<F, XCH> acc) {
-  for (int s = 32; s >= 4; s >>= 1) {
-    XYZZQ<F, XCH> o;
+// the points of a wave summed into point 0 (control flow uniform per point; ds_bpermute moves, no LDS allocation)
+template <class F, int XCH, bool EXT2>
+__device__ __forceinline__ XYZZQ<F, XCH, EXT2> wave_quad_sum(XYZZQ<F, XCH, EXT2> acc) {
+  for (int s = 32; s >= XYZZQ<F, XCH, EXT2>::LANES; s >>= 1) {
+    XYZZQ<F, XCH, EXT2> o;
 #pragma unroll
     for (int i = 0; i < F::NL; i++) o.v.l[i] = __shfl_down(acc.v.l[i], s);
     if ((threadIdx.x & 63u) < (uint32_t)s) acc.add(o);
