@@ -935,7 +935,36 @@ def main():
                                     "ms": pmc_traffic.alone_ms, "achieved": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6,
                                     "frac_of_peak_at_2.4GHz": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6 / (VALU_ISSUE_PEAK_ACTUAL_MIX / 1e9),
                                     "frac_of_peak_at_held_clock": pmc_traffic.valu / pmc_traffic.alone_ms / 1e6 / (VALU_ISSUE_PEAK_ACTUAL_MIX / 1e9 * held / 2.4)}}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_secondary and log_n == 20:
+        # the other BASELINE configs' one-GPU figures in the same driver-run line: configs[1]'s NTT alone,
+        # configs[3] on ONE GPU (a step of --workload msm26: the same function), configs[4] at 2^22
+        if pk is not None:
+            pk.free()
+            pk = None
+        del d_wits
+        torch.cuda.empty_cache()
+        out["ntt_2p20"] = ntt_alone(z, ctx, 20, args.pmc_summary)
+        saved = {k: getattr(pmc_traffic, k) for k in ("valu", "name", "total_valu", "source", "held_clock_ghz", "alone_ms")}
+        margs = argparse.Namespace(**vars(args))
+        margs.steps, margs.warmup, margs.split, margs.msm_log_n = 2, 1, "points", 26
+        t0 = time.time()
+        m26, rc26 = run_msm26(margs, pkg, z, ctx, 0, 1, False)
+        for k, v in saved.items():
+            setattr(pmc_traffic, k, v)
+        out["msm26_n1"] = {"ms": m26["ms_per_step"], "GBps": m26["value"], "frac_of_hbm_peak": m26["frac_of_hbm_peak"],
+                           "matches_closed_form": m26["matches_closed_form_on_every_rank"], "phase_ms_per_msm": m26["phase_ms_per_msm"],
+                           "roofline": m26["roofline"], "block_seconds": time.time() - t0,
+                           "what": "BASELINE configs[3] on ONE GPU: one G1 MSM of 2^26 points (8 GiB algorithmic), the body of "
+                                   "`bench.py --workload msm26`, 2 timed steps"}
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        out["config4"] = config4_block(z, ctx, args.relation)
+        out["config4"]["block_seconds"] = time.time() - t0
+    if dry:
+        mark_dry_run(out, world)
+    if rank == 0 and not args.no_cpu_baseline:
+        # (at world > 1 too: the other ranks are past their timed region -- the barrier inside timed_region -- and only wait
+        # in destroy_process_group; a line without it reads as unmeasured)
         out["cpu_baseline"] = cpu_baseline(z, ctx, min(args.cpu_sample_log_n, log_n), log_n, args.relation)
     if rank == 0:
         emit(out)

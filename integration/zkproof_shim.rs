@@ -80,8 +80,34 @@ fn fresh_rs() -> [u8; 64] {
     rs
 }
 
+/// serde for the 192 proof bytes: the reference derives `serde::Serialize, serde::Deserialize` on `ZkProof`
+/// (relations.rs:15) and serde implements neither for `[u8; 192]` (its array impls stop at 32), so the derive needs this
+/// `with`-module (the `serde-big-array` crate's `BigArray` does the same; written out here so the shim adds no dependency).
+/// Wire form: a 192-tuple of u8, i.e. exactly what `[u8; N]` serialises to for N <= 32.
+mod proof_bytes_serde {
+    use serde::{de::{Error, SeqAccess, Visitor}, ser::SerializeTuple, Deserializer, Serializer};
+    pub fn serialize<S: Serializer>(v: &[u8; 192], s: S) -> Result<S::Ok, S::Error> {
+        let mut t = s.serialize_tuple(192)?;
+        for b in v { t.serialize_element(b)?; }
+        t.end()
+    }
+    pub fn deserialize<'de, D: Deserializer<'de>>(d: D) -> Result<[u8; 192], D::Error> {
+        struct V;
+        impl<'de> Visitor<'de> for V {
+            type Value = [u8; 192];
+            fn expecting(&self, f: &mut core::fmt::Formatter) -> core::fmt::Result { f.write_str("192 proof bytes") }
+            fn visit_seq<A: SeqAccess<'de>>(self, mut a: A) -> Result<[u8; 192], A::Error> {
+                let mut out = [0u8; 192];
+                for (i, o) in out.iter_mut().enumerate() { *o = a.next_element()?.ok_or_else(|| A::Error::invalid_length(i, &self))?; }
+                Ok(out)
+            }
+        }
+        d.deserialize_tuple(192, V)
+    }
+}
+
 #[ink::scale_derive(Encode, Decode, TypeInfo)]
-#[derive(Debug, Clone, Copy)]
+#[derive(Debug, Clone, Copy, serde::Serialize, serde::Deserialize)]  // the reference's derives (relations.rs:14-15)
 pub struct ZkProof {
     id: Scalar,
     trapdoor_new: Scalar,
@@ -93,6 +119,7 @@ pub struct ZkProof {
     merkle_proof: [Scalar; MERKLE_TREE_DEPTH],
     merkle_proof_leaf_id: u32,
     /// Groth16 proof of the relation this value was produced by (creation or update), compressed A || B || C
+    #[serde(with = "proof_bytes_serde")]
     proof: [u8; 192],
     /// the Merkle root the last update was proved against (what the caller passes to the contract's update_note)
     merkle_root: Scalar,
@@ -179,7 +206,16 @@ impl ZkProof {
         }
     }
 
-    /// relations.rs:138-155, same arguments: the contract's update_note (contract/lib.rs:63-78)
+    /// relations.rs:138-155, same arguments: the contract's update_note (contract/lib.rs:63-78).
+    ///
+    /// PRECONDITION on `merkle_root` (where the drop-in is NOT a no-op for the caller): the relation proves membership of
+    /// the old note under a POSEIDON tree -- `CircuitMerkleProof::verify`, merkle_proof.rs:38-61, the same hash as the note
+    /// hashes -- while the mock contract keeps a SHA-256 tree (`contract/merkle.rs:48-106`) and the callers pass ITS root
+    /// (`drink_tests/utils/shielder.rs:85-91, 116-127`; the mock's `verify_update` recomputes that root with SHA-256,
+    /// relations.rs:147-153).  With real proofs the root handed in here must be the Poseidon root the proof was made
+    /// against: `update_account` returns it next to the proof (`ZkProof::merkle_root()`), `zkmi_poseidon_merkle_root_dev` /
+    /// the contract-side tree must be switched to Poseidon-5.  A SHA-256 root fails with
+    /// `ZkpError::VerificationError` -- it is a different public input, never a silent accept.
     pub fn verify_update(&self, op_pub: OpPub, h_note_new: Scalar, merkle_root: Scalar, nullifier_old: Scalar) -> Result<(), ZkpError> {
         let vk = VERIFYING_KEYS.get().ok_or(ZkpError::VerificationError)?;
         match unsafe {

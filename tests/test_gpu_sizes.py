@@ -4,6 +4,7 @@ multi-threaded restatement: seconds per case on the GPU box's host cores), plus 
 The smaller-size sweeps, golden fixtures and property tests live in test_gpu_parity.py; this file closes the gap the
 round-2 verdict named: NTT at 2^20 / 2^22 in all four modes, G1 MSM at 2^20 (uniform and witness-like), G2 MSM at 2^18
 (oracle) and 2^22 (closed form), full proof bytes at 2^18 and 2^20 over the ORACLE's own trusted setup."""
+import json
 import os
 import subprocess
 import sys
@@ -217,7 +218,7 @@ def test_update_note_proof_from_an_oracle_side_witness(ctx, zk, op_kind):
     r1 = zk.update_note_r1cs(lg, op_kind)
     rng = ec.SplitMix64(0xB0B + op_kind)
     tok = [rng.fr(), rng.fr()]
-    bal, amount, slot = [5000, 123], 321, op_kind
+    bal, amount, slot = [5000, 123], 321, 1 - op_kind  # (deposit into slot 1, withdraw from slot 0)
     new_note, old_note = (rng.fr(), rng.fr(), rng.fr()), (rng.fr(), rng.fr(), rng.fr())
     user = rng.fr()
     shape = [rng.next() & 1 for _ in range(height)]
@@ -408,9 +409,47 @@ def test_bench_gpus_gt_1_spawns_ranks_or_fails():
         assert p.returncode != 0 and not lines, p.stdout[-2000:]
 
 
+@pytest.mark.parametrize("world,workload", [(2, "proofs"), (8, "proofs"), (2, "msm26"), (8, "msm26")])
+def test_bench_multi_rank_path_as_a_shared_gpu_dry_run(world, workload):
+    """bench.py's N > 1 branch -- the exact command the driver's scaling step runs -- executed before an 8-GPU node meets it:
+    `bench.py --gpus N --shared-gpu-dry-run` spawns N ranks BEFORE touching HIP (spawn_ranks), every rank proves / owns its
+    share on device 0, the barriers and the max-over-ranks run over gloo, the library's exchange over tests/fake_rccl, and
+    rank 0 alone emits ONE JSON line with every contract key, `cpu_baseline` included; the line is marked and its metric name
+    cannot be mistaken for a scaling point.  LOCAL_WORLD_SIZE reaches the library: a rank's host threads = its share of
+    the CPUs the box grants."""
+    args = ["--gpus", str(world), "--shared-gpu-dry-run", "--warmup", "1", "--no-secondary", "--cpu-sample-log-n", "14"]
+    if workload == "proofs":
+        args += ["--steps", "3", "--log-n", "14"]
+    else:
+        args += ["--workload", "msm26", "--steps", "1", "--msm-log-n", "20", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "starting %d ranks" % world in p.stderr
+    o = lines[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in o, key
+    assert o["dry_run_shared_gpu"] is True and o["metric"].startswith("DRY_RUN_%d_ranks_sharing_one_gpu__" % world) and o["physical_gpus"] == 1
+    assert o["n_gpus"] == world and o["value"] > 0
+    if workload == "proofs":
+        assert o["verified_by_pairing"] is True and o["scaling"] == "weak"
+        assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["proof_bytes_match_gpu"] is True
+        h = o["host"]
+        assert h["local_ranks"] == world and h["threads"] == max(1, min(16, h["cpus_granted"] // world)), h
+        assert abs(o["value"] - world * o["steps"] / (o["ms_per_step"] * o["steps"] / 1e3)) < 1e-6 * o["value"]
+    else:
+        assert o["matches_closed_form_on_every_rank"] is True and o["scaling"] == "strong"
+    # a launcher with another world size is refused, dry run or not
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--shared-gpu-dry-run"], capture_output=True, text=True, env=env2, timeout=120)
+    assert p2.returncode == 2 and "refusing" in p2.stderr and "{" not in p2.stdout
+
+
 VARIANTS = [
     {},
-    {"ZKMI_NTT_RB": "0"}, {"ZKMI_NTT_RB": "1"}, {"ZKMI_NTT_RB": "2"}, {"ZKMI_NTT_RB": "4"}, {"ZKMI_NTT_RB": "5"},
+    {"ZKMI_NTT_RB": "0"}, {"ZKMI_NTT_RB": "1"}, {"ZKMI_NTT_RB": "2"}, {"ZKMI_NTT_RB": "3"}, {"ZKMI_NTT_RB": "4"}, {"ZKMI_NTT_RB": "5"},
     {"ZKMI_NTT_LOCAL3": "1", "ZKMI_WITNESS_BATCH": "0"},
     {"ZKMI_SORT_FINE": "0"}, {"ZKMI_SORT_FINE": "2"}, {"ZKMI_SORT_STAGE": "0"},
     {"ZKMI_HEAVY_ON": "0"}, {"ZKMI_HEAVY_ON": "1"},

@@ -469,7 +469,10 @@ hipError_t NttDomainT<F>::init(int log_n_, hipStream_t stream) {
 //       and the 8-element form costs the prover 2-3 % (one 256-VGPR wave per SIMD plus 105 KB of LDS leaves room for
 //       one accumulation wave instead of three beside it)
 //   4 / 5 = one-wave workgroups on 1024- / 512-element tiles (5: three passes of <= 7 stages at N = 2^20)
-static int ntt_rb_mode() { return ZK_TUNE("ZKMI_NTT_RB", 3); }
+//   6 (round 6, the product's): mode 3 with HALF tiles where a pass has a full 2^11-element one -- 2^10 elements on 512 threads,
+//       60 KiB of LDS, two workgroups per CU: 2^16 0.075 -> 0.063 ms, 2^20 0.292 -> 0.271, 2^22 1.205 -> 1.075 per transform
+//       through the C ABI (profiles/r06/experiments/ntt_half_tiles_ab.txt)
+static int ntt_rb_mode() { return ZK_TUNE("ZKMI_NTT_RB", 6); }
 
 #ifdef ZKMI_EXPERIMENTS
 template <class F, bool DIF, bool LTW, int LOGE, int LOGR = 0, bool ONEW = false>
@@ -516,7 +519,11 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
       // workgroup so that all 1024 threads own a butterfly in every stage
       Q = (t0 > 0) ? 1 : ((log_n > S) ? 1 : 0);
       // wide tiles for a short strided pass of a big transform (mode 3): 2^11 elements per tile, >= 512 tiles per vector
-      if (mode == 3 && t0 > 0 && S < 10 && log_n - 11 >= 9) Q = (11 - S < t0) ? 11 - S : t0;
+      if ((mode == 3 || mode == 6) && t0 > 0 && S < 10 && log_n - 11 >= 9) Q = (11 - S < t0) ? 11 - S : t0;
+      // mode 6 (round 6): HALF tiles -- 2^10 elements (40 KiB + 20 KiB of twiddles) on 512 threads, so that TWO workgroups
+      // share a CU's 160 KiB of LDS and one computes while the other waits at a barrier (the 2^11-element tile is the only
+      // workgroup on its CU: each of its 10 barriers idles the CU)
+      if (mode == 6 && S + Q == 11) Q -= 1;
     }
     passes[np++] = {t0, S, Q};
     t0 += S;
@@ -556,7 +563,12 @@ static hipError_t run_passes(F* buf, const F* tw, int log_n, const F* post, uint
     }
 #endif
     const size_t lds = ((size_t)tile_n + (local_tw ? (1u << (p.S - 1)) : 0u)) * sizeof(F);
-    if (tile_n >= 1024) {
+    if (tile_n == 1024 && mode == 6) {
+      if (local_tw)
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 512>), grid, dim3(512), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp, co);
+      else
+        hipLaunchKernelGGL((k_ntt_pass<F, DIF, false, 512>), grid, dim3(512), lds, stream, buf, tw, log_n, p.t0, p.S, p.Q, pp, co);
+    } else if (tile_n >= 1024) {
       if (local_tw)
         hipLaunchKernelGGL((k_ntt_pass<F, DIF, true, 1024>), grid, dim3(1024), lds, stream, buf, tw, log_n, p.t0, p.S,
                            p.Q, pp, co);
@@ -660,7 +672,15 @@ hipError_t ntt_enable_big_lds() {
                        reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, true, 1024>),
                        reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, true, 1024>),
                        reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, false, 1024>),
-                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, false, 1024>)};
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, false, 1024>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, true, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, false, true, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, true, false, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<Fr28, false, false, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, true, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, true, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, true, false, 512>),
+                       reinterpret_cast<const void*>(k_ntt_pass<BnFr28, false, false, 512>)};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
