@@ -248,7 +248,7 @@ def pmc_traffic(path, kernel):
     guide's x2 correction for 128-byte coalesced requests is NOT applied.
     A missing file or kernel yields traffic = None with a note (the timing above it stays valid)."""
     pmc_traffic.valu = pmc_traffic.name = pmc_traffic.total_valu = pmc_traffic.source = None
-    pmc_traffic.held_clock_ghz = pmc_traffic.alone_ms = None
+    pmc_traffic.held_clock_ghz = pmc_traffic.alone_ms = pmc_traffic.upper_bound = None
     if path == "none":
         return None, "PMC summary lookup disabled (--pmc-summary none)"
     try:
@@ -286,9 +286,18 @@ def pmc_traffic(path, kernel):
             pmc_traffic.valu = r.get("SQ_INSTS_VALU_avg_per_dispatch")
             pmc_traffic.held_clock_ghz = r.get("held_clock_ghz_avg_per_dispatch")
             pmc_traffic.alone_ms = (r.get("alone_ns_avg_per_dispatch") or 0) / 1e6 or None
+            # The guide's gfx950 correction (FETCH_SIZE tallies the 128-B requests of a wide COALESCED read -- 16 B per lane,
+            # adjacent lanes adjacent addresses -- at 64 B: double it) applies to streaming reads.  This kernel's reads are
+            # per-lane gathers of 112- / 224-byte table entries, 16 B per lane and instruction at 64 unrelated addresses: 64-B
+            # requests, counted exactly -- so `traffic` is the UNCORRECTED sum, and `traffic_upper_bound` = 2 x FETCH + WRITE
+            # is what it would be if every request were a mis-tallied 128-B one; the truth lies between, near the lower value.
+            pmc_traffic.upper_bound = (2.0 * fetch + write) * 1024.0
             return (fetch + write) * 1024.0, (
                 "bytes/launch = (FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) from %s (separate rocprofv3 --pmc passes of "
-                "this command; uncorrected: per-lane gathers of table entries, 64-B requests)" % (fetch, write, path))
+                "this command). UNCORRECTED for the gfx950 FETCH_SIZE half-count: that correction applies to wide coalesced "
+                "streaming reads (128-B requests tallied at 64 B), these are per-lane gathers of table entries (64-B requests, "
+                "counted exactly); upper bound if every request were half-counted: traffic_upper_bound = 2 x FETCH + WRITE"
+                % (fetch, write, path))
     return None, ("kernel %r has no FETCH_SIZE / WRITE_SIZE row in %s (stale summary: refresh with scripts/profile.sh): "
                   "traffic not reported" % (kernel, path))
 
@@ -299,6 +308,7 @@ pmc_traffic.total_valu = None
 pmc_traffic.source = None
 pmc_traffic.held_clock_ghz = None
 pmc_traffic.alone_ms = None
+pmc_traffic.upper_bound = None
 # 1024 SIMDs x 2.4 GHz / 4 cycles: v_mad_u64_u32 / v_mad_i64_i32 (77 % of the kernel's instructions) issue once per
 # 4 cycles per SIMD (scripts/ubench.hip); under this load the chip holds ~1.95 GHz, so ~500 G/s is what is attainable
 VALU_ISSUE_PEAK = 614.4e9
@@ -645,6 +655,7 @@ def run_msm26(args, pkg, z, ctx, rank, world, use_dist):
     if world == 1 and args.msm_pmc_summary != "none" and args.split == "points":
         traffic, note = pmc_traffic(args.msm_pmc_summary, "k_accum_g1_nc")
         out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_upper_bound"] = pmc_traffic.upper_bound
         out["roofline"]["traffic_note"] = note
         out["roofline"]["traffic_source"] = pmc_traffic.source
         if pmc_traffic.valu and avg_ms > 0:
@@ -684,14 +695,20 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the H2D-inclusive and whole-MSM measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation", choices=["poseidon", "chain"], default="poseidon")
-    ap.add_argument("--pmc-summary", default="profiles/r05/pmc_summary_bench_steps3.json")
-    ap.add_argument("--msm-pmc-summary", default="profiles/r05/pmc_summary_msm26_steps1.json")
+    ap.add_argument("--pmc-summary", default="profiles/r06/pmc_summary_bench_steps3.json")
+    ap.add_argument("--msm-pmc-summary", default="profiles/r06/pmc_summary_msm26_steps1.json")
     ap.add_argument("--shared-gpu-dry-run", action="store_true",
                     help="TEST MODE for boxes with ONE GPU: the N ranks of --gpus N all use device 0 (RCCL refuses that, so the process group "
                          "is gloo and the library's exchange runs over the all-gather double tests/fake_rccl).  Exercises the real spawn, "
                          "rank-0-only emit, max-over-ranks timing and the world-size refusal; the line is marked dry_run_shared_gpu and its "
                          "metric name says so -- it is NOT a scaling point")
     args = ap.parse_args()
+    for name in ("pmc_summary", "msm_pmc_summary"):
+        # (the newest committed summary; an older round's stands in until scripts/profile.sh has been run for this one --
+        # `traffic_source.same_sources_as_this_run` then reads false)
+        v = getattr(args, name)
+        if v != "none" and not os.path.exists(os.path.join(ROOT, v)) and "profiles/r06/" in v:
+            setattr(args, name, v.replace("profiles/r06/", "profiles/r05/"))
     if args.steps is None:
         args.steps = 48 if args.workload == "proofs" else 3
     if args.gpus < 1:
@@ -818,6 +835,7 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
+        "traffic_upper_bound": pmc_traffic.upper_bound,
         "traffic_note": traffic_note,
         "traffic_source": pmc_traffic.source,
         "avg_launch_ms": avg_ms,
@@ -944,7 +962,7 @@ def main():
         del d_wits
         torch.cuda.empty_cache()
         out["ntt_2p20"] = ntt_alone(z, ctx, 20, args.pmc_summary)
-        saved = {k: getattr(pmc_traffic, k) for k in ("valu", "name", "total_valu", "source", "held_clock_ghz", "alone_ms")}
+        saved = {k: getattr(pmc_traffic, k) for k in ("valu", "name", "total_valu", "source", "held_clock_ghz", "alone_ms", "upper_bound")}
         margs = argparse.Namespace(**vars(args))
         margs.steps, margs.warmup, margs.split, margs.msm_log_n = 2, 1, "points", 26
         t0 = time.time()

@@ -1635,7 +1635,9 @@ def test_2d_split_under_the_big_window_plan_at_world_8(window_groups):
     (zkmi_msm_g1_split2d_allgather), 2^24 points under their own plan -- the partitioned 20-bit windows, 13 windows, so the
     ranges own 6 + 7 resp. 3 + 3 + 3 + 4 windows and the spread top window sits in the last range -- over the all-gather
     double; every rank must reach the closed form.  (Ranks share GPU 0: nothing here says anything about RCCL or xGMI.)"""
-    out = _run_multigpu(8, ["--one-gpu", "--config", "3", "--msm-log-n", "24", "--window-groups", str(window_groups)])
+    # (only the 2-D leg: eight contexts with the workspaces of a 2^24 plan -- 12 bucket arrays of 13 x 2^19 buckets each -- already
+    # take most of the one GPU they share)
+    out = _run_multigpu(8, ["--one-gpu", "--config", "3", "--msm-log-n", "24", "--window-groups", str(window_groups), "--legs", "2d"])
     two_d = [o for o in out if "2-D split" in o.get("workload", "")]
     assert len(two_d) == 1 and two_d[0]["matches_closed_form_on_every_rank"] and two_d[0]["ranks"] == 8
     assert "%d point groups x %d window ranges" % (8 // window_groups, window_groups) in two_d[0]["workload"]

@@ -1809,6 +1809,21 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         continue;
       }
 #endif
+#ifdef ZKMI_EXPERIMENTS
+      if ((quad_mask & 16) && tot_b <= (1u << 16)) {
+        // one small MSM by itself: an octet per bucket (msm_quad.hpp k_accum_q) -- 4 products per entry instead of 10
+        if constexpr (g2_engine) {
+          AccumQArgs<QPT> qa;
+          for (int k = 0; k < MSM_MULTI_MAX; k++) {
+            qa.bases[k] = d_bases[m];
+            qa.buckets[k] = bk;
+            qa.sort[k] = view_of(m);
+          }
+          hipLaunchKernelGGL(k_accum_q<QPT>, dim3((tot_b + QPW - 1) / QPW, 1), dim3(64), 0, st, qa, tot_b);
+        }
+        continue;
+      }
+#endif
       hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
                          sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
     }
@@ -1823,6 +1838,21 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     }
     // small plans (one small proof): two lanes per bucket (A/B library: ZKMI_SOLO_SPLIT=0: one)
     const bool split2 = ZK_TUNE("ZKMI_SOLO_SPLIT", 1) != 0;
+#ifdef ZKMI_EXPERIMENTS
+    if ((quad_mask & 16) && tot_b <= (1u << 16)) {
+      // a quad per bucket (msm_quad.hpp k_accum_q): the complete law in line, no redo list
+      if constexpr (!g2_engine) {
+        AccumQArgs<QPT> qa;
+        for (int m = 0; m < MSM_MULTI_MAX; m++) {
+          const int k = m < nm ? m : 0;
+          qa.bases[m] = d_bases[k];
+          qa.buckets[m] = bk_of(k);
+          qa.sort[m] = view_of(k);
+        }
+        hipLaunchKernelGGL(k_accum_q<QPT>, dim3((tot_b + QPW - 1) / QPW, nm), dim3(64), 0, st, qa, tot_b);
+      }
+    } else
+#endif
     if (split2 && tot_b <= (1u << 16))
       hipLaunchKernelGGL((k_accum_g1_split2<F, 1>), dim3((2 * tot_b + 63) / 64, nm), dim3(64), 0, st, set, tot_b);
 #ifdef ZKMI_EXPERIMENTS

@@ -87,6 +87,49 @@ k_treesum_final_q(const typename PT::Point* __restrict__ stage, uint32_t nchunk,
   if (quad == 0) quad_store_host(acc, partial + idx, partial_host + idx);
 }
 
+#ifdef ZKMI_EXPERIMENTS
+// (A/B library only: measured in round 6, not adopted -- profiles/r06/experiments/quad_accumulation_ab.txt: at 4 - 8 lanes per
+// bucket the launch fills the chip instead of being a latency chain, and an entry costs 16 products where the mixed addition
+// needs 10: 2^14 unchanged, 2^16 2.85 -> 3.4 - 4.1 ms)
+// Bucket ACCUMULATION with a point (quad / octet) per bucket, for ONE small proof or ONE small MSM by itself: the launch is a
+// fraction of a millisecond of chip time but lasts as long as the fullest bucket's chain of dependent additions (17 entries
+// per bucket at 2^14: 0.7 ms in the lane-pair G2 kernel, whose mixed addition is a chain of 10 Fq2 products); here an entry
+// costs the 4 products of the quad form, the complete law handles P + P in line (no redo list), heavy buckets stay with the
+// heavy kernels.  grid = (ceil(buckets / PER_WAVE), MSMs of the launch); the next entry is loaded before the current addition.
+template <class PT>
+struct AccumQArgs {
+  const typename PT::APoint* bases[MSM_MULTI_MAX];
+  typename PT::Point* buckets[MSM_MULTI_MAX];
+  SortView sort[MSM_MULTI_MAX];
+};
+template <class PT>
+__global__ void __launch_bounds__(64, PT::LANES == 4 ? 3 : 2)
+k_accum_q(const AccumQArgs<PT> args, uint32_t total_buckets) {
+  const typename PT::APoint* __restrict__ const bases = args.bases[blockIdx.y];
+  typename PT::Point* __restrict__ const buckets = args.buckets[blockIdx.y];
+  const SortView& sv = args.sort[blockIdx.y];
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / PT::LANES;
+  if (t >= total_buckets) return;  // uniform per point
+  const uint32_t b = sv.perm[t];
+  const uint32_t cnt = sv.count[b];
+  if (cnt > sv.heavy_thr) return;  // the heavy-bucket kernels own it
+  const uint32_t beg = sv.begin[b], end = beg + cnt;
+  PT acc = PT::infinity();
+  if (beg < end) {
+    uint32_t v = sv.sorted[beg];
+    PT cur = PT::from_affine(bases + (v & 0x7fffffffu), (v >> 31) != 0);
+    for (uint32_t j = beg + 1; j < end; j++) {
+      v = sv.sorted[j];
+      const PT nxt = PT::from_affine(bases + (v & 0x7fffffffu), (v >> 31) != 0);
+      acc.add(cur);
+      cur = nxt;
+    }
+    acc.add(cur);
+  }
+  acc.store(buckets + b);
+}
+#endif  // ZKMI_EXPERIMENTS
+
 // k_accum_redo with a point (quad / octet) per stride of the listed bucket's entries (the entries enter as XYZZ points (x, +-y, 1, 1))
 template <class PT>
 __global__ void __launch_bounds__(64, PT::LANES == 4 ? 3 : 2)
