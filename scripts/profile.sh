@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every file under profiles/<round>/ in one command, on the GPU box, from the repo root:
 #
-#     bash scripts/profile.sh r05            # -> gpurun_out/prof_r05/{trace,pmc_*}/..., summaries in profiles/r05/
+#     bash scripts/profile.sh r06            # -> gpurun_out/prof_r06/{trace,pmc_*}/..., summaries in profiles/r06/
 # Run it LAST in a round, after the final commit that touches zk-apps_amd/csrc: the PMC summary is stamped with the digest
 # of those sources and bench.py compares it with the sources it runs (roofline.traffic_source.same_sources_as_this_run).
 #
@@ -9,7 +9,7 @@
 # collection are separate runs, and the counters are split over passes that fit the hardware slots
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: /opt/skills/guides/MI355X_MICROARCH.md, PMC slots).
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 OUT=gpurun_out/prof_$ROUND
 DST=profiles/$ROUND
 STEPS_TRACE=${STEPS_TRACE:-48}
@@ -33,7 +33,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAV
   > "$OUT/alone.log" 2>&1
 python3 scripts/kernel_alone_report.py "$OUT/alone" > "$DST/kernels_alone_bench_steps${STEPS_PMC}.txt" 2>> "$OUT/alone.log"
 # 2c. not under the profiler: the complete default bench line and the proof rate per domain size
-python3 scripts/domain_sweep.py 12 21 > "$DST/domain_sweep.txt" 2> "$OUT/domain_sweep.err"
+python3 scripts/domain_sweep.py 12 22 > "$DST/domain_sweep.txt" 2> "$OUT/domain_sweep.err"
 
 # 3. summaries that are small enough to commit
 STATS=$(find "$OUT/trace" -name '*_kernel_stats.csv' | head -1)

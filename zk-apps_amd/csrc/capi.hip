@@ -198,6 +198,7 @@ int32_t zkmi_ctx_create(int32_t device, zkmi_ctx** out_ctx) {
   zkmi_ctx* c = new (std::nothrow) zkmi_ctx();
   if (!c) return ZKMI_ERR_BAD_ARG;
   c->device = device;
+  c->g1.nslots = 2;                     // MSMs by themselves use slots 0 and 1; a key setup asks for all twelve (ensure_slots)
   c->g2.nslots = zkmi_ctx::PROOF_RING;  // one G2 MSM per proof in flight
   c->g1_bn.nslots = 1;                  // BN254 MSMs run one at a time
   int prio_lo = 0, prio_hi = 0;

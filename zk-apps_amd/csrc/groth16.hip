@@ -429,6 +429,7 @@ static hipError_t pk_alloc(zkmi_pk* pk, zkmi_ctx* ctx, const zkmi_r1cs* r) {
   if ((e = ctx->sort.reserve(cap, true)) != hipSuccess) return e;
   if (prover_sort_side() && (e = ctx->sort_z2.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->sort_h.reserve(cap, true)) != hipSuccess) return e;
+  if ((e = ctx->g1.ensure_slots(MsmEngine<Fq28>::SLOTS)) != hipSuccess) return e;  // three proofs in flight x four G1 MSMs
   if ((e = ctx->g1.reserve(cap, true)) != hipSuccess) return e;
   if ((e = ctx->g2.reserve(cap, true)) != hipSuccess) return e;
   if (G > 1) {

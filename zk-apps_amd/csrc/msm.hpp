@@ -177,6 +177,11 @@ struct MsmEngine {
   bool has_shared = false;
   hipError_t reserve(uint64_t n, bool shared_too = false);
   hipError_t reserve_buckets(uint64_t buckets);  // at least this many buckets per slot
+  // The buffers must serve at least n slots from now on.  A context starts with TWO (what an MSM by itself, the pipelined big
+  // MSM and the exchange collectives use: slots 0 and 1) -- a rank of a split 2^26-term MSM then holds 3 GB of bucket arrays
+  // instead of the 18 GB of the prover's twelve; a key setup asks for SLOTS.  Growing frees the buffers (the next reserve()
+  // rebuilds them); call it between synchronous entry points only.
+  hipError_t ensure_slots(int n);
   // device part: bucket accumulation + reduction down to per-window partials,
   // async copy of the partials to the host and an event; does not block
   // accumulation runs on `st`; the (low-occupancy, latency-bound) reduction runs on

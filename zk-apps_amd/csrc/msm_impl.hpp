@@ -1547,6 +1547,19 @@ void MsmEngine<F>::destroy_events() {
 }
 
 template <class F>
+hipError_t MsmEngine<F>::ensure_slots(int n) {
+  if (n > SLOTS) return hipErrorInvalidValue;
+  if (n <= nslots) return hipSuccess;
+  const bool sh = has_shared;
+  const uint64_t mb = min_buckets;
+  release();
+  has_shared = sh;
+  min_buckets = mb;
+  nslots = n;
+  return hipSuccess;
+}
+
+template <class F>
 hipError_t MsmEngine<F>::reserve_buckets(uint64_t buckets) {
   if (buckets <= cap_buckets) return hipSuccess;
   const bool sh = has_shared;
