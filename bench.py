@@ -381,7 +381,8 @@ def ntt_alone(z, ctx, log_n, pmc_path):
     except (OSError, ValueError):
         rows = []
     for r in rows:
-        if r.get("kernel", "").startswith("k_ntt_pass") and "1024" in r["kernel"] and r.get("alone_ns_avg_per_dispatch") and log_n == 20:
+        # (the full-size pass kernel: 512 threads since round 6, 1 024 before)
+        if r.get("kernel", "").startswith("k_ntt_pass") and ("512" in r["kernel"] or "1024" in r["kernel"]) and r.get("alone_ns_avg_per_dispatch") and log_n == 20:
             ms = r["alone_ns_avg_per_dispatch"] / 1e6
             out["pass_kernel"] = {"kernel": r["kernel"], "alone_ms_per_launch": ms,
                                   "valu_frac_of_issue_peak": r.get("SQ_INSTS_VALU_avg_per_dispatch", 0) / (ms * 1e-3) / VALU_ISSUE_PEAK,
