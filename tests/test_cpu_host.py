@@ -1048,6 +1048,7 @@ def test_kernel_register_budgets():
         "k_accum_g1_nc<Fq28,3,1,0,0>": (168, 0), "k_accum_g1_nc<Fq28,3,1,1,0>": (168, 0),
         "k_accum_g1_nc<BnFq28,3,1,0,0>": (168, 0), "k_accum_g2_nc<Fq2,2,1>": (256, 0),
         "k_accum_heavy_nc<Fq28,3>": (168, 96), "k_accum_heavy_nc_g2<Fq2,2>": (256, 0),
+        "k_accum_g2_split2<Fq2,0>": (320, 0),  # one wave per SIMD by design (one small G2 MSM by itself)
         # quad (G1, BN254 G1: <F, 0, 0>) and octet (G2: <Fq28, 0, 1>, two waves per SIMD) forms of the reduction-side kernels
         "k_segreduce_q<Fq28,0,0>": (168, 0), "k_treesum_q<Fq28,0,0>": (168, 0), "k_treesum_final_q<Fq28,0,0>": (168, 0),
         "k_accum_redo_q<Fq28,0,0>": (168, 0), "k_heavy_q<Fq28,0,0>": (168, 64),

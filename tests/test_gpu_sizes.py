@@ -459,7 +459,7 @@ VARIANTS = [
     {"ZKMI_BIG_SORT": "0"}, {"ZKMI_BIG_FINE_LOG": "8"}, {"ZKMI_BIG_FINE_LOG": "9"}, {"ZKMI_WIN_TWO_LEVEL": "30", "ZKMI_SOLO_EVENT_ORDER": "0"}, {"ZKMI_WIN_TWO_LEVEL": "17"}, {"ZKMI_BIG_WSTAGE": "0", "ZKMI_SPLIT_PLAIN_RANK": "1"}, {"ZKMI_SORT_BIG": "1"},
     {"ZKMI_SOLO_FUSE_H": "0", "ZKMI_SOLO_G2_EARLY": "0"}, {"ZKMI_SOLO_MAX_LOG": "12", "ZKMI_G2_TREE_SPLIT": "0"}, {"ZKMI_SPREAD": "0"}, {"ZKMI_SOLO_SPLIT": "0"}, {"ZKMI_FORCE_MULTI": "1"}, {"ZKMI_FORCE_MULTI": "1", "ZKMI_SOLO_SPLIT": "0"},
     {"ZKMI_QUAD": "0", "ZKMI_QUAD_BATCH": "0", "ZKMI_QUAD_G2": "0", "ZKMI_QUAD_G2_BATCH": "0"}, {"ZKMI_QUAD": "5", "ZKMI_QUAD_BATCH": "10", "ZKMI_QUAD_G2": "10", "ZKMI_QUAD_G2_BATCH": "5"},
-    {"ZKMI_QUAD": "10", "ZKMI_QUAD_BATCH": "5", "ZKMI_QUAD_G2": "5", "ZKMI_QUAD_G2_BATCH": "10"}, {"ZKMI_QUAD_BATCH": "15", "ZKMI_QUAD_G2_BATCH": "15", "ZKMI_HEAVY_NC": "0"}, {"ZKMI_QUAD": "31", "ZKMI_QUAD_G2": "31"},
+    {"ZKMI_QUAD": "10", "ZKMI_QUAD_BATCH": "5", "ZKMI_QUAD_G2": "5", "ZKMI_QUAD_G2_BATCH": "10"}, {"ZKMI_QUAD_BATCH": "15", "ZKMI_QUAD_G2_BATCH": "15", "ZKMI_HEAVY_NC": "0"}, {"ZKMI_QUAD": "31", "ZKMI_QUAD_G2": "31"}, {"ZKMI_SOLO_SPLIT_G2": "0", "ZKMI_HEAVY_DEFER": "1"},
 ]
 EXP_LIB = os.path.join(ROOT, "zk-apps_amd", "libzkmi_exp.so")
 

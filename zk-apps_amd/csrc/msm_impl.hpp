@@ -653,6 +653,87 @@ k_accum_g2_nc(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restri
   st_comp(dst + 6 + comp, acc.zzz.v);
 }
 
+// G2, TWO lane pairs per bucket (pair 0: entries beg, beg + 2, ...; pair 1: beg + 1, beg + 3, ...), pair 0 adds the two partial
+// sums at the end: k_accum_g1_split2's idea for the G2 launch of ONE small proof, which is 0.3 ms of chip time but lasts as long
+// as the fullest bucket's chain of dependent mixed additions (17 per bucket at 2^14: 0.65 ms, the longest link of a 1.9 ms
+// proof).  One wave per SIMD (the general addition on top of the loop's state does not fit 256 registers); only for plans of
+// <= 2^16 buckets on an otherwise idle chip.  A doubling in either half or in the final addition sends the bucket to the redo list.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64, 1)
+k_accum_g2_split2(const Affine<Fq2_28>* __restrict__ bases, const uint32_t* __restrict__ begin, const uint32_t* __restrict__ count,
+                  const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sorted, XYZZ<Fq2_28>* __restrict__ buckets,
+                  uint32_t total_buckets, uint32_t heavy_thr, uint32_t* __restrict__ redo) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = gt >> 2, sub = (gt >> 1) & 1u, comp = gt & 1u;
+  if (t >= total_buckets) return;  // quad-uniform
+  const uint32_t b = perm[t];
+  const uint32_t cnt = count[b];
+  if (cnt > heavy_thr) return;
+  const uint32_t beg = begin[b], end = beg + cnt;
+  Fq28* dst = reinterpret_cast<Fq28*>(buckets + b);  // x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1
+  auto load_point = [&](uint32_t v, Affine<Fq2P>& p) {  // true = the point at infinity (see k_accum_g2_nc)
+    const Fq28* src = reinterpret_cast<const Fq28*>(bases + (v & 0x7fffffffu));
+    p.x.v = ld_comp(src + comp);
+    p.y.v = ld_comp(src + 2 + comp);
+    uint32_t o = (uint32_t)p.y.v.l[0];
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+    if (o != 0) return false;
+#pragma unroll
+    for (int i = 0; i < Fq28::NL; i++) o |= (uint32_t)p.x.v.l[i] | (uint32_t)p.y.v.l[i];
+    o |= (uint32_t)__builtin_amdgcn_mov_dpp((int)o, 0xB1, 0xF, 0xF, true);
+    return o == 0;
+  };
+  XYZZ<Fq2P> acc = XYZZ<Fq2P>::infinity();
+  bool has = false, bad = false;
+  uint32_t j = beg + sub;
+  for (; j < end; j += 2) {  // this pair's first entry that is not the point at infinity starts its sum
+    Affine<Fq2P> p;
+    const uint32_t v = sorted[j];
+    if (load_point(v, p)) continue;
+    acc.x = p.x;
+    acc.y = (v >> 31) ? p.y.neg() : p.y;
+    acc.zz = Fq2P::one();
+    acc.zzz = Fq2P::one();
+    has = true;
+    j += 2;
+    break;
+  }
+  for (; j < end; j += 2) {
+    Affine<Fq2P> p;
+    const uint32_t v = sorted[j];
+    if (load_point(v, p)) continue;
+    if (!madd_generic(acc, p, 0u - (v >> 31))) {  // pair-uniform
+      bad = true;
+      break;
+    }
+  }
+  // the other pair's state and partial sum (lane ^ 2: the same component of the other pair)
+  const uint32_t flags = (has ? 1u : 0u) | (bad ? 2u : 0u);
+  const uint32_t pflags = (uint32_t)__shfl_xor((int)flags, 2);
+  XYZZ<Fq2P> o;
+#pragma unroll
+  for (int i = 0; i < Fq28::NL; i++) {
+    o.x.v.l[i] = __shfl_xor(acc.x.v.l[i], 2);
+    o.y.v.l[i] = __shfl_xor(acc.y.v.l[i], 2);
+    o.zz.v.l[i] = __shfl_xor(acc.zz.v.l[i], 2);
+    o.zzz.v.l[i] = __shfl_xor(acc.zzz.v.l[i], 2);
+  }
+  if (sub != 0) return;
+  bool redo_it = ((flags | pflags) & 2u) != 0;
+  if (!redo_it) {
+    if (has && (pflags & 1u)) redo_it = !add_generic(acc, o);  // pair-uniform
+    else if (!has) acc = (pflags & 1u) ? o : XYZZ<Fq2P>::infinity();
+  }
+  if (redo_it) {
+    if (comp == 0) redo[1 + atomicAdd(redo, 1u)] = b;  // k_accum_redo recomputes the bucket with the complete addition
+  } else {
+    st_comp(dst + comp, acc.x.v);
+    st_comp(dst + 2 + comp, acc.y.v);
+    st_comp(dst + 4 + comp, acc.zz.v);
+    st_comp(dst + 6 + comp, acc.zzz.v);
+  }
+}
+
 // the listed buckets again, with the complete addition (rare: repeated bases with equal digits)
 // The kernel also CLEARS the list for the slot's next MSM: every workgroup reads the length first, and the last one to
 // finish (a ticket word behind the list) resets length and ticket -- no hipMemsetAsync launch in front of an accumulation
@@ -1725,6 +1806,10 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
   // of LDS) are then placed while the SIMDs are still free; queued behind it they waited for the accumulation to drain.
   bool heavy_first[MSM_MULTI_MAX];
   hipStream_t heavy_stream[MSM_MULTI_MAX];
+  // (A/B library, ZKMI_HEAVY_DEFER=1: one small proof / MSM by itself queues its heavy launches BEHIND the accumulation launch --
+  // still ordered behind the sort only -- so that the accumulation, the longest link, is submitted ~50 us per MSM earlier.
+  // Measured in round 6: no gain, 2^14 - 2^15 slightly worse; g2_split2_ab.txt)
+  const bool heavy_deferred = host_spin && tot_b <= (1u << 16) && (quad_mask & 8) && heavy_on == 2 && ZK_TUNE("ZKMI_HEAVY_DEFER", 0) != 0;
   auto launch_heavy = [&](int m) {
     const MsmSort& sort = *sorts[m];
     // MSMs of different slots may overlap: partial sums, plan and tickets per slot
@@ -1786,7 +1871,7 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     if (heavy_first[m]) {
       if ((e = hipEventRecord(pre[slots[m]], st)) != hipSuccess) return e;
       if ((e = hipStreamWaitEvent(heavy_stream[m], pre[slots[m]], 0)) != hipSuccess) return e;
-      launch_heavy(m);
+      if (!heavy_deferred) launch_heavy(m);
     }
   }
   auto view_of = [&](int m) {
@@ -1837,6 +1922,14 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
         continue;
       }
 #endif
+      if (host_spin && tot_b <= (1u << 15) && ZK_TUNE("ZKMI_SOLO_SPLIT_G2", 1) != 0) {
+        // one small G2 MSM by itself (the G2 launch of a single small proof): two lane pairs per bucket halve the chain
+        // (2^13 1.99 -> 1.74 ms, 2^14 1.92 -> 1.77, 2^15 2.38 -> 2.2; at 2^16 buckets the chip is full and it costs 0.08 ms:
+        // profiles/r06/experiments/g2_split2_ab.txt)
+        hipLaunchKernelGGL(k_accum_g2_split2<0>, dim3((4 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
+                           sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
+        continue;
+      }
       hipLaunchKernelGGL((k_accum_g2_nc<2, 1>), dim3((2 * tot_b + 63) / 64), dim3(64), 0, st, d_bases[m], sort.begin, sort.count,
                          sort.perm, sort.sorted, bk, tot_b, heavy_thr, redo);
     }
@@ -1919,6 +2012,9 @@ hipError_t MsmEngine<F>::run_device_multi(const MsmSort* const* sorts, const Aff
     }
   }
   if (prof) prof->end(ph_accum, st);  // the phase brackets the accumulation launch(es) only (roofline leg of bench.py)
+  if (heavy_deferred)
+    for (int m = 0; m < nm; m++)
+      if (heavy_first[m]) launch_heavy(m);
 
   // ---- behind it, per MSM: heavy kernels that run in line, redo list, reduction, copy of the partials ----
   const uint32_t segs_per_win = pl.nb >> pl.seg_log;
