@@ -322,3 +322,98 @@ def test_bn254_kzg_opening_oracle_identities():
     assert proof == bn.pt_mul(bn.G1, q_tau)
     assert (tau - z) * q_tau % bn.R == sum(pow(v, j, bn.R) * (bn.eval_polynomial(p, tau) - y) for j, (p, y) in enumerate(zip(polys, ys))) % bn.R
 
+
+
+def test_quad_split_addition_dataflow_model():
+    """The round table of csrc/quad.hpp (one XYZZ coordinate per lane of a quad, four rounds of one product
+    per lane, operands exchanged by quad_perm selectors) as a plain-integer model: four "lanes" holding numbers mod p, the same
+    selector constants, the same per-lane operand choices -- against add-2008-s / dbl-2008-s-1 written out directly, and against
+    the affine group law on real curve points.  It pins the DATAFLOW (which lane multiplies what, which selector moves which
+    value); the HIP code itself is checked on the GPU by test_quad_split_addition_selftest."""
+    import random
+
+    from oracle import bls12_381 as ec
+
+    p = ec.P
+    perm = lambda sel, v: [v[sel[i]] for i in range(4)]
+    ROT2, SWAP, B0, B1 = [2, 3, 0, 1], [1, 0, 3, 2], [0] * 4, [1] * 4
+    P0023, P0110, P0223, P3103 = [0, 0, 2, 3], [0, 1, 1, 0], [0, 2, 2, 3], [3, 1, 0, 3]
+    mul = lambda a, b: [x * y % p for x, y in zip(a, b)]
+    sub = lambda a, b: [(x - y) % p for x, y in zip(a, b)]
+    K = range(4)
+
+    def quad_dbl(v):
+        a1 = [v[k] * 2 % p if k == 1 else v[k] for k in K]
+        m1 = mul(a1, a1)
+        m = [3 * x % p for x in perm(B0, m1)]
+        vv = perm(B1, m1)
+        m2 = mul([m[k] if k == 3 else a1[k] for k in K], [m[k] if k == 3 else vv[k] for k in K])
+        x3 = [(perm(P3103, m2)[k] - 2 * m2[k]) % p for k in K]
+        w = perm(B1, m2)
+        m3 = mul([m[k] if k == 0 else v[k] for k in K], [(m2[k] - x3[k]) % p if k == 0 else w[k] for k in K])
+        y3 = sub(perm(P0023, m3), m3)
+        return [x3[0], y3[1], m2[2], m3[3]]
+
+    def quad_add(v, o):
+        if o[2] == 0:
+            return list(v)
+        if v[2] == 0:
+            return list(o)
+        m1 = mul(v, perm(ROT2, o))
+        d = sub(perm(ROT2, m1), m1)
+        m2 = mul([d[k] if k < 2 else v[k] for k in K], [d[k] if k < 2 else o[k] for k in K])
+        if m2[0] == 0:
+            return quad_dbl(v) if m2[1] == 0 else [0, 0, 0, 0]
+        pp, u1 = perm(B0, m2), perm(P0023, m1)
+        m3 = mul([d[0], u1[1], m2[2], m2[3]], pp)
+        s2, s3 = perm(SWAP, m2), perm(SWAP, m3)
+        x3 = [((s2[k] if k == 0 else m2[k]) - (m3[k] if k == 0 else s3[k]) - 2 * (s3[k] if k == 0 else m3[k])) % p for k in K]
+        s1p = perm(P0110, [d[k] if k == 0 else m1[k] for k in K])
+        ppp = perm(B0, m3)
+        m4 = mul([m3[0], d[1], s1p[2], m3[3]], [s1p[0], (m3[1] - x3[1]) % p, ppp[2], s1p[3]])
+        y3 = sub(m4, perm(P0223, m4))
+        return [x3[0], y3[1], m3[2], m4[3]]
+
+    def ref_add(a, o):
+        x1, y1, zz1, zzz1 = a
+        x2, y2, zz2, zzz2 = o
+        u1, u2, s1, s2 = x1 * zz2 % p, x2 * zz1 % p, y1 * zzz2 % p, y2 * zzz1 % p
+        P_, R_ = (u2 - u1) % p, (s2 - s1) % p
+        PP = P_ * P_ % p
+        PPP, Q = P_ * PP % p, u1 * PP % p
+        x3 = (R_ * R_ - PPP - 2 * Q) % p
+        return [x3, (R_ * (Q - x3) - s1 * PPP) % p, zz1 * zz2 * PP % p, zzz1 * zzz2 * PPP % p]
+
+    def ref_dbl(a):
+        x, y, zz, zzz = a
+        u = 2 * y % p
+        v = u * u % p
+        w, s, m = u * v % p, x * v % p, 3 * x * x % p
+        x3 = (m * m - 2 * s) % p
+        return [x3, (m * (s - x3) - w * y) % p, v * zz % p, w * zzz % p]
+
+    rnd = random.Random(60)
+    for _ in range(50):
+        a, o = [rnd.randrange(p) for _ in range(4)], [rnd.randrange(p) for _ in range(4)]
+        assert quad_add(a, o) == ref_add(a, o)
+        assert quad_dbl(a) == ref_dbl(a)
+        lam = rnd.randrange(1, p)
+        same = [a[0] * lam**2 % p, a[1] * lam**3 % p, a[2] * lam**2 % p, a[3] * lam**3 % p]
+        assert quad_add(a, same) == ref_dbl(a)  # equal points in different representations: the doubling rounds
+        assert quad_add(a, [same[0], -same[1] % p, same[2], same[3]]) == [0, 0, 0, 0]
+    # on the curve: k G + m G through the quad dataflow equals the affine law
+    to_xyzz = lambda pt: [pt[0], pt[1], 1, 1]
+
+    def to_affine(q):
+        zi = pow(q[3], -1, p)
+        zzi = pow(q[2], -1, p)
+        return (q[0] * zzi % p, q[1] * zi % p)
+
+    for k, m in ((1, 1), (2, 3), (5, 11), (123456789, 987654321)):
+        pk, pm = ec.g1_mul(k), ec.g1_mul(m)
+        got = quad_add(to_xyzz(pk), to_xyzz(pm))
+        assert to_affine(got) == tuple(ec.g1_mul(k + m))
+    acc = [0, 0, 0, 0]
+    for k in range(1, 9):  # infinity + G + 2G + ... (the first addition takes the "this is infinity" exit)
+        acc = quad_add(acc, to_xyzz(ec.g1_mul(k)))
+    assert to_affine(acc) == tuple(ec.g1_mul(36))
